@@ -1,0 +1,237 @@
+/*
+ * npb_fields.h -- state schema of the batched plant stepper (public ABI vocabulary).
+ *
+ * One table drives everything that has to agree on "what is a plant's state":
+ *   - the struct-of-arrays layout in HBM (slot index -> column of N plants),
+ *   - the field ids accepted by npb_get_field()/npb_set_field() (include/npb.h),
+ *   - the per-subsystem register structs the HIP kernel streams through,
+ *   - the CPU oracle's array-of-structs plant record (oracle/),
+ *   - the test harness that compares every field with the reference's own
+ *     attribute of the same meaning (the quoted path, relative to the
+ *     reference's NuclearPlantSimulator object; "" = no single reference leaf).
+ *
+ * X-macro kinds (each section macro takes F, A, I):
+ *   F(name, "path")          one fp64 scalar
+ *   A(name, count, "path")   fp64 array; path uses {k} for the element index
+ *   I(name, "path")          one int32 (flags, enums, counters)
+ * Inside a section all fp64 members precede all int32 members.
+ * Path placeholders: {i} = 0-based instance, {j} = 1-based instance, {k} = array index.
+ *
+ * Only CARRIED state (read before it is overwritten in the next step) and the
+ * handful of outputs needed by get_observation() live here; everything else is
+ * recomputed inside the step.  The algorithmic-bytes figure used for the
+ * roofline is derived from this table (npb_state_bytes()).
+ */
+#ifndef NPB_FIELDS_H
+#define NPB_FIELDS_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#define NPB_NUM_SG 3
+#define NPB_NUM_TSP 7
+#define NPB_NUM_PUMPS 4
+#define NPB_NUM_STAGES 14
+#define NPB_NUM_BEARINGS 4
+#define NPB_NUM_EJECTORS 2
+
+/* ---- primary side: ReactorState + heat source + simulator-level carried scalars
+ * reference: systems/primary/__init__.py:48-106, heat_sources/constant_heat_source.py:47-66,
+ *            simulator/core/sim.py:391-399,495 */
+#define NPB_PRIM_FIELDS(F, A, I) \
+  F(neutron_flux,          "primary_physics.state.neutron_flux") \
+  F(reactivity,            "primary_physics.state.reactivity") \
+  A(precursors, 6,         "primary_physics.state.delayed_neutron_precursors[{k}]") \
+  F(fuel_temperature,      "primary_physics.state.fuel_temperature") \
+  F(coolant_temperature,   "primary_physics.state.coolant_temperature") \
+  F(coolant_pressure,      "primary_physics.state.coolant_pressure") \
+  F(coolant_flow_rate,     "primary_physics.state.coolant_flow_rate") \
+  F(coolant_void_fraction, "primary_physics.state.coolant_void_fraction") \
+  F(steam_temperature,     "primary_physics.state.steam_temperature") \
+  F(steam_pressure,        "primary_physics.state.steam_pressure") \
+  F(steam_flow_rate,       "primary_physics.state.steam_flow_rate") \
+  F(feedwater_flow_rate,   "primary_physics.state.feedwater_flow_rate") \
+  F(control_rod_position,  "primary_physics.state.control_rod_position") \
+  F(steam_valve_position,  "primary_physics.state.steam_valve_position") \
+  F(boron_concentration,   "primary_physics.state.boron_concentration") \
+  F(xenon_concentration,   "primary_physics.state.xenon_concentration") \
+  F(iodine_concentration,  "primary_physics.state.iodine_concentration") \
+  F(samarium_concentration,"primary_physics.state.samarium_concentration") \
+  F(burnable_poison_worth, "primary_physics.state.burnable_poison_worth") \
+  F(fuel_burnup,           "primary_physics.state.fuel_burnup") \
+  F(power_level,           "primary_physics.state.power_level") \
+  F(thermal_power_mw,      "primary_physics.thermal_power_mw") \
+  F(total_reactivity_pcm,  "primary_physics.total_reactivity_pcm") \
+  F(hs_setpoint_percent,   "primary_physics.heat_source.power_setpoint_percent") \
+  F(hs_filtered_noise_mw,  "primary_physics.heat_source.filtered_noise_mw") \
+  F(last_heat_removal_factor, "_last_heat_removal_factor") \
+  F(sim_time,              "time") \
+  I(scram_status,          "primary_physics.state.scram_status") \
+  I(has_heat_removal_factor, "")
+
+/* ---- one U-tube steam generator (x3)
+ * reference: steam_generator/steam_generator.py:87-112, tsp_fouling_model.py:126-147,175-190,
+ *            tube_interior_fouling.py:67-79, fouling_model_base.py:84-92 */
+#define NPB_SG_FIELDS(F, A, I) \
+  F(secondary_pressure,   "secondary_physics.steam_generator_system.steam_generators[{i}].secondary_pressure") \
+  F(steam_quality,        "secondary_physics.steam_generator_system.steam_generators[{i}].steam_quality") \
+  F(water_level,          "secondary_physics.steam_generator_system.steam_generators[{i}].water_level") \
+  F(steam_flow_rate,      "secondary_physics.steam_generator_system.steam_generators[{i}].steam_flow_rate") \
+  F(secondary_temperature,"secondary_physics.steam_generator_system.steam_generators[{i}].secondary_temperature") \
+  F(heat_transfer_rate,   "secondary_physics.steam_generator_system.steam_generators[{i}].heat_transfer_rate") \
+  F(tube_wall_temp,       "secondary_physics.steam_generator_system.steam_generators[{i}].tube_wall_temp") \
+  A(tsp_magnetite, 7,     "secondary_physics.steam_generator_system.steam_generators[{i}].tsp_fouling.deposits.magnetite_thickness[{k}]") \
+  A(tsp_copper, 7,        "secondary_physics.steam_generator_system.steam_generators[{i}].tsp_fouling.deposits.copper_thickness[{k}]") \
+  A(tsp_silica, 7,        "secondary_physics.steam_generator_system.steam_generators[{i}].tsp_fouling.deposits.silica_thickness[{k}]") \
+  A(tsp_biological, 7,    "secondary_physics.steam_generator_system.steam_generators[{i}].tsp_fouling.deposits.biological_thickness[{k}]") \
+  F(tsp_fouling_fraction, "secondary_physics.steam_generator_system.steam_generators[{i}].tsp_fouling.fouling_fraction") \
+  F(tsp_pressure_drop_ratio, "secondary_physics.steam_generator_system.steam_generators[{i}].tsp_fouling.pressure_drop_ratio") \
+  F(tsp_ht_degradation,   "secondary_physics.steam_generator_system.steam_generators[{i}].tsp_fouling.heat_transfer_degradation") \
+  F(tsp_operating_years,  "secondary_physics.steam_generator_system.steam_generators[{i}].tsp_fouling.operating_years") \
+  F(scale_thickness,      "secondary_physics.steam_generator_system.steam_generators[{i}].tube_interior_fouling.scale_thickness") \
+  F(scale_iron_oxide,     "secondary_physics.steam_generator_system.steam_generators[{i}].tube_interior_fouling.scale_composition['iron_oxide']") \
+  F(scale_crud,           "secondary_physics.steam_generator_system.steam_generators[{i}].tube_interior_fouling.scale_composition['crud_deposits']") \
+  F(scale_corrosion,      "secondary_physics.steam_generator_system.steam_generators[{i}].tube_interior_fouling.scale_composition['corrosion_products']") \
+  F(scale_thermal_resistance, "secondary_physics.steam_generator_system.steam_generators[{i}].tube_interior_fouling.scale_thermal_resistance") \
+  F(scale_operating_years,"secondary_physics.steam_generator_system.steam_generators[{i}].tube_interior_fouling.operating_years") \
+  I(tsp_shutdown_required,"secondary_physics.steam_generator_system.steam_generators[{i}].tsp_fouling.shutdown_required")
+
+/* ---- one feedwater pump with its lubrication system (x4: 3 running + 1 spare)
+ * reference: feedwater/pump_system.py:62-90 (FeedwaterPumpState), primary/coolant/pump_models.py:30-48,
+ *            feedwater/pump_lubrication.py:204-215, lubrication_base.py:150-176
+ * status codes follow PumpStatus order (pump_models.py:21-27): 0 RUNNING 1 STOPPED 2 STARTING 3 STOPPING 4 TRIPPED */
+#define NPB_PUMP_FIELDS(F, A, I) \
+  F(speed_percent,      "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.speed_percent") \
+  F(speed_setpoint,     "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.speed_setpoint") \
+  F(flow_rate,          "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.flow_rate") \
+  F(power_consumption,  "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.power_consumption") \
+  F(flow_demand,        "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].flow_demand") \
+  F(suction_pressure,   "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.suction_pressure") \
+  F(discharge_pressure, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.discharge_pressure") \
+  F(npsh_available,     "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.npsh_available") \
+  F(differential_pressure, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.differential_pressure") \
+  F(cavitation_intensity, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.cavitation_intensity") \
+  F(cavitation_damage,  "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.cavitation_damage") \
+  F(cavitation_time,    "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.cavitation_time") \
+  F(motor_temperature,  "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.motor_temperature") \
+  F(vibration_level,    "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.vibration_level") \
+  F(oil_level,          "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.oil_level") \
+  F(oil_temperature,    "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.oil_temperature") \
+  F(oil_contamination,  "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.oil_contamination_level") \
+  F(oil_moisture,       "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.oil_moisture_content") \
+  F(oil_acidity,        "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.oil_acidity_number") \
+  F(oil_viscosity_change, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.oil_viscosity_change") \
+  F(antioxidant_level,  "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.antioxidant_level") \
+  F(anti_wear_level,    "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.anti_wear_additive_level") \
+  F(corrosion_inhibitor_level, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.corrosion_inhibitor_level") \
+  F(lubrication_effectiveness, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.lubrication_effectiveness") \
+  F(wear_impeller,      "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.component_wear['impeller']") \
+  F(wear_motor_bearings,"secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.component_wear['motor_bearings']") \
+  F(wear_pump_bearings, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.component_wear['pump_bearings']") \
+  F(wear_thrust_bearing,"secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.component_wear['thrust_bearing']") \
+  F(wear_mechanical_seals, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.component_wear['mechanical_seals']") \
+  F(wear_coupling_system, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.component_wear['coupling_system']") \
+  F(efficiency_degradation, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.pump_efficiency_degradation") \
+  F(flow_degradation,   "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.pump_flow_degradation") \
+  F(head_degradation,   "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.pump_head_degradation") \
+  F(vibration_increase, "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.vibration_increase") \
+  F(seal_leakage_rate,  "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].lubrication_system.seal_leakage_rate") \
+  I(status,             "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.status") \
+  I(available,          "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.available") \
+  I(trip_active,        "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.trip_active") \
+  I(trip_reason,        "")
+
+/* ---- feedwater system level: three-element control, shared cavitation monitor, protection timers
+ * reference: feedwater/level_control.py:39-44,137-150, performance_monitoring.py:91-113,
+ *            protection_system.py:40-57 and the trip_timers dict, feedwater/physics.py:157-161 */
+#define NPB_FW_FIELDS(F, A, I) \
+  A(level_integral_errors, 3, "secondary_physics.feedwater_system.level_control.level_integral_errors[{k}]") \
+  A(previous_level_errors, 3, "secondary_physics.feedwater_system.level_control.previous_level_errors[{k}]") \
+  F(quality_integral_error,   "secondary_physics.feedwater_system.level_control.quality_compensator.quality_integral_error") \
+  F(total_flow_rate,          "secondary_physics.feedwater_system.total_flow_rate") \
+  F(total_power_consumption,  "secondary_physics.feedwater_system.total_power_consumption") \
+  F(cav_accumulated_damage,   "secondary_physics.feedwater_system.diagnostics.cavitation_model.accumulated_damage") \
+  F(cav_time_in_cavitation,   "secondary_physics.feedwater_system.diagnostics.cavitation_model.time_in_cavitation") \
+  F(overall_health_score,     "secondary_physics.feedwater_system.diagnostics.overall_health_score") \
+  F(npsh_low_low_timer,       "secondary_physics.feedwater_system.protection_system.npsh_protection.npsh_low_low_timer") \
+  F(timer_low_flow,           "secondary_physics.feedwater_system.protection_system.trip_timers['low_flow']") \
+  F(timer_high_flow,          "secondary_physics.feedwater_system.protection_system.trip_timers['high_flow']") \
+  F(timer_bearing_temp,       "secondary_physics.feedwater_system.protection_system.trip_timers['bearing_temp']") \
+  F(timer_motor_temp,         "secondary_physics.feedwater_system.protection_system.trip_timers['motor_temp']") \
+  F(timer_vibration,          "secondary_physics.feedwater_system.protection_system.trip_timers['vibration']") \
+  I(system_availability,      "secondary_physics.feedwater_system.system_availability") \
+  I(running_mask,             "=sum(1 << (int(p[-1]) - 1) for p in root.secondary_physics.feedwater_system.pump_system.running_pumps)") \
+  I(cav_events_count,         "=len(root.secondary_physics.feedwater_system.diagnostics.cavitation_model.cavitation_events)") \
+  I(system_trip_active,       "secondary_physics.feedwater_system.protection_system.system_trip_active") \
+  I(npsh_low_low_trip_active, "secondary_physics.feedwater_system.protection_system.npsh_protection.npsh_low_low_trip_active")
+
+/* ---- secondary-system level carried scalars and the outputs get_observation() reads
+ * reference: systems/secondary/__init__.py:300-310,385-398,447-453,921-927 */
+#define NPB_SEC_FIELDS(F, A, I) \
+  F(previous_feedwater_temp,  "secondary_physics._previous_feedwater_temp") \
+  F(electrical_power_output,  "secondary_physics.electrical_power_output") \
+  F(thermal_efficiency,       "secondary_physics.thermal_efficiency") \
+  F(total_steam_flow,         "secondary_physics.total_steam_flow") \
+  F(total_heat_transfer,      "secondary_physics.total_heat_transfer") \
+  F(total_feedwater_flow,     "secondary_physics.total_feedwater_flow") \
+  F(load_demand,              "secondary_physics.load_demand") \
+  F(cooling_water_temperature,"secondary_physics.cooling_water_temperature") \
+  F(operating_hours,          "secondary_physics.operating_hours") \
+  F(sg_avg_pressure,          "secondary_physics.steam_generator_system.average_steam_pressure") \
+  F(sg_avg_temperature,       "secondary_physics.steam_generator_system.average_steam_temperature") \
+  F(sg_avg_quality,           "secondary_physics.steam_generator_system.average_steam_quality") \
+  I(has_previous_sg_conditions, "") \
+  I(sg_system_availability,   "secondary_physics.steam_generator_system.system_availability")
+
+/* section list: S(member, TYPE, struct_type, count) */
+#define NPB_SECTIONS(S) \
+  S(prim, PRIM, npb_prim_t, 1) \
+  S(sg,   SG,   npb_sg_t,   NPB_NUM_SG) \
+  S(pump, PUMP, npb_pump_t, NPB_NUM_PUMPS) \
+  S(fw,   FW,   npb_fw_t,   1) \
+  S(sec,  SEC,  npb_sec_t,  1)
+
+/* ------------------------------------------------------------------ structs */
+#define NPB__F(name, path)        double name;
+#define NPB__A(name, count, path) double name[count];
+#define NPB__I(name, path)        int32_t name;
+#define NPB__NOF(name, path)
+#define NPB__NOA(name, count, path)
+#define NPB__NOI(name, path)
+#define NPB__CNTF(name, path)        + 1
+#define NPB__CNTA(name, count, path) + (count)
+#define NPB__CNTI(name, path)        + 1
+
+/* per section: struct npb_<sec>_t (all fp64 members first, then all int32),
+ * NPB_<SEC>_NF64 / NPB_<SEC>_NI32 = slots of one instance */
+#define NPB__DEFINE(member, T, stype, count) \
+  typedef struct stype { \
+    NPB_##T##_FIELDS(NPB__F, NPB__A, NPB__NOI) \
+    NPB_##T##_FIELDS(NPB__NOF, NPB__NOA, NPB__I) \
+  } stype; \
+  enum { NPB_##T##_NF64 = (0 NPB_##T##_FIELDS(NPB__CNTF, NPB__CNTA, NPB__NOI)), \
+         NPB_##T##_NI32 = (0 NPB_##T##_FIELDS(NPB__NOF, NPB__NOA, NPB__CNTI)), \
+         NPB_##T##_COUNT = (count) };
+NPB_SECTIONS(NPB__DEFINE)
+
+/* base slot of each section in the global fp64 / int32 column tables
+ * (section-major, then instance, then member order) */
+enum {
+#define NPB__BASEF(member, T, stype, count) \
+  NPB_##T##_F64_BASE, NPB_##T##_F64_LAST_ = NPB_##T##_F64_BASE + (count) * NPB_##T##_NF64 - 1,
+  NPB_SECTIONS(NPB__BASEF)
+  NPB_TOTAL_F64
+};
+enum {
+#define NPB__BASEI(member, T, stype, count) \
+  NPB_##T##_I32_BASE, NPB_##T##_I32_LAST_ = NPB_##T##_I32_BASE + (count) * NPB_##T##_NI32 - 1,
+  NPB_SECTIONS(NPB__BASEI)
+  NPB_TOTAL_I32
+};
+
+/* slot of a member inside its section instance (fp64 members are laid out first) */
+#define NPB_F64_SLOT(stype, member) ((int)(offsetof(stype, member) / sizeof(double)))
+#define NPB_I32_SLOT(stype, T, member) \
+  ((int)((offsetof(stype, member) - (size_t)NPB_##T##_NF64 * sizeof(double)) / sizeof(int32_t)))
+
+#endif /* NPB_FIELDS_H */

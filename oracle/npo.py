@@ -1,0 +1,150 @@
+"""ctypes binding of the CPU oracle (oracle/libnpo.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libnpo.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build())
+        L.npo_get_f64.restype = ctypes.c_double
+        L.npo_get_f64.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.npo_set_f64.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+        L.npo_get_i32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.npo_set_i32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.npo_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.npo_get_all.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.npo_step_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 10
+        L.npo_observe_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Params:
+    """npb_params_t as a raw buffer with attribute access by name."""
+
+    def __init__(self):
+        from nuclear_sim_amd.schema import PARAMS
+        L = lib()
+        self._names = [p[0] for p in PARAMS]
+        self._buf = np.zeros(L.npo_params_size(), dtype=np.uint8)
+        L.npo_params_default(_ptr(self._buf))
+        nd = len(self._names)
+        assert self._buf.size == nd * 8 + 8 + 4 * 4, (self._buf.size, nd)
+
+    def _dview(self):
+        return self._buf[: (len(self._names) + 1) * 8].view(np.float64)
+
+    def _iview(self):
+        return self._buf[(len(self._names) + 1) * 8:].view(np.int32)
+
+    def __getattr__(self, k):
+        if k.startswith("_"):
+            raise AttributeError(k)
+        if k in self._names:
+            return float(self._dview()[self._names.index(k)])
+        if k == "dt":
+            return float(self._dview()[len(self._names)])
+        ints = ["heat_source", "hs_noise_enabled", "mode"]
+        if k in ints:
+            return int(self._iview()[ints.index(k)])
+        raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        if k.startswith("_"):
+            return object.__setattr__(self, k, v)
+        if k in self._names:
+            self._dview()[self._names.index(k)] = v
+        elif k == "dt":
+            self._dview()[len(self._names)] = v
+        elif k in ("heat_source", "hs_noise_enabled", "mode"):
+            self._iview()[["heat_source", "hs_noise_enabled", "mode"].index(k)] = v
+        else:
+            raise AttributeError(k)
+
+    @property
+    def ptr(self):
+        return _ptr(self._buf)
+
+
+class OraclePlants:
+    """n plants stepped by the scalar C oracle."""
+
+    def __init__(self, n, params=None):
+        from nuclear_sim_amd.schema import SCHEMA
+        self.schema = SCHEMA
+        self.L = lib()
+        assert self.L.npo_num_f64() == SCHEMA.total_f64 and self.L.npo_num_i32() == SCHEMA.total_i32
+        self.n = n
+        self.params = params or Params()
+        self._buf = np.zeros(n * self.L.npo_plant_size(), dtype=np.uint8)
+        self.L.npo_init(_ptr(self._buf), n, self.params.ptr)
+
+    def get(self, name, instance=0, k=0, plant=0):
+        kind, slot = self.schema.slot(name, instance, k)
+        if kind == "f64":
+            return self.L.npo_get_f64(_ptr(self._buf), plant, slot)
+        return self.L.npo_get_i32(_ptr(self._buf), plant, slot)
+
+    def set(self, name, value, instance=0, k=0, plant=None):
+        kind, slot = self.schema.slot(name, instance, k)
+        plants = range(self.n) if plant is None else [plant]
+        vals = np.broadcast_to(np.asarray(value), (len(plants),)) if plant is None else [value]
+        for p, v in zip(plants, vals):
+            if kind == "f64":
+                self.L.npo_set_f64(_ptr(self._buf), p, slot, float(v))
+            else:
+                self.L.npo_set_i32(_ptr(self._buf), p, slot, int(v))
+
+    def state(self, plant=0):
+        f = np.zeros(self.schema.total_f64)
+        i = np.zeros(self.schema.total_i32, dtype=np.int32)
+        self.L.npo_get_all(_ptr(self._buf), plant, _ptr(f), _ptr(i))
+        return f, i
+
+    def set_state(self, f64, i32, plant=0):
+        for s, v in enumerate(f64):
+            self.L.npo_set_f64(_ptr(self._buf), plant, s, float(v))
+        for s, v in enumerate(i32):
+            self.L.npo_set_i32(_ptr(self._buf), plant, s, int(v))
+
+    def observe(self):
+        obs = np.zeros((self.n, 22))
+        self.L.npo_observe_batch(_ptr(self._buf), self.n, _ptr(obs))
+        return obs
+
+    def step(self, action=None, magnitude=None, setpoint=None, noise_z=None, cw_temp=None):
+        n = self.n
+
+        def col(a, dt):
+            if a is None:
+                return None
+            return np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=dt), (n,)))
+        a = col(action, np.int32); m = col(magnitude, np.float64); sp = col(setpoint, np.float64)
+        z = col(noise_z, np.float64); cw = col(cw_temp, np.float64)
+        obs = np.zeros((n, 22)); rew = np.zeros(n); done = np.zeros(n, dtype=np.uint8)
+        flags = np.zeros(n, dtype=np.uint32); info = np.zeros((n, 10))
+        self.L.npo_step_batch(_ptr(self._buf), n, self.params.ptr, _ptr(a), _ptr(m), _ptr(sp), _ptr(z), _ptr(cw),
+                              _ptr(obs), _ptr(rew), _ptr(done), _ptr(flags), _ptr(info))
+        return obs, rew, done, flags, info

@@ -1,0 +1,59 @@
+/*
+ * npo_api.c -- C entry points of the CPU oracle (built into oracle/libnpo.so).
+ * TEST INFRASTRUCTURE ONLY: loaded by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg; never by the product path.
+ */
+#include <stdlib.h>
+#include "npo_step.h"
+#include "npo_init.h"
+
+#define NPO_API __attribute__((visibility("default")))
+
+NPO_API int npo_plant_size(void) { return (int)sizeof(npo_plant_t); }
+NPO_API int npo_num_f64(void) { return NPB_TOTAL_F64; }
+NPO_API int npo_num_i32(void) { return NPB_TOTAL_I32; }
+NPO_API int npo_params_size(void) { return (int)sizeof(npb_params_t); }
+NPO_API void npo_params_default(npb_params_t *p) { npb_params_default(p); }
+
+/* plants: n contiguous npo_plant_t records */
+NPO_API void npo_init(npo_plant_t *plants, int n, const npb_params_t *P) {
+  for (int i = 0; i < n; i++) npo_plant_init(&plants[i], P);
+}
+NPO_API double npo_get_f64(npo_plant_t *plants, int plant, int slot) { return *npo_f64_slot(&plants[plant], slot); }
+NPO_API void npo_set_f64(npo_plant_t *plants, int plant, int slot, double v) { *npo_f64_slot(&plants[plant], slot) = v; }
+NPO_API int npo_get_i32(npo_plant_t *plants, int plant, int slot) { return *npo_i32_slot(&plants[plant], slot); }
+NPO_API void npo_set_i32(npo_plant_t *plants, int plant, int slot, int v) { *npo_i32_slot(&plants[plant], slot) = v; }
+/* gather all slots of one plant (for trajectory comparison) */
+NPO_API void npo_get_all(npo_plant_t *plants, int plant, double *f64, int32_t *i32) {
+  for (int s = 0; s < NPB_TOTAL_F64; s++) f64[s] = *npo_f64_slot(&plants[plant], s);
+  for (int s = 0; s < NPB_TOTAL_I32; s++) i32[s] = *npo_i32_slot(&plants[plant], s);
+}
+
+/* One step for n plants. Per-plant input columns may be NULL (defaults: NO_ACTION,
+ * magnitude 1, setpoint/cooling unchanged, z = 0). Outputs may be NULL. */
+NPO_API void npo_step_batch(npo_plant_t *plants, int n, const npb_params_t *P,
+                            const int32_t *action, const double *magnitude, const double *setpoint,
+                            const double *noise_z, const double *cw_temp,
+                            double *obs, double *reward, uint8_t *done, uint32_t *trip_flags, double *info) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int i = 0; i < n; i++) {
+    npo_inputs_t in;
+    in.action = action ? action[i] : 8;
+    in.magnitude = magnitude ? magnitude[i] : 1.0;
+    in.power_setpoint = setpoint ? setpoint[i] : NAN;
+    in.noise_z = noise_z ? noise_z[i] : 0.0;
+    in.cooling_water_temp = cw_temp ? cw_temp[i] : NAN;
+    npo_outputs_t o;
+    npo_step(&plants[i], P, &in, &o);
+    if (obs) memcpy(obs + (size_t)i * NPB_OBS_DIM, o.obs, sizeof(o.obs));
+    if (reward) reward[i] = o.reward;
+    if (done) done[i] = o.done;
+    if (trip_flags) trip_flags[i] = o.trip_flags;
+    if (info) memcpy(info + (size_t)i * NPB_INFO_DIM, o.info, sizeof(o.info));
+  }
+}
+NPO_API void npo_observe_batch(npo_plant_t *plants, int n, double *obs) {
+  for (int i = 0; i < n; i++) npo_observation(&plants[i], obs + (size_t)i * NPB_OBS_DIM);
+}

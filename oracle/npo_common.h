@@ -1,0 +1,72 @@
+/*
+ * npo_common.h -- helpers shared by the CPU oracle's subsystem restatements.
+ *
+ * TEST INFRASTRUCTURE ONLY.  oracle/ is a plain-C, scalar, fp64, one-plant-per-call
+ * restatement of the reference's per-timestep physics path
+ * (NuclearPlantSimulator.step, simulator/core/sim.py:130-258).  It exists to check
+ * the HIP stepper; nothing in the product path may include, link or call it.
+ * It is pinned against golden vectors generated from the importable Python
+ * reference (tests/golden/, generator: oracle/ref_harness/make_golden.py).
+ *
+ * The helpers reproduce the *semantics* of the numpy / builtin calls the
+ * reference uses on Python scalars:
+ *   np.clip(x, lo, hi)  -> npo_clip   (propagates NaN like numpy)
+ *   max(a, b), min(a, b) (Python builtins: keep the FIRST argument unless the
+ *                         second compares strictly greater / smaller)
+ */
+#ifndef NPO_COMMON_H
+#define NPO_COMMON_H
+
+#include <math.h>
+#include <string.h>
+#include <stdint.h>
+#include "../include/npb_fields.h"
+#include "../include/npb_params.h"
+
+#ifndef NPO_FN
+#define NPO_FN static inline
+#endif
+
+#define NPO_PI 3.141592653589793
+
+NPO_FN double npo_clip(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+NPO_FN double npo_pymax(double a, double b) { return (b > a) ? b : a; }
+NPO_FN double npo_pymin(double a, double b) { return (b < a) ? b : a; }
+
+/* per-step inputs of one plant (what step() receives, sim.py:130-133, plus the
+ * pre-drawn standard-normal sample that replaces ConstantHeatSource's MT19937 draw) */
+typedef struct npo_inputs_t {
+  int32_t action;          /* ControlAction value 0..14 (primary/__init__.py:28-45); 8 = NO_ACTION */
+  double magnitude;        /* step(magnitude=...) */
+  double power_setpoint;   /* heat_source.set_power_setpoint(x) before the step; NaN = leave unchanged */
+  double noise_z;          /* standard normal sample for constant_heat_source.py:178 */
+  double cooling_water_temp; /* step(cooling_water_temp=...); NaN = leave unchanged */
+} npo_inputs_t;
+
+enum { NPB_OBS_DIM = 22, NPB_INFO_DIM = 10 };
+/* info columns (sim.py:199-250) */
+enum {
+  NPB_INFO_THERMAL_POWER = 0, NPB_INFO_REACTIVITY_PCM, NPB_INFO_ELECTRICAL_POWER,
+  NPB_INFO_THERMAL_EFFICIENCY, NPB_INFO_STEAM_FLOW, NPB_INFO_STEAM_PRESSURE,
+  NPB_INFO_CONDENSER_PRESSURE, NPB_INFO_CONDENSER_HEAT_REJECTION, NPB_INFO_TIME,
+  NPB_INFO_FEEDWATER_FLOW
+};
+/* trip flag bits */
+enum {
+  NPB_TRIP_SCRAM = 1u << 0,        /* scram_status latched */
+  NPB_TRIP_SCRAM_FIRED = 1u << 1,  /* scram fired on this step (== done) */
+  NPB_TRIP_NAN_RESET = 1u << 2,    /* thermal_hydraulics.py:247 reset taken */
+  NPB_TRIP_TURBINE = 1u << 3,      /* turbine protection trip_active */
+  NPB_TRIP_FW_SYSTEM = 1u << 4,    /* feedwater protection system_trip_active */
+  NPB_TRIP_FW_PUMP0 = 1u << 8      /* bits 8..11: feedwater pump i tripped */
+};
+
+typedef struct npo_outputs_t {
+  double obs[NPB_OBS_DIM];
+  double reward;
+  double info[NPB_INFO_DIM];
+  uint32_t trip_flags;
+  uint8_t done;
+} npo_outputs_t;
+
+#endif

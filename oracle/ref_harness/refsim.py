@@ -1,0 +1,114 @@
+"""Harness that imports the *reference* simulator from /root/reference (this
+container only; the reference never travels to the GPU box) so that golden
+vectors can be generated and the C oracle can be checked leaf-by-leaf.
+
+Not part of the product. Not imported by anything outside oracle/ and the
+fixture generator scripts.
+
+What it does beyond a plain import:
+  * puts /root/reference/nuclear_simulator on sys.path (the reference imports
+    itself as top-level `systems.*` / `simulator.*`, sim.py:11-13);
+  * attaches a `from_dict` classmethod to the reference's config dataclasses,
+    because `dataclass_wizard` (requirements.txt:10) is not installed here and
+    `SecondaryReactorPhysics.__init__` needs it (secondary/__init__.py:240-243);
+  * silences the reference's print() chatter;
+  * neutralises the pH controller's *unseeded global* numpy RNG
+    (ph_control_system.py:278,288,409-420) so runs are reproducible:
+    normal() -> 0, random() -> 1.0.
+"""
+import contextlib
+import dataclasses
+import io
+import os
+import sys
+import typing
+
+REF_ROOT = os.environ.get("NPB_REFERENCE_ROOT", "/root/reference")
+REF_PKG = os.path.join(REF_ROOT, "nuclear_simulator")
+
+
+def available() -> bool:
+    return os.path.isdir(REF_PKG)
+
+
+def _build_dataclass(cls, data):
+    """Recursive dict -> dataclass (snake_case keys only), the subset of
+    dataclass_wizard.from_dict the reference relies on."""
+    if not dataclasses.is_dataclass(cls) or not isinstance(data, dict):
+        return data
+    hints = typing.get_type_hints(cls)
+    kwargs = {}
+    for f in dataclasses.fields(cls):
+        if f.name not in data or not f.init:
+            continue
+        v = data[f.name]
+        t = hints.get(f.name, None)
+        origin = typing.get_origin(t)
+        if dataclasses.is_dataclass(t) and isinstance(v, dict):
+            v = _build_dataclass(t, v)
+        elif origin in (list, typing.List) and isinstance(v, list):
+            (arg,) = typing.get_args(t) or (None,)
+            if arg is not None and dataclasses.is_dataclass(arg):
+                v = [_build_dataclass(arg, x) for x in v]
+        elif origin is typing.Union:
+            for arg in typing.get_args(t):
+                if dataclasses.is_dataclass(arg) and isinstance(v, dict):
+                    v = _build_dataclass(arg, v)
+                    break
+        kwargs[f.name] = v
+    return cls(**kwargs)
+
+
+_ready = False
+
+
+def setup():
+    global _ready
+    if _ready:
+        return
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REF_PKG)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    if REF_PKG not in sys.path:
+        sys.path.insert(0, REF_PKG)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import systems.secondary.config as sc
+        import systems.secondary.feedwater.config as fc
+        import systems.secondary.condenser.config as cc
+        import systems.secondary.turbine.config as tc
+        import systems.secondary.steam_generator.config as gc
+    for cls in (sc.SecondarySystemConfig, fc.FeedwaterConfig, cc.CondenserConfig,
+                tc.TurbineConfig, gc.SteamGeneratorConfig):
+        if not hasattr(cls, "from_dict"):
+            cls.from_dict = classmethod(_build_dataclass)
+    # neutralise the unseeded global RNG used only by the pH controller
+    import numpy as np
+    np.random.normal = lambda *a, **k: 0.0
+    np.random.random = lambda *a, **k: 1.0
+    _ready = True
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def make_sim(dt=1.0, heat_source="constant", noise=False, noise_std_percent=0.1,
+             noise_seed=42, secondary=None, state_management=False):
+    """Construct a reference NuclearPlantSimulator."""
+    setup()
+    with quiet():
+        from simulator.core.sim import NuclearPlantSimulator
+        from systems.primary.reactor.heat_sources import ConstantHeatSource, ReactorHeatSource
+        if heat_source == "constant":
+            hs = ConstantHeatSource(3000.0, noise_enabled=noise,
+                                    noise_std_percent=noise_std_percent,
+                                    noise_seed=noise_seed)
+        else:
+            hs = ReactorHeatSource(3000.0)
+        cfg = {"secondary_system": secondary or {}}
+        sim = NuclearPlantSimulator(dt=dt, heat_source=hs, secondary_config=cfg,
+                                    enable_state_management=state_management)
+    return sim

@@ -1,0 +1,94 @@
+"""Run a scenario on the *reference* simulator and record a trace: per-step inputs,
+obs/reward/done/info and the value of every schema column's reference attribute.
+Harness-only (needs /root/reference; see refsim.py).
+
+Scenario dict keys:
+  name, steps, dt, heat_source ("constant"|"reactor"), noise (bool), noise_seed,
+  noise_std_percent, secondary (IC override dict for SecondarySystemConfig.from_dict),
+  equilibrium: (power, rods) -> start ReactorState from create_equilibrium_state,
+  actions: {step: (action_id, magnitude)} or callable(step)->(action, magnitude),
+  setpoints: callable(step)->percent or None,
+  cooling: callable(step)->degC or None,
+  pokes: {step: [(python_path, value), ...]} applied to the sim before that step.
+"""
+import enum
+
+import numpy as np
+
+from . import refsim
+from .leaves import resolve
+
+
+def _val(sim, path):
+    if not path:
+        return np.nan
+    try:
+        v = resolve(sim, path)
+    except (AttributeError, KeyError, IndexError):
+        return np.nan
+    if isinstance(v, enum.Enum):
+        # numeric enums by value, string-valued enums by declaration index
+        v = v.value if isinstance(v.value, (int, float)) else list(type(v)).index(v)
+    try:
+        return float(v)
+    except (TypeError, ValueError):
+        return np.nan
+
+
+def run_reference(sc, columns):
+    """columns: SCHEMA.columns(). Returns dict of arrays."""
+    refsim.setup()
+    sim = refsim.make_sim(dt=sc.get("dt", 1.0), heat_source=sc.get("heat_source", "constant"),
+                          noise=sc.get("noise", False), noise_std_percent=sc.get("noise_std_percent", 0.1),
+                          noise_seed=sc.get("noise_seed", 42), secondary=sc.get("secondary"))
+    from systems.primary import ControlAction
+    if sc.get("equilibrium") is not None:
+        from systems.primary.reactor.reactivity_model import create_equilibrium_state
+        p, rods = sc["equilibrium"]
+        with refsim.quiet():
+            st = create_equilibrium_state(power_level=p, control_rod_position=rods, auto_balance=True)
+        sim.primary_physics.state = st
+        sim.state = st
+    for path, v in sc.get("init_pokes", []):
+        exec("sim.%s = v" % path, {"sim": sim, "v": v})
+    T = sc["steps"]
+    paths = [c[3] for c in columns]
+    state = np.full((T + 1, len(paths)), np.nan)
+    state[0] = [_val(sim, p) for p in paths]
+    obs = np.zeros((T, 22)); rew = np.zeros(T); done = np.zeros(T, dtype=np.uint8)
+    info = np.full((T, 10), np.nan)
+    act = np.full(T, 8, dtype=np.int32); mag = np.ones(T); sp = np.full(T, np.nan)
+    cw = np.full(T, np.nan); z = np.zeros(T)
+    # pre-draw the heat-source noise exactly as numpy's legacy RandomState would
+    if sc.get("noise", False):
+        z[:] = np.random.RandomState(sc.get("noise_seed", 42)).standard_normal(T)
+    actions = sc.get("actions")
+    for t in range(T):
+        for path, v in sc.get("pokes", {}).get(t, []):
+            exec("sim.%s = v" % path, {"sim": sim, "v": v})
+        if actions is not None:
+            a = actions(t) if callable(actions) else actions.get(t)
+            if a is not None:
+                act[t], mag[t] = a
+        if sc.get("setpoints") is not None:
+            v = sc["setpoints"](t)
+            if v is not None:
+                sp[t] = v
+                sim.primary_physics.heat_source.set_power_setpoint(v)
+        kw = {}
+        if sc.get("cooling") is not None:
+            v = sc["cooling"](t)
+            if v is not None:
+                cw[t] = v; kw["cooling_water_temp"] = v
+        with refsim.quiet():
+            r = sim.step(ControlAction(int(act[t])), magnitude=float(mag[t]), **kw)
+        obs[t] = r["observation"]; rew[t] = r["reward"]; done[t] = bool(r["done"])
+        i = r["info"]
+        info[t] = [i["thermal_power"], i["reactivity"], i.get("electrical_power", np.nan),
+                   i.get("thermal_efficiency", np.nan), i.get("steam_flow", np.nan),
+                   i.get("steam_pressure", np.nan), i.get("condenser_pressure", np.nan),
+                   i.get("condenser_heat_rejection", np.nan), i["time"],
+                   i["secondary_system"]["feedwater_total_flow"] if "secondary_system" in i else np.nan]
+        state[t + 1] = [_val(sim, p) for p in paths]
+    return dict(state=state, obs=obs, reward=rew, done=done, info=info,
+                action=act, magnitude=mag, setpoint=sp, cooling=cw, noise_z=z), sim
