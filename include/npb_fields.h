@@ -165,6 +165,47 @@
   I(system_trip_active,       "secondary_physics.feedwater_system.protection_system.system_trip_active") \
   I(npsh_low_low_trip_active, "secondary_physics.feedwater_system.protection_system.npsh_protection.npsh_low_low_trip_active")
 
+/* ---- turbine: 14 stages, rotor, 4 bearings, metal-temperature tracker, protection timers,
+ * bearing lubrication system
+ * reference: turbine/stage_system.py:49-96, rotor_dynamics.py:55-82,803-822,
+ *            turbine/enhanced_physics.py:56-71,190-198,531-544, lubrication_base.py:150-176,
+ *            turbine_bearing_lubrication.py:97-185
+ * Per stage only efficiency_degradation, deposit_thickness and blade_wear_factor are stored:
+ * fouling_factor, blade_condition_factor and actual_efficiency are pure functions of them
+ * (stage_system.py:294-339) and are re-derived when the stage is loaded. */
+#define NPB_TURB_FIELDS(F, A, I) \
+  A(stage_efficiency_degradation, 14, "=list(root.secondary_physics.turbine.stage_system.stages.values())[{k}].efficiency_degradation") \
+  A(stage_deposit_thickness, 14,      "=list(root.secondary_physics.turbine.stage_system.stages.values())[{k}].deposit_thickness") \
+  A(stage_blade_wear_factor, 14,      "=list(root.secondary_physics.turbine.stage_system.stages.values())[{k}].blade_wear_factor") \
+  F(rotor_speed,          "secondary_physics.turbine.rotor_dynamics.rotor_speed") \
+  F(rotor_temperature,    "secondary_physics.turbine.rotor_dynamics.rotor_temperature") \
+  F(thermal_bow,          "secondary_physics.turbine.rotor_dynamics.thermal_bow") \
+  F(thermal_expansion,    "secondary_physics.turbine.rotor_dynamics.thermal_expansion") \
+  A(bearing_load, 4,        "=list(root.secondary_physics.turbine.rotor_dynamics.bearings.values())[{k}].current_load") \
+  A(bearing_metal_temp, 4,  "=list(root.secondary_physics.turbine.rotor_dynamics.bearings.values())[{k}].metal_temperature") \
+  A(bearing_wear_factor, 4, "=list(root.secondary_physics.turbine.rotor_dynamics.bearings.values())[{k}].wear_factor") \
+  A(rotor_temperatures, 8,  "secondary_physics.turbine.thermal_tracker.rotor_temperatures[{k}]") \
+  A(casing_temperatures, 6, "secondary_physics.turbine.thermal_tracker.casing_temperatures[{k}]") \
+  A(blade_temperatures, 14, "secondary_physics.turbine.thermal_tracker.blade_temperatures[{k}]") \
+  F(timer_overspeed,      "secondary_physics.turbine.protection_system.trip_timers['overspeed']") \
+  F(timer_vibration,      "secondary_physics.turbine.protection_system.trip_timers['vibration']") \
+  F(timer_bearing_temp,   "secondary_physics.turbine.protection_system.trip_timers['bearing_temp']") \
+  F(load_demand,          "secondary_physics.turbine.load_demand") \
+  F(total_power_output,   "secondary_physics.turbine.total_power_output") \
+  F(vibration_displacement, "secondary_physics.turbine.rotor_dynamics.vibration_monitor.displacement_x") \
+  F(lub_oil_temperature,  "secondary_physics.turbine.bearing_lubrication_system.oil_temperature") \
+  F(lub_oil_contamination,"secondary_physics.turbine.bearing_lubrication_system.oil_contamination_level") \
+  F(lub_oil_moisture,     "secondary_physics.turbine.bearing_lubrication_system.oil_moisture_content") \
+  F(lub_oil_acidity,      "secondary_physics.turbine.bearing_lubrication_system.oil_acidity_number") \
+  F(lub_oil_viscosity_change, "secondary_physics.turbine.bearing_lubrication_system.oil_viscosity_change") \
+  F(lub_antioxidant_level,"secondary_physics.turbine.bearing_lubrication_system.antioxidant_level") \
+  F(lub_anti_wear_level,  "secondary_physics.turbine.bearing_lubrication_system.anti_wear_additive_level") \
+  F(lub_corrosion_inhibitor_level, "secondary_physics.turbine.bearing_lubrication_system.corrosion_inhibitor_level") \
+  F(lub_effectiveness,    "secondary_physics.turbine.bearing_lubrication_system.lubrication_effectiveness") \
+  A(lub_wear, 5,          "=list(root.secondary_physics.turbine.bearing_lubrication_system.component_wear.values())[{k}]") \
+  I(trip_active,          "secondary_physics.turbine.protection_system.trip_active") \
+  I(trip_latched_mask,    "")
+
 /* ---- secondary-system level carried scalars and the outputs get_observation() reads
  * reference: systems/secondary/__init__.py:300-310,385-398,447-453,921-927 */
 #define NPB_SEC_FIELDS(F, A, I) \
@@ -189,6 +230,7 @@
   S(sg,   SG,   npb_sg_t,   NPB_NUM_SG) \
   S(pump, PUMP, npb_pump_t, NPB_NUM_PUMPS) \
   S(fw,   FW,   npb_fw_t,   1) \
+  S(turb, TURB, npb_turb_t, 1) \
   S(sec,  SEC,  npb_sec_t,  1)
 
 /* ------------------------------------------------------------------ structs */

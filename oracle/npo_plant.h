@@ -12,6 +12,7 @@ typedef struct npo_plant_t {
   npb_sg_t sg[NPB_NUM_SG];
   npb_pump_t pump[NPB_NUM_PUMPS];
   npb_fw_t fw;
+  npb_turb_t turb;
   npb_sec_t sec;
 } npo_plant_t;
 

@@ -13,6 +13,7 @@
 #include "npo_primary.h"
 #include "npo_sg.h"
 #include "npo_feedwater.h"
+#include "npo_turbine.h"
 
 typedef struct npo_secondary_result_t {
   double electrical_power_mw, thermal_efficiency, total_steam_flow, sg_avg_pressure;
@@ -103,7 +104,13 @@ NPO_FN void npo_secondary_tail(npo_plant_t *pl, const npb_params_t *P, const npo
                                const npo_sgsys_result_t *sgr, const npo_fw_result_t *fwr, npo_secondary_result_t *r) {
   npb_sec_t *sec = &pl->sec;
   (void)c;
-  /* TODO turbine + condenser */
+  /* ---- STEP 5: turbine (dt in hours; load_demand handed over in PERCENT, :564-569) */
+  double sg_pressures[NPB_NUM_SG];
+  for (int i = 0; i < NPB_NUM_SG; i++) sg_pressures[i] = pl->sg[i].secondary_pressure;
+  npo_turbine_result_t tr;
+  npo_turbine_update(&pl->turb, sgr->avg_pressure, sgr->avg_temperature, sgr->total_steam_flow, sg_pressures,
+                     sec->sg_system_availability, sec->load_demand, 0.007, P->dt / 60.0, &tr);
+  /* TODO condenser */
   sec->total_steam_flow = sgr->total_steam_flow;
   sec->total_heat_transfer = sgr->total_thermal_power;
   sec->total_feedwater_flow = fwr->total_flow_rate;
