@@ -206,6 +206,53 @@
   I(trip_active,          "secondary_physics.turbine.protection_system.trip_active") \
   I(trip_latched_mask,    "")
 
+/* ---- WaterChemistry instances (x2): [0] the secondary-level one shared with the feedwater system
+ * (secondary/__init__.py:316-321), [1] the condenser-owned one (condenser/physics.py:528-532).
+ * The third instance (SG-system-owned) is never updated and lives in npb_params.h.
+ * reference: water_chemistry.py:222-275; composite indices are recomputed inside every update. */
+#define NPB_CHEM_FIELDS(F, A, I) \
+  F(ph,                     "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].ph") \
+  F(hardness,               "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].hardness") \
+  F(total_dissolved_solids, "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].total_dissolved_solids") \
+  F(chloride,               "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].chloride") \
+  F(dissolved_oxygen,       "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].dissolved_oxygen") \
+  F(chlorine_residual,      "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].chlorine_residual") \
+  F(antiscalant_concentration, "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].antiscalant_concentration") \
+  F(corrosion_inhibitor_level, "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].corrosion_inhibitor_level") \
+  F(treatment_efficiency,   "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].treatment_efficiency") \
+  F(water_aggressiveness,   "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].water_aggressiveness") \
+  F(scaling_tendency,       "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].scaling_tendency")
+
+/* ---- condenser: tube degradation, 3-species fouling, vacuum system with 2 steam-jet ejectors
+ * reference: condenser/physics.py:55-71,151-165,540-559, vacuum_system.py:40-52,270-300,
+ *            vacuum_pump.py:52-92 */
+#define NPB_COND_FIELDS(F, A, I) \
+  F(cooling_water_outlet_temp,  "secondary_physics.condenser.cooling_water_outlet_temp") \
+  F(heat_rejection_rate,        "secondary_physics.condenser.heat_rejection_rate") \
+  F(active_tube_count,          "secondary_physics.condenser.tube_degradation.active_tube_count") \
+  F(plugged_tube_count,         "secondary_physics.condenser.tube_degradation.plugged_tube_count") \
+  F(average_wall_thickness,     "secondary_physics.condenser.tube_degradation.average_wall_thickness") \
+  F(vibration_damage,           "secondary_physics.condenser.tube_degradation.vibration_damage_accumulation") \
+  F(corrosion_damage,           "secondary_physics.condenser.tube_degradation.corrosion_damage_accumulation") \
+  F(biofouling_thickness,       "secondary_physics.condenser.fouling_model.biofouling_thickness") \
+  F(scale_thickness,            "secondary_physics.condenser.fouling_model.scale_thickness") \
+  F(corrosion_product_thickness,"secondary_physics.condenser.fouling_model.corrosion_product_thickness") \
+  F(fouling_distribution_factor,"secondary_physics.condenser.fouling_model.fouling_distribution_factor") \
+  F(time_since_cleaning,        "secondary_physics.condenser.fouling_model.time_since_cleaning") \
+  F(total_fouling_resistance,   "secondary_physics.condenser.fouling_model.total_fouling_resistance") \
+  F(condenser_pressure,         "secondary_physics.condenser.vacuum_system.condenser_pressure") \
+  F(air_partial_pressure,       "secondary_physics.condenser.vacuum_system.air_partial_pressure") \
+  F(current_air_leakage,        "secondary_physics.condenser.vacuum_system.current_air_leakage") \
+  F(air_mass_in_condenser,      "secondary_physics.condenser.vacuum_system.air_mass_in_condenser") \
+  F(vacuum_system_efficiency,   "secondary_physics.condenser.vacuum_system.system_efficiency") \
+  F(rotation_timer,             "secondary_physics.condenser.vacuum_system.control_logic.rotation_timer") \
+  A(ej_nozzle_fouling, 2,       "=list(root.secondary_physics.condenser.vacuum_system.ejectors.values())[{k}].nozzle_fouling_factor") \
+  A(ej_diffuser_fouling, 2,     "=list(root.secondary_physics.condenser.vacuum_system.ejectors.values())[{k}].diffuser_fouling_factor") \
+  A(ej_nozzle_erosion, 2,       "=list(root.secondary_physics.condenser.vacuum_system.ejectors.values())[{k}].nozzle_erosion_factor") \
+  I(ej_operating_mask,          "=sum(int(e.is_operating) << k for k, e in enumerate(root.secondary_physics.condenser.vacuum_system.ejectors.values()))") \
+  I(lead_ejector,               "=(-1 if root.secondary_physics.condenser.vacuum_system.control_logic.lead_ejector_id is None else int(root.secondary_physics.condenser.vacuum_system.control_logic.lead_ejector_id[-1]) - 1)") \
+  I(lag_ejector,                "=(-1 if root.secondary_physics.condenser.vacuum_system.control_logic.lag_ejector_id is None else int(root.secondary_physics.condenser.vacuum_system.control_logic.lag_ejector_id[-1]) - 1)")
+
 /* ---- secondary-system level carried scalars and the outputs get_observation() reads
  * reference: systems/secondary/__init__.py:300-310,385-398,447-453,921-927 */
 #define NPB_SEC_FIELDS(F, A, I) \
@@ -231,6 +278,8 @@
   S(pump, PUMP, npb_pump_t, NPB_NUM_PUMPS) \
   S(fw,   FW,   npb_fw_t,   1) \
   S(turb, TURB, npb_turb_t, 1) \
+  S(chem, CHEM, npb_chem_t, 2) \
+  S(cond, COND, npb_cond_t, 1) \
   S(sec,  SEC,  npb_sec_t,  1)
 
 /* ------------------------------------------------------------------ structs */

@@ -10,6 +10,7 @@
 #include "npo_sg.h"
 #include "npo_feedwater.h"
 #include "npo_turbine.h"
+#include "npo_condenser.h"
 
 /* ReactorState defaults  systems/primary/__init__.py:48-106 */
 NPO_FN void npo_prim_init(npb_prim_t *s) {
@@ -121,6 +122,31 @@ NPO_FN void npo_turb_init(npb_turb_t *t) {
   for (int i = 0; i < 5; i++) t->lub_wear[i] = wear[i];
 }
 
+/* WaterChemistry.__init__ water_chemistry.py:222-275; index 1 then receives the condenser's initial
+ * conditions (condenser/physics.py:1476-1500: ph 7.5, hardness 150, chlorine 1.0, DO 8.0) AFTER the
+ * composite indices were computed from the design values */
+NPO_FN void npo_chem_init(npb_chem_t *c, int index) {
+  memset(c, 0, sizeof(*c));
+  c->ph = 9.2; c->hardness = 150.0; c->total_dissolved_solids = 500.0; c->chloride = 50.0; c->dissolved_oxygen = 0.005;
+  c->chlorine_residual = 0.5; c->antiscalant_concentration = 5.0; c->corrosion_inhibitor_level = 10.0;
+  c->treatment_efficiency = 0.95;
+  npo_chem_composites(c);
+  if (index == 1) { c->ph = 7.5; c->hardness = 150.0; c->chlorine_residual = 1.0; c->dissolved_oxygen = 8.0; }
+}
+
+/* EnhancedCondenserPhysics.__init__ + _apply_initial_conditions condenser/physics.py:486-562,1374-1555 with
+ * CondenserInitialConditions defaults (condenser/config.py); VacuumSystem.__init__ vacuum_system.py:252-300 */
+NPO_FN void npo_cond_init(npb_cond_t *cd) {
+  memset(cd, 0, sizeof(*cd));
+  cd->cooling_water_outlet_temp = 35.632642211589584; cd->heat_rejection_rate = 2000000000.0;
+  cd->active_tube_count = 84000; cd->plugged_tube_count = 0; cd->average_wall_thickness = 0.00159;
+  cd->fouling_distribution_factor = 1.0;
+  cd->condenser_pressure = 0.007; cd->air_partial_pressure = 0.0005; cd->current_air_leakage = 0.05;
+  cd->air_mass_in_condenser = 0.1; cd->vacuum_system_efficiency = 1.0; cd->rotation_timer = 0.0;
+  for (int e = 0; e < 2; e++) { cd->ej_nozzle_fouling[e] = 1.0; cd->ej_diffuser_fouling[e] = 1.0; cd->ej_nozzle_erosion[e] = 1.0; }
+  cd->ej_operating_mask = 0; cd->lead_ejector = -1; cd->lag_ejector = -1;
+}
+
 NPO_FN void npo_plant_init(npo_plant_t *pl, const npb_params_t *P) {
   (void)P;
   npo_prim_init(&pl->prim);
@@ -128,6 +154,8 @@ NPO_FN void npo_plant_init(npo_plant_t *pl, const npb_params_t *P) {
   for (int i = 0; i < NPB_NUM_PUMPS; i++) npo_pump_init(&pl->pump[i], i);
   npo_fw_init(&pl->fw);
   npo_turb_init(&pl->turb);
+  for (int i = 0; i < 2; i++) npo_chem_init(&pl->chem[i], i);
+  npo_cond_init(&pl->cond);
   npo_sec_init(&pl->sec);
 }
 #endif

@@ -14,6 +14,7 @@
 #include "npo_sg.h"
 #include "npo_feedwater.h"
 #include "npo_turbine.h"
+#include "npo_condenser.h"
 
 typedef struct npo_secondary_result_t {
   double electrical_power_mw, thermal_efficiency, total_steam_flow, sg_avg_pressure;
@@ -33,7 +34,9 @@ NPO_FN void npo_feedwater_obs(const npo_plant_t *pl, double *flow, double *power
 /* SecondaryReactorPhysics._saturation_temperature  secondary/__init__.py:1455 ff */
 NPO_FN double npo_sec_tsat(double pressure_mpa);
 
-/* turbine -> condenser -> gates; defined after the subsystem headers exist */
+NPO_FN void npo_secondary_chemistry(npo_plant_t *pl, const npb_params_t *P) { (void)pl; (void)P; /* filled in by npo_ph.h */ }
+
+/* turbine -> condenser -> gates */
 NPO_FN void npo_secondary_tail(npo_plant_t *pl, const npb_params_t *P, const npo_coupling_t *c,
                                const npo_sgsys_result_t *sgr, const npo_fw_result_t *fwr, npo_secondary_result_t *r);
 
@@ -110,18 +113,56 @@ NPO_FN void npo_secondary_tail(npo_plant_t *pl, const npb_params_t *P, const npo
   npo_turbine_result_t tr;
   npo_turbine_update(&pl->turb, sgr->avg_pressure, sgr->avg_temperature, sgr->total_steam_flow, sg_pressures,
                      sec->sg_system_availability, sec->load_demand, 0.007, P->dt / 60.0, &tr);
-  /* TODO condenser */
-  sec->total_steam_flow = sgr->total_steam_flow;
-  sec->total_heat_transfer = sgr->total_thermal_power;
+  /* ---- condenser with the ACTUAL LP exhaust quality from LP-6's outlet enthalpy (:591-621) */
+  double lp_exhaust_quality = 0.90;
+  {
+    double h_f = npo_cond_hf(tr.condenser_pressure), h_g = npo_cond_hg(tr.condenser_pressure);
+    double h_fg = h_g - h_f;
+    if (h_fg > 0) {
+      lp_exhaust_quality = (tr.lp6_outlet_enthalpy - h_f) / h_fg;
+      lp_exhaust_quality = npo_pymax(0.0, npo_pymin(1.0, lp_exhaust_quality));
+    }
+  }
+  npo_condenser_result_t cr;
+  npo_condenser_update(&pl->cond, &pl->chem[1], tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality,
+                       45000.0, sec->cooling_water_temperature, 1.2, 185.0, P->dt / 60.0, &cr);
   sec->total_feedwater_flow = fwr->total_flow_rate;
   sec->operating_hours += P->dt / 3600.0;
+
+  /* ---- chemistry sidecar (:634-665): shared WaterChemistry + pH controller */
+  npo_secondary_chemistry(pl, P);
+
+  sec->total_steam_flow = sgr->total_steam_flow;
+  sec->total_heat_transfer = sgr->total_thermal_power;
+  /* ---- energy accounting and electrical-power gates (:750-932) */
+  double primary_thermal_power = 0.0;
+  for (int i = 0; i < NPB_NUM_SG; i++) primary_thermal_power += c->thermal_power[i];
+  double thermal_power_mw = primary_thermal_power;
+  double turbine_electrical_power = tr.electrical_power_net;
+  double total_system_heat_rejection_mw = primary_thermal_power - turbine_electrical_power;
+  double actual_feedwater_flow = fwr->total_flow_rate;
+  double power_reduction_factor = 1.0;
+  if (actual_feedwater_flow < 300.0) power_reduction_factor = 0.0;
+  if (power_reduction_factor > 0.0) {
+    if (sgr->total_steam_flow < (300.0 * 0.5)) power_reduction_factor *= 0.1;
+    if (sgr->avg_pressure < (1.0 * 0.5)) power_reduction_factor *= 0.1;
+    if (thermal_power_mw > (primary_thermal_power * 1.1)) power_reduction_factor = 0.0;
+  }
+  sec->electrical_power_output = turbine_electrical_power * power_reduction_factor;
+  if (primary_thermal_power > 0) sec->thermal_efficiency = sec->electrical_power_output / primary_thermal_power;
+  else sec->thermal_efficiency = 0.0;
+
+  r->electrical_power_mw = sec->electrical_power_output;
+  r->thermal_efficiency = sec->thermal_efficiency;
   r->total_steam_flow = sgr->total_steam_flow;
   r->sg_avg_pressure = sgr->avg_pressure;
-  r->condenser_pressure = 0.007;
+  r->condenser_pressure = cr.condenser_pressure;
+  r->total_system_heat_rejection = total_system_heat_rejection_mw * 1e6;
   r->feedwater_total_flow = fwr->total_flow_rate;
   r->feedwater_total_power = fwr->total_power_consumption;
   r->feedwater_system_available = fwr->system_availability;
-  r->trip_flags = (fwr->pump_trip_mask << 8) | (pl->fw.system_trip_active ? NPB_TRIP_FW_SYSTEM : 0);
+  r->trip_flags = (fwr->pump_trip_mask << 8) | (pl->fw.system_trip_active ? NPB_TRIP_FW_SYSTEM : 0) |
+                  (tr.trip_active ? NPB_TRIP_TURBINE : 0);
 }
 
 #endif
