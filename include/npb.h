@@ -1,0 +1,103 @@
+/*
+ * npb.h -- C ABI of the MI355X batched plant stepper (libnpb.so).
+ *
+ * This is the drop-in boundary for the per-timestep physics path of NuclearnAI/nuclear-sim:
+ * the reference has no FFI (it is pure Python), so each entry point names the Python interface
+ * it stands in for.  A maintainer of the reference binds these with ctypes;
+ * this repo's own host mirror is nuclear_sim_amd/env.py.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * NPB_E* code (text via npb_last_error); the caller owns every I/O buffer and passes raw DEVICE
+ * pointers (e.g. torch.Tensor.data_ptr()); the library owns only the struct-of-arrays state arena
+ * inside the handle; npb_step() allocates nothing and only enqueues work on `stream`
+ * (a hipStream_t, NULL = default stream).  One handle per stream; distinct handles are independent.
+ */
+#ifndef NPB_H
+#define NPB_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "npb_fields.h"
+#include "npb_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPB_VERSION 100 /* 0.1.0 */
+#ifndef NPB_API
+#define NPB_API __attribute__((visibility("default")))
+#endif
+
+enum { NPB_OK = 0, NPB_EINVAL = -1, NPB_EHIP = -2, NPB_ENOMEM = -3 };
+enum { NPB_KIND_F64 = 0, NPB_KIND_I32 = 1 };
+enum { NPB_OBS_DIM = 22, NPB_INFO_DIM = 10 };
+
+/* info columns written by npb_step (the scalar keys of step()'s info dict, sim.py:199-250) */
+enum {
+  NPB_INFO_THERMAL_POWER = 0, NPB_INFO_REACTIVITY_PCM, NPB_INFO_ELECTRICAL_POWER, NPB_INFO_THERMAL_EFFICIENCY,
+  NPB_INFO_STEAM_FLOW, NPB_INFO_STEAM_PRESSURE, NPB_INFO_CONDENSER_PRESSURE, NPB_INFO_CONDENSER_HEAT_REJECTION,
+  NPB_INFO_TIME, NPB_INFO_FEEDWATER_FLOW
+};
+/* trip_flags bits */
+enum {
+  NPB_TRIP_SCRAM = 1u << 0,        /* ReactorState.scram_status latched (scram_logic.py:57) */
+  NPB_TRIP_SCRAM_FIRED = 1u << 1,  /* scram fired on this step == step()['done'] (sim.py:256) */
+  NPB_TRIP_NAN_RESET = 1u << 2,    /* NaN reset taken (thermal_hydraulics.py:247-270) */
+  NPB_TRIP_TURBINE = 1u << 3,      /* TurbineProtectionSystem.trip_active */
+  NPB_TRIP_FW_SYSTEM = 1u << 4,    /* FeedwaterProtectionSystem.system_trip_active */
+  NPB_TRIP_FW_PUMP0 = 1u << 8      /* bits 8..11: feedwater pump i trip_active */
+};
+
+typedef struct NpbHandle NpbHandle;
+
+NPB_API int npb_version(void);
+/* schema sizes (must equal NPB_TOTAL_F64 / NPB_TOTAL_I32 the caller was compiled against) */
+NPB_API int npb_num_f64(void);
+NPB_API int npb_num_i32(void);
+/* carried bytes per plant = 8 * num_f64 + 4 * num_i32: S_carry of the roofline accounting */
+NPB_API size_t npb_state_bytes(void);
+/* algorithmic HBM bytes of one plant-step: 2 * state_bytes (read + write every carried column)
+ * + per-step inputs (action 4 + magnitude/setpoint/noise/cooling 4*8) + outputs (obs 22*8 + reward 8
+ * + done 1 + trip_flags 4 + info 10*8) */
+NPB_API size_t npb_step_bytes_per_plant(void);
+
+NPB_API void npb_default_params(npb_params_t *p);
+
+/* NuclearPlantSimulator.__init__ (sim.py:30-87) for n_plants plants on HIP device `device`:
+ * allocates the SoA arena and fills it with the construction-time state. */
+NPB_API int npb_create(const npb_params_t *params, int n_plants, int device, NpbHandle **out);
+NPB_API int npb_destroy(NpbHandle *h);
+NPB_API const char *npb_last_error(const NpbHandle *h); /* h may be NULL: last create error */
+NPB_API int npb_num_plants(const NpbHandle *h);
+NPB_API int npb_set_params(NpbHandle *h, const npb_params_t *params);
+
+/* re-initialise plants to the construction-time state; mask (device, uint8[n], NULL = all) selects plants.
+ * Stands in for constructing a fresh simulator (the data-gen runner's episode start,
+ * maintenance_scenario_runner.py:210-244). */
+NPB_API int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream);
+
+/* state columns: sim.state.<attr> / component attribute access.  `slot` is the global slot of
+ * npb_fields.h; buf holds n_plants elements (double or int32_t) on the device or the host. */
+NPB_API int npb_get_field(NpbHandle *h, int kind, int slot, void *buf, int buf_is_device, void *stream);
+NPB_API int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int buf_is_device, void *stream);
+/* raw arena: f64[slot * pitch + plant], i32[slot * pitch + plant] */
+NPB_API int npb_state_arena(NpbHandle *h, double **f64, int32_t **i32, size_t *pitch);
+
+/* NuclearPlantSimulator.step (sim.py:130-258) for every plant.  Input columns (device, n_plants each)
+ * may be NULL: action -> NO_ACTION(8), magnitude -> 1.0, power_setpoint -> unchanged
+ * (NaN entries also mean unchanged; replaces heat_source.set_power_setpoint), noise_z -> 0
+ * (standard-normal sample that ConstantHeatSource would draw, constant_heat_source.py:178),
+ * cooling_water_temp -> unchanged.  Output columns (device) may be NULL:
+ * obs [n,22] row-major, reward [n], done [n] u8, trip_flags [n] u32, info [n,10]. */
+NPB_API int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const double *power_setpoint,
+             const double *noise_z, const double *cooling_water_temp, double *obs, double *reward, uint8_t *done,
+             uint32_t *trip_flags, double *info, void *stream);
+
+/* NuclearPlantSimulator.get_observation (sim.py:290-333) */
+NPB_API int npb_observe(NpbHandle *h, double *obs, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPB_H */

@@ -268,6 +268,9 @@
   F(sg_avg_pressure,          "secondary_physics.steam_generator_system.average_steam_pressure") \
   F(sg_avg_temperature,       "secondary_physics.steam_generator_system.average_steam_temperature") \
   F(sg_avg_quality,           "secondary_physics.steam_generator_system.average_steam_quality") \
+  A(prev_sg_levels, 3,        "secondary_physics._previous_sg_conditions['levels'][{k}]") \
+  A(prev_sg_steam_flows, 3,   "secondary_physics._previous_sg_conditions['steam_flows'][{k}]") \
+  A(prev_sg_qualities, 3,     "secondary_physics._previous_sg_conditions['steam_qualities'][{k}]") \
   I(has_previous_sg_conditions, "") \
   I(sg_system_availability,   "secondary_physics.steam_generator_system.system_availability")
 

@@ -1,0 +1,82 @@
+"""ctypes binding of libnpb.so (the HIP stepper's C ABI, include/npb.h).
+
+There is no CPU fallback: if the shared library is missing or does not load, importing
+this module raises.  Build it with ``make -C nuclear_sim_amd/csrc`` (or
+``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .schema import PARAMS, SCHEMA
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnpb.so")
+
+NPB_KIND_F64, NPB_KIND_I32 = 0, 1
+HEAT_CONSTANT, HEAT_REACTOR = 0, 1
+MODE_FULL, MODE_PRIMARY_SG = 0, 1
+
+
+class NpbError(RuntimeError):
+    pass
+
+
+def _make_params_struct():
+    fields = [(name, ctypes.c_double) for name, _d, _p in PARAMS]
+    fields += [("dt", ctypes.c_double), ("heat_source", ctypes.c_int), ("hs_noise_enabled", ctypes.c_int),
+               ("mode", ctypes.c_int), ("reserved_", ctypes.c_int)]
+    return type("NpbParams", (ctypes.Structure,), {"_fields_": fields})
+
+
+NpbParams = _make_params_struct()
+
+_lib = None
+
+
+def load():
+    """Load libnpb.so and declare its entry points; raises NpbError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NpbError("%s not found: build the HIP extension first (make -C nuclear_sim_amd/csrc); "
+                       "there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.npb_version.restype = ci
+    L.npb_num_f64.restype = ci
+    L.npb_num_i32.restype = ci
+    L.npb_state_bytes.restype = ctypes.c_size_t
+    L.npb_step_bytes_per_plant.restype = ctypes.c_size_t
+    L.npb_default_params.argtypes = [ctypes.POINTER(NpbParams)]
+    L.npb_create.argtypes = [ctypes.POINTER(NpbParams), ci, ci, ctypes.POINTER(vp)]
+    L.npb_destroy.argtypes = [vp]
+    L.npb_last_error.argtypes = [vp]
+    L.npb_last_error.restype = ctypes.c_char_p
+    L.npb_num_plants.argtypes = [vp]
+    L.npb_set_params.argtypes = [vp, ctypes.POINTER(NpbParams)]
+    L.npb_reset.argtypes = [vp, vp, vp]
+    L.npb_get_field.argtypes = [vp, ci, ci, vp, ci, vp]
+    L.npb_set_field.argtypes = [vp, ci, ci, vp, ci, vp]
+    L.npb_state_arena.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    L.npb_step.argtypes = [vp] + [vp] * 11
+    L.npb_observe.argtypes = [vp, vp, vp]
+    if L.npb_num_f64() != SCHEMA.total_f64 or L.npb_num_i32() != SCHEMA.total_i32:
+        raise NpbError("libnpb.so was built against a different include/npb_fields.h (%d/%d vs %d/%d): rebuild"
+                       % (L.npb_num_f64(), L.npb_num_i32(), SCHEMA.total_f64, SCHEMA.total_i32))
+    _lib = L
+    return L
+
+
+def default_params() -> "NpbParams":
+    p = NpbParams()
+    load().npb_default_params(ctypes.byref(p))
+    return p
+
+
+def check(rc, handle=None):
+    if rc != 0:
+        msg = load().npb_last_error(handle)
+        raise NpbError("libnpb error %d: %s" % (rc, msg.decode() if msg else "?"))

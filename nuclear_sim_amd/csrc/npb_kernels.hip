@@ -1,0 +1,440 @@
+/*
+ * npb_kernels.hip -- the fused plant-step kernel for gfx950 (MI355X) and its small companions.
+ *
+ * One wavefront lane = one plant.  State lives in HBM as a struct-of-arrays: column `slot` of the
+ * fp64 table is f64[slot * Npad + plant], so every load/store instruction of a wave touches 64
+ * consecutive doubles (512 B, fully coalesced).  A plant's ~530 carried scalars do not fit a lane's
+ * register file at once, so the step STREAMS the plant subsystem by subsystem in the reference's own
+ * order (NuclearPlantSimulator.step, simulator/core/sim.py:130-258; SecondaryReactorPhysics.update_system,
+ * systems/secondary/__init__.py:340-1021):
+ *
+ *   primary -> coupling -> feedwater (4 pumps, one at a time) -> 3 steam generators (one at a time)
+ *   -> turbine -> condenser -> electrical-power gates -> feedback -> observation / reward / done
+ *
+ * Each phase loads its section struct from the SoA columns, updates it in registers and stores it
+ * back; only the ~30 coupling scalars stay live between phases.  No MFMA (there is no dense
+ * contraction on this path), no inter-lane communication except the LDS transpose that turns the
+ * wave's 64 x 22 observation block into coalesced row-major stores.  Plants are independent, so
+ * blocks never share data and the block -> XCD placement cannot matter.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "npd_common.h"
+#include "npd_primary.h"
+#include "npd_sg.h"
+#include "npd_feedwater.h"
+#include "npd_turbine.h"
+#include "npd_condenser.h"
+#include "npd_init.h"
+#include "npb_kernels.h"
+
+#define NPB_WAVE 64
+#define NPB_OBS_PAD 23 /* LDS row stride in doubles: 22 + 1 keeps the transpose at <= 2-way bank conflicts */
+
+/* ---- section <-> SoA column movers.  A section struct is NF64 doubles followed by NI32 int32s
+ * (include/npb_fields.h), so a fully unrolled constant-index copy is all that is needed. */
+template <int NF, int NI, typename S>
+__device__ __forceinline__ void npd_load(S &s, const double *__restrict__ f64, const int32_t *__restrict__ i32,
+                                         size_t N, size_t p, int fbase, int ibase) {
+  double *d = reinterpret_cast<double *>(&s);
+#pragma unroll
+  for (int k = 0; k < NF; k++) d[k] = f64[(size_t)(fbase + k) * N + p];
+  int32_t *q = reinterpret_cast<int32_t *>(d + NF);
+#pragma unroll
+  for (int k = 0; k < NI; k++) q[k] = i32[(size_t)(ibase + k) * N + p];
+}
+template <int NF, int NI, typename S>
+__device__ __forceinline__ void npd_store(const S &s, double *__restrict__ f64, int32_t *__restrict__ i32,
+                                          size_t N, size_t p, int fbase, int ibase) {
+  const double *d = reinterpret_cast<const double *>(&s);
+#pragma unroll
+  for (int k = 0; k < NF; k++) f64[(size_t)(fbase + k) * N + p] = d[k];
+  const int32_t *q = reinterpret_cast<const int32_t *>(d + NF);
+#pragma unroll
+  for (int k = 0; k < NI; k++) i32[(size_t)(ibase + k) * N + p] = q[k];
+}
+#define NPD_LOAD(T, stype, s, inst) \
+  npd_load<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, f64, i32, N, p, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
+                                                  NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32)
+#define NPD_STORE(T, stype, s, inst) \
+  npd_store<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, f64, i32, N, p, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
+                                                   NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32)
+/* single-column access */
+#define NPD_F64_COL(T, stype, member, inst) \
+  f64[(size_t)(NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64 + NPB_F64_SLOT(stype, member)) * N + p]
+#define NPD_F64_COLK(T, stype, member, inst, k) \
+  f64[(size_t)(NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64 + NPB_F64_SLOT(stype, member) + (k)) * N + p]
+#define NPD_I32_COL(T, stype, member, inst) \
+  i32[(size_t)(NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32 + NPB_I32_SLOT(stype, T, member)) * N + p]
+
+/* wave-cooperative store of a [64][W] block held one row per lane into row-major global memory */
+template <int W>
+__device__ __forceinline__ void npd_store_rows(const double *row, double *__restrict__ out, double *lds,
+                                               size_t block_base, size_t n_valid) {
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < W; j++) lds[lane * NPB_OBS_PAD + j] = row[j];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    int idx = k * NPB_WAVE + lane;
+    int r = idx / W, c = idx % W;
+    if (block_base + r < n_valid) out[block_base * W + idx] = lds[r * NPB_OBS_PAD + c];
+  }
+  __syncthreads();
+}
+
+/* get_observation  sim.py:290-333 (primary part) */
+__device__ __forceinline__ void npd_obs_primary(const npb_prim_t &s, double *obs) {
+  obs[0] = s.neutron_flux / 1e12;
+  obs[1] = s.fuel_temperature / 1000;
+  obs[2] = s.coolant_temperature / 300;
+  obs[3] = s.coolant_pressure / 20;
+  obs[4] = s.coolant_flow_rate / 50000;
+  obs[5] = s.steam_temperature / 300;
+  obs[6] = s.steam_pressure / 10;
+  obs[7] = s.steam_flow_rate / 3000;
+  obs[8] = s.control_rod_position / 100;
+  obs[9] = s.steam_valve_position / 100;
+  obs[10] = s.power_level / 100;
+  obs[11] = (double)(s.scram_status != 0);
+}
+
+__global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
+    npb_params_t P, int n_plants, size_t N, double *__restrict__ f64, int32_t *__restrict__ i32,
+    const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
+    const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,
+    double *__restrict__ reward_out, uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out,
+    double *__restrict__ info_out) {
+  __shared__ double lds[NPB_WAVE * NPB_OBS_PAD];
+  const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
+  const size_t p = block_base + threadIdx.x; /* always < N (arena is padded to a multiple of 64) */
+  const bool live = p < (size_t)n_plants;
+  const double dt = P.dt;
+
+  npd_inputs_t in;
+  in.action = (live && action) ? action[p] : 8;
+  in.magnitude = (live && magnitude) ? magnitude[p] : 1.0;
+  in.power_setpoint = (live && setpoint) ? setpoint[p] : NAN;
+  in.noise_z = (live && noise_z) ? noise_z[p] : 0.0;
+  in.cooling_water_temp = (live && cw_temp) ? cw_temp[p] : NAN;
+
+  double obs[NPB_OBS_DIM];
+  double info[NPB_INFO_DIM];
+  double base_reward, load_demand, cooling_water_temperature;
+  int scram_fired, nan_reset, scram_status;
+  npd_coupling_t c;
+
+  /* ================= phase 0: primary side + coupling (sim.py:141-161) ================= */
+  {
+    npb_prim_t s;
+    NPD_LOAD(PRIM, npb_prim_t, s, 0);
+    if (!isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
+    scram_fired = npd_primary_update(&s, &P, &in, &nan_reset);
+    npd_primary_to_secondary(&s, &c);
+    s.sim_time += dt;
+    load_demand = s.power_level; /* sim.py:161: the caller's load_demand is overwritten */
+    scram_status = s.scram_status;
+    npd_obs_primary(s, obs); /* obs[7] is patched after the secondary side has produced the steam flow */
+    /* base reward, sim.py:503-519 */
+    double power_reward = -fabs(s.power_level - 100) / 100;
+    double temp_penalty = 0, pressure_penalty = 0;
+    if (s.fuel_temperature > 800) temp_penalty = -(s.fuel_temperature - 800) / 100;
+    if (s.coolant_pressure > 16) pressure_penalty = -(s.coolant_pressure - 16);
+    double scram_penalty = s.scram_status ? -100 : 0;
+    base_reward = power_reward + temp_penalty + pressure_penalty + scram_penalty;
+    info[NPB_INFO_THERMAL_POWER] = s.thermal_power_mw;
+    info[NPB_INFO_REACTIVITY_PCM] = s.total_reactivity_pcm;
+    info[NPB_INFO_TIME] = s.sim_time;
+    NPD_STORE(PRIM, npb_prim_t, s, 0);
+  }
+
+  /* ================= secondary prelude (secondary/__init__.py:371-453) ================= */
+  cooling_water_temperature = NPD_F64_COL(SEC, npb_sec_t, cooling_water_temperature, 0);
+  if (!isnan(in.cooling_water_temp)) cooling_water_temperature = in.cooling_water_temp; /* sim.py:138-139 */
+  double actual_feedwater_temp;
+  {
+    double prev = NPD_F64_COL(SEC, npb_sec_t, previous_feedwater_temp, 0);
+    double estimated_feedwater_temp = 40.0 + 187.0;
+    double alpha = 0.1;
+    actual_feedwater_temp = (alpha * estimated_feedwater_temp + (1 - alpha) * prev);
+    NPD_F64_COL(SEC, npb_sec_t, previous_feedwater_temp, 0) = actual_feedwater_temp;
+  }
+  double primary_thermal_power = 0.0;
+#pragma unroll
+  for (int i = 0; i < NPB_NUM_SG; i++) primary_thermal_power += c.thermal_power[i];
+  double load_demand_fraction = npd_pymin(1.0, primary_thermal_power / 3000.0);
+  load_demand_fraction = npd_pymax(load_demand_fraction, 0.2);
+  const int has_prev = NPD_I32_COL(SEC, npb_sec_t, has_previous_sg_conditions, 0);
+
+  double fw_total_flow = 0.0, fw_total_power = 0.0;
+  int fw_available = 1;
+  uint32_t trip_flags = 0;
+
+  if (P.mode == NPB_MODE_FULL) {
+    /* ================= phase 1: feedwater system (physics.py:662-863) ================= */
+    double prev_levels[NPB_NUM_SG], prev_flows[NPB_NUM_SG], prev_quals[NPB_NUM_SG];
+#pragma unroll
+    for (int i = 0; i < NPB_NUM_SG; i++) {
+      if (has_prev) { /* the stored copy of the previous SG conditions (:530-535), not the SG objects */
+        prev_levels[i] = NPD_F64_COLK(SEC, npb_sec_t, prev_sg_levels, 0, i);
+        prev_flows[i] = NPD_F64_COLK(SEC, npb_sec_t, prev_sg_steam_flows, 0, i);
+        prev_quals[i] = NPD_F64_COLK(SEC, npb_sec_t, prev_sg_qualities, 0, i);
+      } else { /* :447-453 hard-coded first-step values, not the SG initial conditions */
+        prev_levels[i] = 12.5; prev_flows[i] = 555.0 * load_demand_fraction; prev_quals[i] = 0.99;
+      }
+    }
+    npb_fw_t fw;
+    NPD_LOAD(FW, npb_fw_t, fw, 0);
+    double total_flow_demand = npd_fw_level_control(&fw, prev_levels, prev_flows, prev_quals, dt);
+    int n_prev_running = 0;
+#pragma unroll
+    for (int i = 0; i < NPB_NUM_PUMPS; i++) n_prev_running += (fw.running_mask >> i) & 1;
+    double flow_per_pump = (n_prev_running > 0) ? total_flow_demand / n_prev_running : 0.0;
+    npd_pump_sysconds_t sc;
+    sc.feedwater_temperature = 40.0; sc.suction_pressure = 0.5; sc.discharge_pressure = 7.4; /* :457-464 */
+    sc.max_sg_level = npd_pymax3(prev_levels[0], prev_levels[1], prev_levels[2]);
+    npd_fw_acc_t acc;
+    acc.total_flow = acc.total_power = acc.flow_sum = 0.0;
+    acc.total_cavitation_risk = acc.total_wear_level = acc.total_vibration = 0.0;
+    acc.running_count = acc.running_mask = acc.trips = 0; acc.trip_mask = 0;
+#pragma unroll 1
+    for (int i = 0; i < NPB_NUM_PUMPS; i++) {
+      npb_pump_t pm;
+      NPD_LOAD(PUMP, npb_pump_t, pm, i);
+      npd_fw_pump_step(&pm, &fw, &acc, i, n_prev_running, flow_per_pump, &sc, dt);
+      NPD_STORE(PUMP, npb_pump_t, pm, i);
+    }
+    npd_fw_result_t fwr;
+    npd_fw_finish(&fw, &acc, prev_levels, dt, &fwr);
+    NPD_STORE(FW, npb_fw_t, fw, 0);
+    fw_total_flow = fwr.total_flow_rate; fw_total_power = fwr.total_power_consumption;
+    fw_available = fwr.system_availability;
+    trip_flags |= (fwr.pump_trip_mask << 8) | (fw.system_trip_active ? NPB_TRIP_FW_SYSTEM : 0);
+  }
+
+  /* ================= phase 2: steam generators (enhanced_physics.py:433-547) ================= */
+  double sg_total_thermal = 0.0, sg_total_steam = 0.0, sg_ap = 0.0, sg_at = 0.0, sg_aq = 0.0;
+  double sg_pressures[NPB_NUM_SG];
+  int sg_effective = 0;
+  {
+    double actual_total_steam_flow = P.sg_design_total_steam_flow * load_demand_fraction;
+    double total_primary_flow = 0.0;
+#pragma unroll
+    for (int i = 0; i < NPB_NUM_SG; i++) total_primary_flow += c.flow[i];
+#pragma unroll 1
+    for (int i = 0; i < NPB_NUM_SG; i++) {
+      double demand = (total_primary_flow > 0) ? actual_total_steam_flow * (c.flow[i] / total_primary_flow)
+                                               : actual_total_steam_flow / NPB_NUM_SG;
+      /* full mode: equal split of the actual feedwater flow (:500-506 key mismatch); config-2 mode:
+       * "perfect mass balance" fallback (enhanced_physics.py:495-497) */
+      double fwflow = (P.mode == NPB_MODE_FULL) ? fw_total_flow / NPB_NUM_SG : demand;
+      npb_sg_t g;
+      NPD_LOAD(SG, npb_sg_t, g, i);
+      npd_sg_result_t r;
+      npd_sg_update(&g, &P, c.inlet_temp[i], c.outlet_temp[i], c.flow[i], demand, fwflow, actual_feedwater_temp, dt * 60, &r);
+      NPD_STORE(SG, npb_sg_t, g, i);
+      sg_total_thermal += r.heat_transfer_rate; sg_total_steam += r.steam_flow_rate;
+      sg_ap += g.secondary_pressure; sg_at += g.secondary_temperature; sg_aq += g.steam_quality;
+      sg_pressures[i] = g.secondary_pressure;
+      if (r.thermal_efficiency > 0.1) sg_effective++;
+      NPD_F64_COLK(SEC, npb_sec_t, prev_sg_levels, 0, i) = g.water_level;
+      NPD_F64_COLK(SEC, npb_sec_t, prev_sg_steam_flows, 0, i) = r.steam_flow_rate;
+      NPD_F64_COLK(SEC, npb_sec_t, prev_sg_qualities, 0, i) = g.steam_quality;
+    }
+  }
+  const double sg_avg_pressure = sg_ap / NPB_NUM_SG, sg_avg_temperature = sg_at / NPB_NUM_SG, sg_avg_quality = sg_aq / NPB_NUM_SG;
+  const int sg_system_availability = sg_effective >= (NPB_NUM_SG - 1);
+
+  double electrical_power = 0.0, thermal_efficiency = 0.0, condenser_pressure = 0.007;
+  double total_system_heat_rejection = 0.0;
+  if (P.mode == NPB_MODE_FULL) {
+    /* ================= phase 3: turbine (dt in hours, load demand in PERCENT, :564-569) ========== */
+    npd_turbine_result_t tr;
+    {
+      npb_turb_t t;
+      NPD_LOAD(TURB, npb_turb_t, t, 0);
+      npd_turbine_update(&t, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
+                         load_demand, 0.007, dt / 60.0, &tr);
+      NPD_STORE(TURB, npb_turb_t, t, 0);
+    }
+    /* ================= phase 4: condenser (:591-621) ================= */
+    double lp_exhaust_quality = 0.90;
+    {
+      double h_f = npd_cond_hf(tr.condenser_pressure), h_g = npd_cond_hg(tr.condenser_pressure);
+      double h_fg = h_g - h_f;
+      if (h_fg > 0) {
+        lp_exhaust_quality = (tr.lp6_outlet_enthalpy - h_f) / h_fg;
+        lp_exhaust_quality = npd_pymax(0.0, npd_pymin(1.0, lp_exhaust_quality));
+      }
+    }
+    npd_condenser_result_t cr;
+    {
+      npb_cond_t cd; npb_chem_t ch;
+      NPD_LOAD(COND, npb_cond_t, cd, 0);
+      NPD_LOAD(CHEM, npb_chem_t, ch, 1);
+      npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
+                           cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr);
+      NPD_STORE(COND, npb_cond_t, cd, 0);
+      NPD_STORE(CHEM, npb_chem_t, ch, 1);
+    }
+    condenser_pressure = cr.condenser_pressure;
+    /* ================= electrical-power gates (:750-932) ================= */
+    double turbine_electrical_power = tr.electrical_power_net;
+    total_system_heat_rejection = (primary_thermal_power - turbine_electrical_power) * 1e6;
+    double power_reduction_factor = 1.0;
+    if (fw_total_flow < 300.0) power_reduction_factor = 0.0;
+    if (power_reduction_factor > 0.0) {
+      if (sg_total_steam < (300.0 * 0.5)) power_reduction_factor *= 0.1;
+      if (sg_avg_pressure < (1.0 * 0.5)) power_reduction_factor *= 0.1;
+      if (primary_thermal_power > (primary_thermal_power * 1.1)) power_reduction_factor = 0.0;
+    }
+    electrical_power = turbine_electrical_power * power_reduction_factor;
+    thermal_efficiency = (primary_thermal_power > 0) ? electrical_power / primary_thermal_power : 0.0;
+    if (tr.trip_active) trip_flags |= NPB_TRIP_TURBINE;
+  } else {
+    fw_total_flow = sg_total_steam; /* config-2 mode: feedwater == steam demand */
+  }
+
+  /* ================= secondary-level state write-back ================= */
+  NPD_F64_COL(SEC, npb_sec_t, electrical_power_output, 0) = electrical_power;
+  NPD_F64_COL(SEC, npb_sec_t, thermal_efficiency, 0) = thermal_efficiency;
+  NPD_F64_COL(SEC, npb_sec_t, total_steam_flow, 0) = sg_total_steam;
+  NPD_F64_COL(SEC, npb_sec_t, total_heat_transfer, 0) = sg_total_thermal;
+  NPD_F64_COL(SEC, npb_sec_t, total_feedwater_flow, 0) = fw_total_flow;
+  NPD_F64_COL(SEC, npb_sec_t, load_demand, 0) = load_demand;
+  NPD_F64_COL(SEC, npb_sec_t, cooling_water_temperature, 0) = cooling_water_temperature;
+  NPD_F64_COL(SEC, npb_sec_t, operating_hours, 0) += dt / 3600.0;
+  NPD_F64_COL(SEC, npb_sec_t, sg_avg_pressure, 0) = sg_avg_pressure;
+  NPD_F64_COL(SEC, npb_sec_t, sg_avg_temperature, 0) = sg_avg_temperature;
+  NPD_F64_COL(SEC, npb_sec_t, sg_avg_quality, 0) = sg_avg_quality;
+  NPD_I32_COL(SEC, npb_sec_t, has_previous_sg_conditions, 0) = 1;
+  NPD_I32_COL(SEC, npb_sec_t, sg_system_availability, 0) = sg_system_availability;
+
+  /* ================= _apply_secondary_to_primary_feedback  sim.py:429-498 ================= */
+  double heat_removal_factor = sg_total_steam / 1665.0;
+  if (!fw_available) heat_removal_factor *= 0.5;
+  NPD_F64_COL(PRIM, npb_prim_t, steam_flow_rate, 0) = sg_total_steam;
+  NPD_F64_COL(PRIM, npb_prim_t, last_heat_removal_factor, 0) = heat_removal_factor;
+  NPD_I32_COL(PRIM, npb_prim_t, has_heat_removal_factor, 0) = 1;
+
+  /* ================= observation / reward / done / flags / info ================= */
+  obs[7] = sg_total_steam / 3000;
+  obs[12] = electrical_power / 1100;
+  obs[13] = thermal_efficiency / 0.35;
+  obs[14] = sg_total_steam / 1665;
+  obs[15] = load_demand / 100;
+  obs[16] = 227.0 / 250;
+  obs[17] = cooling_water_temperature / 35;
+  obs[18] = fw_total_flow / 1665;
+  obs[19] = fw_total_power / 40;
+  obs[20] = (double)fw_available;
+  obs[21] = fw_total_flow / 1665;
+
+  /* calculate_reward  sim.py:521-542 */
+  double efficiency_reward = (thermal_efficiency - 0.30) * 10;
+  double target_electrical_power = load_demand / 100.0 * 1100.0;
+  double electrical_reward = -fabs(electrical_power - target_electrical_power) / 100;
+  double steam_pressure_penalty = 0;
+  if (sg_avg_pressure < 5.0 || sg_avg_pressure > 8.0) steam_pressure_penalty = -fabs(sg_avg_pressure - 6.895) * 5;
+  double condenser_penalty = 0;
+  if (condenser_pressure > 0.01) condenser_penalty = -(condenser_pressure - 0.007) * 100;
+  double secondary_reward = efficiency_reward + electrical_reward + steam_pressure_penalty + condenser_penalty;
+  double reward = base_reward + secondary_reward * 0.5;
+
+  if (scram_status) trip_flags |= NPB_TRIP_SCRAM;
+  if (scram_fired) trip_flags |= NPB_TRIP_SCRAM_FIRED;
+  if (nan_reset) trip_flags |= NPB_TRIP_NAN_RESET;
+
+  if (live) {
+    if (reward_out) reward_out[p] = reward;
+    if (done_out) done_out[p] = (uint8_t)scram_fired;
+    if (trip_out) trip_out[p] = trip_flags;
+  }
+  if (obs_out) npd_store_rows<NPB_OBS_DIM>(obs, obs_out, lds, block_base, (size_t)n_plants);
+  if (info_out) {
+    /* info  sim.py:199-250 with the non-finite substitutions of :231-240 */
+    info[NPB_INFO_ELECTRICAL_POWER] = isfinite(electrical_power) ? electrical_power : 0.0;
+    info[NPB_INFO_THERMAL_EFFICIENCY] = npd_pymax(0.0, npd_pymin(isfinite(thermal_efficiency) ? thermal_efficiency : 0.0, 0.35));
+    info[NPB_INFO_STEAM_FLOW] = isfinite(sg_total_steam) ? sg_total_steam : 1665.0;
+    info[NPB_INFO_STEAM_PRESSURE] = isfinite(sg_avg_pressure) ? sg_avg_pressure : 6.895;
+    info[NPB_INFO_CONDENSER_PRESSURE] = isfinite(condenser_pressure) ? condenser_pressure : 0.007;
+    info[NPB_INFO_CONDENSER_HEAT_REJECTION] = isfinite(total_system_heat_rejection) ? total_system_heat_rejection : 0.0;
+    info[NPB_INFO_FEEDWATER_FLOW] = fw_total_flow;
+    npd_store_rows<NPB_INFO_DIM>(info, info_out, lds, block_base, (size_t)n_plants);
+  }
+}
+
+/* get_observation() without stepping (after reset / set_field): sim.py:290-333 */
+__global__ __launch_bounds__(NPB_WAVE) void npb_observe_kernel(int mode, int n_plants, size_t N, const double *__restrict__ f64c,
+                                                               const int32_t *__restrict__ i32c, double *__restrict__ obs_out) {
+  __shared__ double lds[NPB_WAVE * NPB_OBS_PAD];
+  double *f64 = const_cast<double *>(f64c);
+  int32_t *i32 = const_cast<int32_t *>(i32c);
+  const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
+  const size_t p = block_base + threadIdx.x;
+  double obs[NPB_OBS_DIM];
+  npb_prim_t s;
+  NPD_LOAD(PRIM, npb_prim_t, s, 0);
+  npd_obs_primary(s, obs);
+  obs[12] = NPD_F64_COL(SEC, npb_sec_t, electrical_power_output, 0) / 1100;
+  obs[13] = NPD_F64_COL(SEC, npb_sec_t, thermal_efficiency, 0) / 0.35;
+  obs[14] = NPD_F64_COL(SEC, npb_sec_t, total_steam_flow, 0) / 1665;
+  obs[15] = NPD_F64_COL(SEC, npb_sec_t, load_demand, 0) / 100;
+  obs[16] = 227.0 / 250;
+  obs[17] = NPD_F64_COL(SEC, npb_sec_t, cooling_water_temperature, 0) / 35;
+  double fwf, fwp; int fwa;
+  if (mode == NPB_MODE_PRIMARY_SG) { fwf = NPD_F64_COL(SEC, npb_sec_t, total_feedwater_flow, 0); fwp = 0.0; fwa = 1; }
+  else {
+    fwf = NPD_F64_COL(FW, npb_fw_t, total_flow_rate, 0);
+    fwp = NPD_F64_COL(FW, npb_fw_t, total_power_consumption, 0);
+    fwa = NPD_I32_COL(FW, npb_fw_t, system_availability, 0) != 0;
+  }
+  obs[18] = fwf / 1665;
+  obs[19] = fwp / 40;
+  obs[20] = (double)fwa;
+  obs[21] = fwf / 1665;
+  npd_store_rows<NPB_OBS_DIM>(obs, obs_out, lds, block_base, (size_t)n_plants);
+}
+
+/* construction-time state for every plant selected by mask (NULL = all): the state the reference's
+ * constructors leave behind with the default SecondarySystemConfig (npd_init.h) */
+__global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size_t N, double *__restrict__ f64,
+                                                            int32_t *__restrict__ i32, const uint8_t *__restrict__ mask,
+                                                            int n_plants) {
+  const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
+  if (mask && p < (size_t)n_plants && !mask[p]) return;
+  if (mask && p >= (size_t)n_plants) return;
+  { npb_prim_t s; npd_prim_init(&s); NPD_STORE(PRIM, npb_prim_t, s, 0); }
+#pragma unroll 1
+  for (int i = 0; i < NPB_NUM_SG; i++) { npb_sg_t g; npd_sg_init(&g); NPD_STORE(SG, npb_sg_t, g, i); }
+#pragma unroll 1
+  for (int i = 0; i < NPB_NUM_PUMPS; i++) { npb_pump_t pm; npd_pump_init(&pm, i); NPD_STORE(PUMP, npb_pump_t, pm, i); }
+  { npb_fw_t fw; npd_fw_init(&fw); NPD_STORE(FW, npb_fw_t, fw, 0); }
+  { npb_turb_t t; npd_turb_init(&t); NPD_STORE(TURB, npb_turb_t, t, 0); }
+#pragma unroll 1
+  for (int i = 0; i < 2; i++) { npb_chem_t ch; npd_chem_init(&ch, i); NPD_STORE(CHEM, npb_chem_t, ch, i); }
+  { npb_cond_t cd; npd_cond_init(&cd); NPD_STORE(COND, npb_cond_t, cd, 0); }
+  { npb_sec_t sec; npd_sec_init(&sec); NPD_STORE(SEC, npb_sec_t, sec, 0); }
+  (void)P;
+}
+
+/* ---- host-side launchers (called from npb_api.hip) */
+extern "C" void npb_launch_step(const npb_params_t *P, int n_plants, size_t npad, double *f64, int32_t *i32,
+                                const int32_t *action, const double *magnitude, const double *setpoint,
+                                const double *noise_z, const double *cw_temp, double *obs, double *reward, uint8_t *done,
+                                uint32_t *trip_flags, double *info, hipStream_t stream) {
+  dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
+  hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, f64, i32, action, magnitude, setpoint,
+                     noise_z, cw_temp, obs, reward, done, trip_flags, info);
+}
+extern "C" void npb_launch_observe(int mode, int n_plants, size_t npad, const double *f64, const int32_t *i32, double *obs,
+                                   hipStream_t stream) {
+  dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
+  hipLaunchKernelGGL(npb_observe_kernel, grid, block, 0, stream, mode, n_plants, npad, f64, i32, obs);
+}
+extern "C" void npb_launch_init(const npb_params_t *P, int n_plants, size_t npad, double *f64, int32_t *i32,
+                                const uint8_t *mask, hipStream_t stream) {
+  dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
+  hipLaunchKernelGGL(npb_init_kernel, grid, block, 0, stream, *P, npad, f64, i32, mask, n_plants);
+}

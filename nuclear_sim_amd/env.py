@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference's simulator interface on top of the HIP stepper.
+
+``BatchedPlantEnv`` steps N independent plants per call (one wavefront lane per plant);
+``NuclearPlantSimulator`` / ``NuclearPlantEnv`` are single-plant facades with the reference's
+scalar signatures (simulator/core/sim.py:27-258, 911-940) so that existing loops
+(maintenance_scenario_runner.py:383-411, data/gen_training_data.py:249-290) run unchanged.
+
+PyTorch is only the device-array container: every tensor handed to the library is passed as
+a raw device pointer (``tensor.data_ptr()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .schema import SCHEMA
+
+
+class ControlAction(enum.Enum):
+    """systems/primary/__init__.py:28-45"""
+    CONTROL_ROD_INSERT = 0
+    CONTROL_ROD_WITHDRAW = 1
+    INCREASE_COOLANT_FLOW = 2
+    DECREASE_COOLANT_FLOW = 3
+    OPEN_STEAM_VALVE = 4
+    CLOSE_STEAM_VALVE = 5
+    INCREASE_FEEDWATER = 6
+    DECREASE_FEEDWATER = 7
+    NO_ACTION = 8
+    DILUTE_BORON = 9
+    BORATE_COOLANT = 10
+    START_FEEDWATER_PUMP = 11
+    STOP_FEEDWATER_PUMP = 12
+    INCREASE_FEEDWATER_PUMP_SPEED = 13
+    DECREASE_FEEDWATER_PUMP_SPEED = 14
+
+
+INFO_COLUMNS = ("thermal_power", "reactivity", "electrical_power", "thermal_efficiency", "steam_flow",
+                "steam_pressure", "condenser_pressure", "condenser_heat_rejection", "time", "feedwater_flow")
+
+
+class HeatSourceNoise:
+    """Per-plant pre-drawn heat-source noise, bit-identical to the reference's
+    ``np.random.RandomState(seed).normal(0, sigma)`` stream (constant_heat_source.py:58-62,178):
+    numpy's legacy normal is loc + scale * gauss, so the standard-normal stream of the same
+    RandomState reproduces it exactly.  Drawn on the host in blocks."""
+
+    def __init__(self, seeds: Sequence[int], block: int = 256):
+        self._rngs = [np.random.RandomState(int(s)) for s in seeds]
+        self._block = block
+        self._buf = None
+        self._pos = block
+
+    def next(self) -> np.ndarray:
+        if self._pos >= self._block:
+            self._buf = np.stack([r.standard_normal(self._block) for r in self._rngs])
+            self._pos = 0
+        out = np.ascontiguousarray(self._buf[:, self._pos])
+        self._pos += 1
+        return out
+
+
+def equilibrium_state(power_level: float = 100.0, control_rod_position: float = 95.0) -> Dict[str, object]:
+    """create_equilibrium_state(auto_balance=True)  reactivity_model.py:443-529, as a field dict
+    for ``BatchedPlantEnv.set_fields``."""
+    beta = [0.000215, 0.001424, 0.001274, 0.002568, 0.000748, 0.000273]
+    lam = [0.077, 0.311, 1.40, 3.87, 1.40, 0.195]
+    flux = 1e13 * (power_level / 100.0)
+    prec = [(beta[i] / lam[i]) * (flux / 1e-5) for i in range(6)]
+    fuel_t = 575.0 + (power_level - 100.0) * 2.0
+    cool_t = 293.0 + (17.0 * (power_level / 100.0))
+    # total reactivity without boron (ReactivityModel.calculate_total_reactivity, boron = 0)
+    pos = min(max(control_rod_position / 100.0, 0.0), 1.0)
+    comps = [3000.0 * (pos - 0.5), -10.0 * 0.0, -2.5e-5 * (fuel_t - 575.0) * 1e5, -3.0e-5 * (cool_t - 280.0) * 1e5,
+             -1000.0 * 0.0, 0.5 * (15.5 - 15.5), (1.0e15 / 1.0e15) * -1800.0, (5.0e14 / 5.0e14) * -600.0,
+             3340.0 + -0.15 * 15000.0, 0.0 * float(np.exp(-0.0002 * 15000.0))]
+    total = 0
+    for c in comps:
+        total = total + c
+    boron = max(0, (total - 0.0) / -10.0)
+    d = {"prim.neutron_flux": 1e13, "prim.power_level": 100.0, "prim.control_rod_position": control_rod_position,
+         "prim.xenon_concentration": 1.0e15, "prim.iodine_concentration": 1.5e16,
+         "prim.samarium_concentration": 5.0e14, "prim.fuel_temperature": fuel_t,
+         "prim.coolant_temperature": cool_t, "prim.boron_concentration": boron}
+    for i in range(6):
+        d[("prim.precursors", 0, i)] = prec[i]
+    return d
+
+
+class BatchedPlantEnv:
+    """N plants behind the reference's step()/reset()/observation contract, as columns.
+
+    step() returns ``(obs[N,22], reward[N], done[N], info)`` where ``info`` holds column tensors
+    (``electrical_power``, ``trip_flags``, ...) instead of one dict per plant.
+    """
+
+    action_space_size = 15       # NuclearPlantEnv sim.py:916
+    observation_space_size = 22  # sim.py:917-918
+
+    def __init__(self, n_envs: int, dt: float = 1.0, heat_source: str = "constant", noise_enabled: bool = False,
+                 noise_std_percent: float = 0.1, noise_seeds: Optional[Sequence[int]] = None,
+                 mode: str = "full", device: int = 0, params: Optional[dict] = None):
+        if not torch.cuda.is_available():
+            raise _lib.NpbError("BatchedPlantEnv needs a HIP device (torch.cuda.is_available() is False); "
+                                "there is no CPU fallback")
+        self.L = _lib.load()
+        self.n = int(n_envs)
+        self.device = torch.device("cuda", device)
+        p = _lib.default_params()
+        p.dt = float(dt)
+        p.heat_source = {"constant": _lib.HEAT_CONSTANT, "reactor": _lib.HEAT_REACTOR}[heat_source]
+        p.hs_noise_enabled = int(bool(noise_enabled))
+        p.hs_noise_std_percent = float(noise_std_percent)
+        p.mode = {"full": _lib.MODE_FULL, "primary_sg": _lib.MODE_PRIMARY_SG}[mode]
+        for k, v in (params or {}).items():
+            setattr(p, k, v)
+        self.params = p
+        self.dt = float(dt)
+        self._h = ctypes.c_void_p()
+        _lib.check(self.L.npb_create(ctypes.byref(p), self.n, device, ctypes.byref(self._h)))
+        with torch.cuda.device(self.device):
+            self._obs = torch.zeros((self.n, 22), dtype=torch.float64, device=self.device)
+            self._reward = torch.zeros(self.n, dtype=torch.float64, device=self.device)
+            self._done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+            self._flags = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+            self._info = torch.zeros((self.n, 10), dtype=torch.float64, device=self.device)
+        self._noise = None
+        if noise_enabled and noise_seeds is not None:
+            self._noise = HeatSourceNoise(noise_seeds)
+        self._keep = []
+
+    # ------------------------------------------------------------------ helpers
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.L.npb_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _col(self, x, dtype):
+        """None | scalar | array | tensor -> device tensor of shape [n] (kept alive until the next step)."""
+        if x is None:
+            return None
+        if isinstance(x, torch.Tensor):
+            t = x.to(device=self.device, dtype=dtype).expand(self.n).contiguous()
+        else:
+            a = np.asarray(x)
+            t = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(a, (self.n,))), dtype=dtype).to(self.device)
+        self._keep.append(t)
+        return t
+
+    @staticmethod
+    def _p(t):
+        return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+    # ------------------------------------------------------------------ state columns
+    def get_field(self, name: str, instance: int = 0, k: int = 0) -> torch.Tensor:
+        kind, slot = SCHEMA.slot(name, instance, k)
+        t = torch.empty(self.n, dtype=torch.float64 if kind == "f64" else torch.int32, device=self.device)
+        _lib.check(self.L.npb_get_field(self._h, 0 if kind == "f64" else 1, slot, self._p(t), 1, self._stream()), self._h)
+        return t
+
+    def set_field(self, name: str, value, instance: int = 0, k: int = 0) -> None:
+        kind, slot = SCHEMA.slot(name, instance, k)
+        t = self._col(value, torch.float64 if kind == "f64" else torch.int32)
+        _lib.check(self.L.npb_set_field(self._h, 0 if kind == "f64" else 1, slot, self._p(t), 1, self._stream()), self._h)
+
+    def set_fields(self, fields: dict) -> None:
+        for key, v in fields.items():
+            if isinstance(key, tuple):
+                self.set_field(key[0], v, *key[1:])
+            else:
+                self.set_field(key, v)
+
+    def state_arrays(self):
+        """(f64[total_f64, n], i32[total_i32, n]) copies of the whole arena (testing / checkpointing)."""
+        f = torch.empty((SCHEMA.total_f64, self.n), dtype=torch.float64, device=self.device)
+        i = torch.empty((SCHEMA.total_i32, self.n), dtype=torch.int32, device=self.device)
+        for s in range(SCHEMA.total_f64):
+            _lib.check(self.L.npb_get_field(self._h, 0, s, ctypes.c_void_p(f[s].data_ptr()), 1, self._stream()), self._h)
+        for s in range(SCHEMA.total_i32):
+            _lib.check(self.L.npb_get_field(self._h, 1, s, ctypes.c_void_p(i[s].data_ptr()), 1, self._stream()), self._h)
+        return f, i
+
+    def load_state_arrays(self, f64, i32) -> None:
+        f = torch.as_tensor(f64, dtype=torch.float64).to(self.device).contiguous()
+        i = torch.as_tensor(i32, dtype=torch.int32).to(self.device).contiguous()
+        for s in range(SCHEMA.total_f64):
+            _lib.check(self.L.npb_set_field(self._h, 0, s, ctypes.c_void_p(f[s].data_ptr()), 1, self._stream()), self._h)
+        for s in range(SCHEMA.total_i32):
+            _lib.check(self.L.npb_set_field(self._h, 1, s, ctypes.c_void_p(i[s].data_ptr()), 1, self._stream()), self._h)
+        torch.cuda.synchronize(self.device)
+
+    @staticmethod
+    def state_bytes_per_plant() -> int:
+        return int(_lib.load().npb_state_bytes())
+
+    @staticmethod
+    def step_bytes_per_plant() -> int:
+        return int(_lib.load().npb_step_bytes_per_plant())
+
+    # ------------------------------------------------------------------ reference API
+    def reset(self, mask=None) -> torch.Tensor:
+        """Back to the construction-time state (episode start of the data-gen runner)."""
+        m = self._col(mask, torch.uint8)
+        _lib.check(self.L.npb_reset(self._h, self._p(m), self._stream()), self._h)
+        return self.get_observation()
+
+    def get_observation(self) -> torch.Tensor:
+        _lib.check(self.L.npb_observe(self._h, self._p(self._obs), self._stream()), self._h)
+        return self._obs
+
+    def step(self, action=None, magnitude=None, power_setpoint=None, cooling_water_temp=None, noise_z=None):
+        self._keep = []
+        a = self._col(None if action is None else action, torch.int32)
+        m = self._col(magnitude, torch.float64)
+        sp = self._col(power_setpoint, torch.float64)
+        cw = self._col(cooling_water_temp, torch.float64)
+        if noise_z is None and self._noise is not None:
+            noise_z = self._noise.next()
+        z = self._col(noise_z, torch.float64)
+        _lib.check(self.L.npb_step(self._h, self._p(a), self._p(m), self._p(sp), self._p(z), self._p(cw),
+                                   self._p(self._obs), self._p(self._reward), self._p(self._done), self._p(self._flags),
+                                   self._p(self._info), self._stream()), self._h)
+        info = {name: self._info[:, j] for j, name in enumerate(INFO_COLUMNS)}
+        info["trip_flags"] = self._flags
+        info["scram_activated"] = self._done
+        return self._obs, self._reward, self._done, info
+
+
+class NuclearPlantSimulator:
+    """Single-plant facade with the reference's scalar signatures (sim.py:27-258)."""
+
+    def __init__(self, dt: float = 1.0, heat_source: str = "constant", enable_secondary: bool = True,
+                 noise_enabled: bool = False, noise_std_percent: float = 0.1, noise_seed: Optional[int] = None,
+                 device: int = 0):
+        if not enable_secondary:
+            raise NotImplementedError("the HIP stepper always runs the secondary side")
+        self.dt = dt
+        self._env = BatchedPlantEnv(1, dt=dt, heat_source=heat_source, noise_enabled=noise_enabled,
+                                    noise_std_percent=noise_std_percent,
+                                    noise_seeds=None if noise_seed is None else [noise_seed], device=device)
+        self._setpoint = None
+
+    def set_power_setpoint(self, power_percent: float) -> None:
+        """heat_source.set_power_setpoint  constant_heat_source.py:93-102 (applied at the next step)."""
+        self._setpoint = float(power_percent)
+
+    def step(self, action: Optional[ControlAction] = None, magnitude: float = 1.0, load_demand: float = None,
+             cooling_water_temp: float = None) -> Dict:
+        a = ControlAction.NO_ACTION.value if action is None else (action.value if isinstance(action, ControlAction) else int(action))
+        obs, rew, done, info = self._env.step(action=[a], magnitude=[magnitude],
+                                              power_setpoint=None if self._setpoint is None else [self._setpoint],
+                                              cooling_water_temp=None if cooling_water_temp is None else [cooling_water_temp])
+        self._setpoint = None
+        o = obs[0].cpu().numpy().copy()
+        inf = {k: (v[0].item()) for k, v in info.items()}
+        inf["scram_activated"] = bool(inf["scram_activated"])
+        return {"observation": o, "reward": float(rew[0].item()), "done": bool(done[0].item()), "info": inf}
+
+    def reset(self, start_at_steady_state: bool = True):
+        return self._env.reset()[0].cpu().numpy().copy()
+
+    def get_observation(self) -> np.ndarray:
+        return self._env.get_observation()[0].cpu().numpy().copy()
+
+
+class NuclearPlantEnv:
+    """Gym-style wrapper  sim.py:911-940."""
+
+    def __init__(self, **kw):
+        self.sim = NuclearPlantSimulator(**kw)
+        self.action_space_size = len(ControlAction)
+        self.observation_space_size = 22
+
+    def reset(self):
+        return self.sim.reset()
+
+    def step(self, action_idx: int, load_demand: float = None, cooling_water_temp: float = None):
+        r = self.sim.step(ControlAction(action_idx), load_demand=load_demand, cooling_water_temp=cooling_water_temp)
+        return r["observation"], r["reward"], r["done"], r["info"]

@@ -1,7 +1,7 @@
 """State schema of the batched plant stepper, parsed from ``include/npb_fields.h``.
 
-The header is the single source of truth (it also generates the device structs
-and the oracle's plant record); this module only reads it so that Python can
+The header is the single source of truth (it also generates the device register
+structs); this module only reads it so that Python can
 address state columns by name: ``SCHEMA.f64["sg.water_level"][i]`` -> slot.
 
 Slot numbering (must match npb_fields.h): section-major, then instance, then

@@ -32,7 +32,7 @@ def lib():
         L.npo_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.npo_get_all.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.npo_step_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 10
-        L.npo_observe_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.npo_observe_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _LIB = L
     return _LIB
 
@@ -131,7 +131,7 @@ class OraclePlants:
 
     def observe(self):
         obs = np.zeros((self.n, 22))
-        self.L.npo_observe_batch(_ptr(self._buf), self.n, _ptr(obs))
+        self.L.npo_observe_batch(_ptr(self._buf), self.n, self.params.ptr, _ptr(obs))
         return obs
 
     def step(self, action=None, magnitude=None, setpoint=None, noise_z=None, cw_temp=None):

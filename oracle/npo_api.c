@@ -54,6 +54,6 @@ NPO_API void npo_step_batch(npo_plant_t *plants, int n, const npb_params_t *P,
     if (info) memcpy(info + (size_t)i * NPB_INFO_DIM, o.info, sizeof(o.info));
   }
 }
-NPO_API void npo_observe_batch(npo_plant_t *plants, int n, double *obs) {
-  for (int i = 0; i < n; i++) npo_observation(&plants[i], obs + (size_t)i * NPB_OBS_DIM);
+NPO_API void npo_observe_batch(npo_plant_t *plants, int n, const npb_params_t *P, double *obs) {
+  for (int i = 0; i < n; i++) npo_observation(&plants[i], P->mode, obs + (size_t)i * NPB_OBS_DIM);
 }

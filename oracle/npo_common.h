@@ -20,8 +20,7 @@
 #include <math.h>
 #include <string.h>
 #include <stdint.h>
-#include "../include/npb_fields.h"
-#include "../include/npb_params.h"
+#include "../include/npb.h"
 
 #ifndef NPO_FN
 #define NPO_FN static inline
@@ -42,24 +41,6 @@ typedef struct npo_inputs_t {
   double noise_z;          /* standard normal sample for constant_heat_source.py:178 */
   double cooling_water_temp; /* step(cooling_water_temp=...); NaN = leave unchanged */
 } npo_inputs_t;
-
-enum { NPB_OBS_DIM = 22, NPB_INFO_DIM = 10 };
-/* info columns (sim.py:199-250) */
-enum {
-  NPB_INFO_THERMAL_POWER = 0, NPB_INFO_REACTIVITY_PCM, NPB_INFO_ELECTRICAL_POWER,
-  NPB_INFO_THERMAL_EFFICIENCY, NPB_INFO_STEAM_FLOW, NPB_INFO_STEAM_PRESSURE,
-  NPB_INFO_CONDENSER_PRESSURE, NPB_INFO_CONDENSER_HEAT_REJECTION, NPB_INFO_TIME,
-  NPB_INFO_FEEDWATER_FLOW
-};
-/* trip flag bits */
-enum {
-  NPB_TRIP_SCRAM = 1u << 0,        /* scram_status latched */
-  NPB_TRIP_SCRAM_FIRED = 1u << 1,  /* scram fired on this step (== done) */
-  NPB_TRIP_NAN_RESET = 1u << 2,    /* thermal_hydraulics.py:247 reset taken */
-  NPB_TRIP_TURBINE = 1u << 3,      /* turbine protection trip_active */
-  NPB_TRIP_FW_SYSTEM = 1u << 4,    /* feedwater protection system_trip_active */
-  NPB_TRIP_FW_PUMP0 = 1u << 8      /* bits 8..11: feedwater pump i tripped */
-};
 
 typedef struct npo_outputs_t {
   double obs[NPB_OBS_DIM];

@@ -25,7 +25,8 @@ typedef struct npo_secondary_result_t {
 } npo_secondary_result_t;
 
 /* what get_observation() reads from feedwater_state (sim.py:323-329) */
-NPO_FN void npo_feedwater_obs(const npo_plant_t *pl, double *flow, double *power, int *avail) {
+NPO_FN void npo_feedwater_obs(const npo_plant_t *pl, int mode, double *flow, double *power, int *avail) {
+  if (mode == NPB_MODE_PRIMARY_SG) { *flow = pl->sec.total_feedwater_flow; *power = 0.0; *avail = 1; return; }
   *flow = pl->fw.total_flow_rate;
   *power = pl->fw.total_power_consumption;
   *avail = pl->fw.system_availability;
@@ -79,8 +80,8 @@ NPO_FN void npo_secondary_update(npo_plant_t *pl, const npb_params_t *P, const n
   double estimated_steam_flow_per_sg = 555.0 * load_demand_fraction;
   double prev_levels[NPB_NUM_SG], prev_flows[NPB_NUM_SG], prev_quals[NPB_NUM_SG];
   for (int i = 0; i < NPB_NUM_SG; i++) {
-    if (sec->has_previous_sg_conditions) {
-      prev_levels[i] = pl->sg[i].water_level; prev_flows[i] = pl->sg[i].steam_flow_rate; prev_quals[i] = pl->sg[i].steam_quality;
+    if (sec->has_previous_sg_conditions) { /* the stored copy (:530-535), not the SG objects */
+      prev_levels[i] = sec->prev_sg_levels[i]; prev_flows[i] = sec->prev_sg_steam_flows[i]; prev_quals[i] = sec->prev_sg_qualities[i];
     } else { /* :447-453 hard-coded first-step values, not the SG initial conditions */
       prev_levels[i] = 12.5; prev_flows[i] = estimated_steam_flow_per_sg; prev_quals[i] = 0.99;
     }
@@ -95,6 +96,10 @@ NPO_FN void npo_secondary_update(npo_plant_t *pl, const npb_params_t *P, const n
   npo_sgsys_result_t sgr;
   npo_sgsys_update(pl->sg, sec, P, c, load_demand_fraction, fw_flows, actual_feedwater_temp, dt * 60, &sgr);
   sec->has_previous_sg_conditions = 1;
+  for (int i = 0; i < NPB_NUM_SG; i++) {
+    sec->prev_sg_levels[i] = pl->sg[i].water_level; sec->prev_sg_steam_flows[i] = sgr.sg_steam_flow[i];
+    sec->prev_sg_qualities[i] = pl->sg[i].steam_quality;
+  }
   double avg_steam_pressure = sgr.avg_pressure;
   double total_steam_flow = sgr.total_steam_flow;
 

@@ -14,7 +14,7 @@
 #include "npo_secondary.h"
 
 /* get_observation  sim.py:290-333 */
-NPO_FN void npo_observation(const npo_plant_t *pl, double *obs) {
+NPO_FN void npo_observation(const npo_plant_t *pl, int mode, double *obs) {
   const npb_prim_t *s = &pl->prim;
   const npb_sec_t *sec = &pl->sec;
   obs[0] = s->neutron_flux / 1e12;
@@ -36,7 +36,7 @@ NPO_FN void npo_observation(const npo_plant_t *pl, double *obs) {
   obs[16] = 227.0 / 250; /* secondary feedwater_temperature is always the 227.0 sim.py:166 passes */
   obs[17] = sec->cooling_water_temperature / 35;
   double fw_flow, fw_power; int fw_avail;
-  npo_feedwater_obs(pl, &fw_flow, &fw_power, &fw_avail);
+  npo_feedwater_obs(pl, mode, &fw_flow, &fw_power, &fw_avail);
   obs[18] = fw_flow / 1665;
   obs[19] = fw_power / 40;
   obs[20] = (double)fw_avail;
@@ -92,7 +92,7 @@ NPO_FN void npo_step(npo_plant_t *pl, const npb_params_t *P, const npo_inputs_t 
 
   s->sim_time += P->dt; /* sim.py:189-193 (state management disabled) */
 
-  npo_observation(pl, out->obs);
+  npo_observation(pl, P->mode, out->obs);
   out->reward = npo_reward(pl, &r);
   out->done = (uint8_t)scram_fired;
   uint32_t flags = r.trip_flags;

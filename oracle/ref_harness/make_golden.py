@@ -1,0 +1,90 @@
+"""Generate the golden vectors under tests/golden/ by running the *reference* simulator
+(/root/reference, this container only).  Each fixture holds one scenario's inputs and the
+reference's outputs, plus the value of every schema column's reference attribute:
+
+  action[T] magnitude[T] setpoint[T] cooling[T] noise_z[T]     per-step inputs
+  obs[T,22] reward[T] done[T] info[T,10]                        per-step outputs
+  state_steps[K], state[K,ncol]                                 sampled state trajectory (step 0 = initial)
+  labels[ncol]                                                  schema column labels (f64 then i32 order of SCHEMA.columns())
+  meta (json)                                                   ctor kwargs / scenario description
+
+Run:  python -m oracle.ref_harness.make_golden        (from the repo root)
+The fixtures are data; the reference itself never leaves this container.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+from nuclear_sim_amd.schema import SCHEMA
+from . import trace
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
+
+
+def scenarios():
+    rng = np.random.default_rng(1235)
+    acts = rng.choice([0, 1, 2, 3, 8, 9, 10, 4, 5], size=400)
+    mags = rng.uniform(0, 1, size=400)
+    S = []
+    # S1: constant-heat steady state, noise off (BASELINE config 1 plumbing) -- long, sampled sparsely
+    S.append(dict(name="s1_constant_steady", steps=1000, every=50))
+    # S1b: constant heat with the data-gen runner's noise (seed 42, 0.1 %)
+    S.append(dict(name="s1b_constant_noise", steps=150, noise=True, noise_seed=42, every=1))
+    # S2: reactor heat source from the equilibrium state with random actuator actions
+    S.append(dict(name="s2_reactor_actions", steps=300, heat_source="reactor", equilibrium=(100.0, 95.0),
+                  actions=lambda t: (int(acts[t]), float(mags[t])), every=5))
+    # S3: default ReactorState() (boron 12 000 ppm -> flux collapse through the clip bands)
+    S.append(dict(name="s3_default_reactor", steps=200, heat_source="reactor", every=5))
+    # S4a: scram by over-power (flux poked to 130 %) and, in a second life after clearing the latch, by pressure
+    S.append(dict(name="s4a_scram_overpower", steps=120, heat_source="reactor", equilibrium=(100.0, 95.0), every=2,
+                  pokes={15: [("primary_physics.state.neutron_flux", 1.3e13)],
+                         70: [("primary_physics.state.scram_status", False), ("primary_physics.state.coolant_pressure", 17.5)]}))
+    # S4b: scram by forced fuel temperature (tests/test_scenarios.py:98-110)
+    S.append(dict(name="s4b_scram_fuel_temp", steps=80, heat_source="reactor", equilibrium=(100.0, 95.0),
+                  pokes={20: [("primary_physics.state.fuel_temperature", 1600.0)]}, every=2))
+    # S5: load following through set_power_setpoint + cooling-water swings
+    S.append(dict(name="s5_load_following", steps=400, noise=True, noise_seed=7,
+                  setpoints=lambda t: 100.0 - 30.0 * min(1.0, t / 60.0) if t < 150 else 70.0 + 30.0 * min(1.0, (t - 150) / 60.0),
+                  cooling=lambda t: 25.0 + 5.0 * float(np.sin(t / 20.0)), every=5))
+    # S7: pump-trip paths poked mid-run: oil level 9 %, NPSH 11 m, previous-step SG level 16.2 m (trips every pump)
+    S.append(dict(name="s7_pump_trips", steps=140, noise=True, noise_seed=3, every=2, pokes={
+        30: [("secondary_physics.feedwater_system.pump_system.pumps['FWP-1'].lubrication_system.oil_level", 9.0)],
+        60: [("secondary_physics.feedwater_system.pump_system.pumps['FWP-2'].state.npsh_available", 11.0)],
+        100: [("secondary_physics._previous_sg_conditions['levels'][0]", 16.2)]}))
+    # S8: dt = 0.1 (unit-heuristic coverage)
+    S.append(dict(name="s8_dt_0p1", steps=200, dt=0.1, noise=True, noise_seed=11, every=5))
+    # S6: oil_top_off initial conditions (feedwater_conditions.py:81-96 base values, pump 1 near the 58 % threshold)
+    S.append(dict(name="s6_oil_levels", steps=120, noise=True, noise_seed=42, every=4,
+                  secondary={"feedwater": {"initial_conditions": {"pump_oil_levels": [59.4, 62.0, 64.0, 90.0]}}}))
+    return S
+
+
+def main(only=None):
+    os.makedirs(OUT, exist_ok=True)
+    cols = SCHEMA.columns()
+    labels = np.array([c[2] for c in cols])
+    kinds = np.array([c[0] for c in cols])
+    for sc in scenarios():
+        if only and sc["name"] not in only:
+            continue
+        ref, _sim = trace.run_reference(sc, cols)
+        T = sc["steps"]
+        every = sc.get("every", 1)
+        steps = sorted(set(list(range(0, T + 1, every)) + [T] + [t + 1 for t in sc.get("pokes", {})] + list(sc.get("pokes", {}).keys())))
+        meta = {k: v for k, v in sc.items() if not callable(v) and k not in ("pokes",)}
+        meta["pokes"] = {str(k): [[p, float(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
+        # pokes expressed in schema labels so tests can replay them without the reference
+        path_to_label = {c[3]: (c[0], c[1], c[2]) for c in cols}
+        meta["pokes_schema"] = {str(k): [[path_to_label[p][2], float(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
+        np.savez_compressed(os.path.join(OUT, sc["name"] + ".npz"),
+                            action=ref["action"], magnitude=ref["magnitude"], setpoint=ref["setpoint"],
+                            cooling=ref["cooling"], noise_z=ref["noise_z"], obs=ref["obs"], reward=ref["reward"],
+                            done=ref["done"], info=ref["info"], state_steps=np.array(steps),
+                            state=ref["state"][steps], labels=labels, kinds=kinds, meta=json.dumps(meta))
+        print(sc["name"], "steps", T, "dones", int(ref["done"].sum()), "elec", float(ref["obs"][-1, 12] * 1100))
+
+
+if __name__ == "__main__":
+    main(only=set(sys.argv[1:]) or None)

@@ -1,0 +1,72 @@
+"""Shared helpers: load a golden fixture and replay it through a stepper."""
+import glob
+import json
+import os
+
+import numpy as np
+
+from nuclear_sim_amd.schema import SCHEMA
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# state columns owned by subsystems that are not restated yet (the shared WaterChemistry +
+# pH controller sidecar): present in the schema/fixtures, excluded from parity
+EXEMPT_PREFIXES = ("chem[0].",)
+# fp64 tolerance of the parity contract (BASELINE.json north_star: 1e-6 relative on fp64 state)
+RTOL = 1e-6
+# columns that are differences of nearly equal numbers (1 - area ratio ~ 1e-8..1e-7): their relative error
+# is an amplified 1-ulp effect, so they are checked with an absolute floor instead
+ATOL_SMALL = 1e-12
+
+
+def fixture_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+class Golden:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+        self.name = name
+        self.meta = json.loads(str(z["meta"]))
+        for k in ("action", "magnitude", "setpoint", "cooling", "noise_z", "obs", "reward", "done", "info",
+                  "state_steps", "state", "labels", "kinds"):
+            setattr(self, k, z[k])
+        self.T = len(self.action)
+        cols = SCHEMA.columns()
+        assert [c[2] for c in cols] == list(self.labels), "fixture was generated with a different schema: regenerate"
+        self.cols = cols
+        self.pokes = {int(k): v for k, v in self.meta.get("pokes_schema", {}).items()}
+
+    def split_state(self, row):
+        """fixture state row -> (f64[total_f64], i32[total_i32]); NaN (no reference leaf) -> None mask."""
+        f = np.zeros(SCHEMA.total_f64); i = np.zeros(SCHEMA.total_i32, dtype=np.int64)
+        fm = np.zeros(SCHEMA.total_f64, dtype=bool); im = np.zeros(SCHEMA.total_i32, dtype=bool)
+        for (kind, slot, label, _p), v in zip(self.cols, row):
+            if np.isnan(v):
+                continue
+            if kind == "f64":
+                f[slot] = v; fm[slot] = True
+            else:
+                i[slot] = int(v); im[slot] = True
+        return f, i, fm, im
+
+    def label_slot(self, label):
+        for kind, slot, lab, _p in self.cols:
+            if lab == label:
+                return kind, slot
+        raise KeyError(label)
+
+
+def compare_state(g, f64, i32, row, where):
+    """Assert a stepper's (f64, i32) state against a fixture row."""
+    bad = []
+    for (kind, slot, label, _p), v in zip(g.cols, row):
+        if np.isnan(v) or label.startswith(EXEMPT_PREFIXES):
+            continue
+        if kind == "i32":
+            if int(i32[slot]) != int(v):
+                bad.append((label, int(i32[slot]), int(v)))
+        else:
+            mine = float(f64[slot])
+            if not (abs(mine - v) <= RTOL * abs(v) + ATOL_SMALL):
+                bad.append((label, mine, float(v)))
+    assert not bad, "%s %s: %d mismatching columns, first: %s" % (g.name, where, len(bad), bad[:5])

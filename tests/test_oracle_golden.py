@@ -1,0 +1,70 @@
+"""CPU: the C oracle (oracle/) against the golden vectors generated from the reference
+(tests/golden/, generator oracle/ref_harness/make_golden.py).  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from golden_util import Golden, compare_state, fixture_names, RTOL
+
+
+def _configure(npo, g):
+    P = npo.Params()
+    m = g.meta
+    P.dt = m.get("dt", 1.0)
+    P.heat_source = 1 if m.get("heat_source") == "reactor" else 0
+    P.hs_noise_enabled = 1 if m.get("noise") else 0
+    P.hs_noise_std_percent = m.get("noise_std_percent", 0.1)
+    return P
+
+
+def test_default_construction_state_matches_reference(oracle_lib):
+    """npo_plant_init == state of a freshly constructed reference simulator (default config)."""
+    g = Golden("s1_constant_steady")
+    o = oracle_lib.OraclePlants(1, _configure(oracle_lib, g))
+    f, i = o.state()
+    compare_state(g, f, i, g.state[0], "construction state")
+
+
+@pytest.mark.parametrize("name", fixture_names())
+def test_oracle_replays_golden(oracle_lib, name):
+    g = Golden(name)
+    o = oracle_lib.OraclePlants(1, _configure(oracle_lib, g))
+    # start from the fixture's initial state (covers equilibrium starts and IC overrides)
+    f0, i0 = o.state()
+    f, i, fm, im = g.split_state(g.state[0])
+    f0[fm] = f[fm]; i0[im] = i[im]
+    o.set_state(f0, i0)
+    sampled = {int(s): k for k, s in enumerate(g.state_steps)}
+    for t in range(g.T):
+        for label, v in g.pokes.get(t, []):
+            kind, slot = g.label_slot(label)
+            if kind == "f64":
+                o.L.npo_set_f64(o._buf.ctypes.data, 0, slot, float(v))
+            else:
+                o.L.npo_set_i32(o._buf.ctypes.data, 0, slot, int(v))
+        obs, rew, done, flags, info = o.step(action=g.action[t], magnitude=g.magnitude[t], setpoint=g.setpoint[t],
+                                             noise_z=g.noise_z[t], cw_temp=g.cooling[t])
+        np.testing.assert_allclose(obs[0], g.obs[t], rtol=RTOL, atol=1e-12, err_msg="%s obs step %d" % (name, t))
+        np.testing.assert_allclose(rew[0], g.reward[t], rtol=RTOL, atol=1e-9, err_msg="%s reward step %d" % (name, t))
+        assert int(done[0]) == int(g.done[t]), "%s done step %d" % (name, t)
+        m = ~np.isnan(g.info[t])
+        np.testing.assert_allclose(info[0][m], g.info[t][m], rtol=RTOL, atol=1e-9, err_msg="%s info step %d" % (name, t))
+        if t + 1 in sampled:
+            fs, is_ = o.state()
+            compare_state(g, fs, is_, g.state[sampled[t + 1]], "after step %d" % t)
+
+
+def test_known_answers_from_reference_tests(oracle_lib):
+    """Coarse known-answer checks lifted from the reference's own tests:
+    ConstantHeatSource 90 % -> 2700 MW (tests/test_heat_sources.py:87-105); scram on forced fuel
+    temperature 1600 C sets rods to 0 and done (tests/test_scenarios.py:98-110)."""
+    P = oracle_lib.Params()
+    o = oracle_lib.OraclePlants(1, P)
+    obs, rew, done, flags, info = o.step(setpoint=90.0)
+    assert info[0][0] == pytest.approx(2700.0)
+    P2 = oracle_lib.Params(); P2.heat_source = 1
+    o2 = oracle_lib.OraclePlants(1, P2)
+    o2.set("prim.fuel_temperature", 1600.0)
+    obs, rew, done, flags, info = o2.step()
+    assert done[0] == 1 and o2.get("prim.control_rod_position") == 0.0 and o2.get("prim.scram_status") == 1
+    obs, rew, done, flags, info = o2.step()
+    assert done[0] == 0  # one-shot: True only on the firing step
