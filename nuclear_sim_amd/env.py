@@ -157,7 +157,7 @@ class BatchedPlantEnv:
             t = x.to(device=self.device, dtype=dtype).expand(self.n).contiguous()
         else:
             a = np.asarray(x)
-            t = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(a, (self.n,))), dtype=dtype).to(self.device)
+            t = torch.as_tensor(np.array(np.broadcast_to(a, (self.n,))), dtype=dtype).to(self.device)
         self._keep.append(t)
         return t
 

@@ -63,6 +63,10 @@ NPO_FN void npo_secondary_update(npo_plant_t *pl, const npb_params_t *P, const n
     npo_sgsys_result_t sgr;
     npo_sgsys_update(pl->sg, sec, P, c, load_demand_fraction, 0, actual_feedwater_temp, dt * 60, &sgr);
     sec->has_previous_sg_conditions = 1;
+    for (int i = 0; i < NPB_NUM_SG; i++) {
+      sec->prev_sg_levels[i] = pl->sg[i].water_level; sec->prev_sg_steam_flows[i] = sgr.sg_steam_flow[i];
+      sec->prev_sg_qualities[i] = pl->sg[i].steam_quality;
+    }
     sec->total_steam_flow = sgr.total_steam_flow;
     sec->total_heat_transfer = sgr.total_thermal_power;
     sec->total_feedwater_flow = sgr.total_steam_flow;
