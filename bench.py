@@ -31,7 +31,7 @@ def cpu_baseline(seconds_budget=15.0):
     """The CPU oracle (plain-C restatement, 'port') timed on this box's host cores on a bounded
     sample of the same workload.  Reported beside the GPU number; it is a baseline, not a target."""
     from oracle import npo
-    n = 2048
+    n = 32768
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     P = npo.Params(); P.hs_noise_enabled = 1
@@ -45,7 +45,7 @@ def cpu_baseline(seconds_budget=15.0):
         ora.step(setpoint=sp, noise_z=rng.standard_normal(n))
         steps += 1
         dt = time.perf_counter() - t0
-        if dt > seconds_budget or steps >= 400:
+        if dt > seconds_budget or steps >= 2000:
             break
     return {"value": n * steps / dt, "unit": "plant-env-steps/s", "cores": cores, "kind": "port",
             "sample": "%d plants x %d steps of the same C3 workload through oracle/libnpo.so (OpenMP over plants, %.1f s)" % (n, steps, dt)}

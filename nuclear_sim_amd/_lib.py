@@ -12,7 +12,7 @@ import os
 from .schema import PARAMS, SCHEMA
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnpb.so")
+LIB_PATH = os.environ.get("NPB_LIB", os.path.join(_HERE, "libnpb.so"))
 
 NPB_KIND_F64, NPB_KIND_I32 = 0, 1
 HEAT_CONSTANT, HEAT_REACTOR = 0, 1
@@ -43,6 +43,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NpbError("%s not found: build the HIP extension first (make -C nuclear_sim_amd/csrc); "
                        "there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm bundles its own HIP runtime; import it first so that libnpb.so binds to the one
+    # runtime already in the process (two HIP runtimes in one process do not see the device).
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     L.npb_version.restype = ci

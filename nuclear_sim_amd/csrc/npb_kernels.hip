@@ -29,6 +29,10 @@
 #include "npb_kernels.h"
 
 #define NPB_WAVE 64
+/* diagnostic builds only (-DNPB_ABLATE=mask): skip phases to attribute kernel time. 1 FW, 2 SG, 4 turbine, 8 condenser */
+#ifndef NPB_ABLATE
+#define NPB_ABLATE 0
+#endif
 #define NPB_OBS_PAD 23 /* LDS row stride in doubles: 22 + 1 keeps the transpose at <= 2-way bank conflicts */
 
 /* ---- section <-> SoA column movers.  A section struct is NF64 doubles followed by NI32 int32s
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   int fw_available = 1;
   uint32_t trip_flags = 0;
 
-  if (P.mode == NPB_MODE_FULL) {
+  if (P.mode == NPB_MODE_FULL && !(NPB_ABLATE & 1)) {
     /* ================= phase 1: feedwater system (physics.py:662-863) ================= */
     double prev_levels[NPB_NUM_SG], prev_flows[NPB_NUM_SG], prev_quals[NPB_NUM_SG];
 #pragma unroll
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
 #pragma unroll
     for (int i = 0; i < NPB_NUM_SG; i++) total_primary_flow += c.flow[i];
 #pragma unroll 1
-    for (int i = 0; i < NPB_NUM_SG; i++) {
+    for (int i = 0; i < ((NPB_ABLATE & 2) ? 0 : NPB_NUM_SG); i++) {
       double demand = (total_primary_flow > 0) ? actual_total_steam_flow * (c.flow[i] / total_primary_flow)
                                                : actual_total_steam_flow / NPB_NUM_SG;
       /* full mode: equal split of the actual feedwater flow (:500-506 key mismatch); config-2 mode:
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     {
       npb_turb_t t;
       NPD_LOAD(TURB, npb_turb_t, t, 0);
-      npd_turbine_update(&t, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
+      if (!(NPB_ABLATE & 4)) npd_turbine_update(&t, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
                          load_demand, 0.007, dt / 60.0, &tr);
       NPD_STORE(TURB, npb_turb_t, t, 0);
     }
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       npb_cond_t cd; npb_chem_t ch;
       NPD_LOAD(COND, npb_cond_t, cd, 0);
       NPD_LOAD(CHEM, npb_chem_t, ch, 1);
-      npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
+      if (!(NPB_ABLATE & 8)) npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
                            cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr);
       NPD_STORE(COND, npb_cond_t, cd, 0);
       NPD_STORE(CHEM, npb_chem_t, ch, 1);
