@@ -174,9 +174,6 @@
  * fouling_factor, blade_condition_factor and actual_efficiency are pure functions of them
  * (stage_system.py:294-339) and are re-derived when the stage is loaded. */
 #define NPB_TURB_FIELDS(F, A, I) \
-  A(stage_efficiency_degradation, 14, "=list(root.secondary_physics.turbine.stage_system.stages.values())[{k}].efficiency_degradation") \
-  A(stage_deposit_thickness, 14,      "=list(root.secondary_physics.turbine.stage_system.stages.values())[{k}].deposit_thickness") \
-  A(stage_blade_wear_factor, 14,      "=list(root.secondary_physics.turbine.stage_system.stages.values())[{k}].blade_wear_factor") \
   F(rotor_speed,          "secondary_physics.turbine.rotor_dynamics.rotor_speed") \
   F(rotor_temperature,    "secondary_physics.turbine.rotor_dynamics.rotor_temperature") \
   F(thermal_bow,          "secondary_physics.turbine.rotor_dynamics.thermal_bow") \
@@ -184,9 +181,6 @@
   A(bearing_load, 4,        "=list(root.secondary_physics.turbine.rotor_dynamics.bearings.values())[{k}].current_load") \
   A(bearing_metal_temp, 4,  "=list(root.secondary_physics.turbine.rotor_dynamics.bearings.values())[{k}].metal_temperature") \
   A(bearing_wear_factor, 4, "=list(root.secondary_physics.turbine.rotor_dynamics.bearings.values())[{k}].wear_factor") \
-  A(rotor_temperatures, 8,  "secondary_physics.turbine.thermal_tracker.rotor_temperatures[{k}]") \
-  A(casing_temperatures, 6, "secondary_physics.turbine.thermal_tracker.casing_temperatures[{k}]") \
-  A(blade_temperatures, 14, "secondary_physics.turbine.thermal_tracker.blade_temperatures[{k}]") \
   F(timer_overspeed,      "secondary_physics.turbine.protection_system.trip_timers['overspeed']") \
   F(timer_vibration,      "secondary_physics.turbine.protection_system.trip_timers['vibration']") \
   F(timer_bearing_temp,   "secondary_physics.turbine.protection_system.trip_timers['bearing_temp']") \
@@ -205,6 +199,16 @@
   A(lub_wear, 5,          "=list(root.secondary_physics.turbine.bearing_lubrication_system.component_wear.values())[{k}]") \
   I(trip_active,          "secondary_physics.turbine.protection_system.trip_active") \
   I(trip_latched_mask,    "")
+
+/* ---- turbine, per-stage and metal-temperature arrays: visited one stage at a time, so the kernel
+ * streams them straight from / to their SoA columns instead of holding them in registers */
+#define NPB_TSTG_FIELDS(F, A, I) \
+  A(stage_efficiency_degradation, 14, "=list(root.secondary_physics.turbine.stage_system.stages.values())[{k}].efficiency_degradation") \
+  A(stage_deposit_thickness, 14,      "=list(root.secondary_physics.turbine.stage_system.stages.values())[{k}].deposit_thickness") \
+  A(stage_blade_wear_factor, 14,      "=list(root.secondary_physics.turbine.stage_system.stages.values())[{k}].blade_wear_factor") \
+  A(rotor_temperatures, 8,  "secondary_physics.turbine.thermal_tracker.rotor_temperatures[{k}]") \
+  A(casing_temperatures, 6, "secondary_physics.turbine.thermal_tracker.casing_temperatures[{k}]") \
+  A(blade_temperatures, 14, "secondary_physics.turbine.thermal_tracker.blade_temperatures[{k}]")
 
 /* ---- WaterChemistry instances (x2): [0] the secondary-level one shared with the feedwater system
  * (secondary/__init__.py:316-321), [1] the condenser-owned one (condenser/physics.py:528-532).
@@ -281,6 +285,7 @@
   S(pump, PUMP, npb_pump_t, NPB_NUM_PUMPS) \
   S(fw,   FW,   npb_fw_t,   1) \
   S(turb, TURB, npb_turb_t, 1) \
+  S(tstg, TSTG, npb_tstg_t, 1) \
   S(chem, CHEM, npb_chem_t, 2) \
   S(cond, COND, npb_cond_t, 1) \
   S(sec,  SEC,  npb_sec_t,  1)

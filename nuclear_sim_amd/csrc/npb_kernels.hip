@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     {
       npb_turb_t t;
       NPD_LOAD(TURB, npb_turb_t, t, 0);
-      if (!(NPB_ABLATE & 4)) npd_turbine_update(&t, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
+      if (!(NPB_ABLATE & 4)) npd_turbine_update(&t, f64, N, p, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
                          load_demand, 0.007, dt / 60.0, &tr);
       NPD_STORE(TURB, npb_turb_t, t, 0);
     }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size
 #pragma unroll 1
   for (int i = 0; i < NPB_NUM_PUMPS; i++) { npb_pump_t pm; npd_pump_init(&pm, i); NPD_STORE(PUMP, npb_pump_t, pm, i); }
   { npb_fw_t fw; npd_fw_init(&fw); NPD_STORE(FW, npb_fw_t, fw, 0); }
-  { npb_turb_t t; npd_turb_init(&t); NPD_STORE(TURB, npb_turb_t, t, 0); }
+  { npb_turb_t t; npb_tstg_t g; npd_turb_init(&t, &g); NPD_STORE(TURB, npb_turb_t, t, 0); NPD_STORE(TSTG, npb_tstg_t, g, 0); }
 #pragma unroll 1
   for (int i = 0; i < 2; i++) { npb_chem_t ch; npd_chem_init(&ch, i); NPD_STORE(CHEM, npb_chem_t, ch, i); }
   { npb_cond_t cd; npd_cond_init(&cd); NPD_STORE(COND, npb_cond_t, cd, 0); }

@@ -24,7 +24,7 @@ NPD_FN double npd_cond_hf(double p) { return 4.18 * npd_cond_tsat(p); }      /* 
 NPD_FN double npd_cond_hg(double p) {                                         /* :1845-1850 */
   double temp = npd_cond_tsat(p);
   double h_f = npd_cond_hf(p);
-  double h_fg = 2257.0 * pow(1.0 - temp / 374.0, 0.38);
+  double h_fg = 2257.0 * npd_powc(1.0 - temp / 374.0, 0.38);
   return h_f + h_fg;
 }
 
@@ -68,7 +68,7 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
   cd->plugged_tube_count += tubes_failed;
   cd->active_tube_count = npd_pymax(1000.0, initial_tube_count - cd->plugged_tube_count);
   double area_factor = cd->active_tube_count / initial_tube_count;
-  double pressure_drop_factor = pow(initial_tube_count / cd->active_tube_count, 1.8);
+  double pressure_drop_factor = npd_powc(initial_tube_count / cd->active_tube_count, 1.8);
 
   /* ---- AdvancedFoulingModel.update_fouling :324-384 */
   double water_temp = (cooling_water_temp_in + cd->cooling_water_outlet_temp) / 2.0;
@@ -153,7 +153,7 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
       else {
         double pressure_capacity_factor = sqrt(motive_p / 1.0);
         double temp_ratio = (motive_steam_temperature + 273.15) / (180.0 + 273.15);
-        double temp_capacity_factor = pow(temp_ratio, 0.25);
+        double temp_capacity_factor = npd_powc(temp_ratio, 0.25);
         double suction_pressure_ratio = suction / 0.007;
         double suction_capacity_factor = 1.0 / (1.0 + 0.5 * (suction_pressure_ratio - 1.0));
         double available_capacity = (25.0 * pressure_capacity_factor * temp_capacity_factor * suction_capacity_factor * overall);
@@ -204,9 +204,9 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
   double air_concentration = (cd->air_partial_pressure / npd_pymax(0.001, cd->condenser_pressure));
   double air_degradation_factor = 1.0 - 0.5 * air_concentration;
   double h_steam = 12000.0 * air_degradation_factor;
-  double flow_factor = pow(cooling_water_flow / 45000.0, 0.8);
+  double flow_factor = npd_powc(cooling_water_flow / 45000.0, 0.8);
   double h_water_base = 5000.0 * flow_factor;
-  double h_water = h_water_base * pow(pressure_drop_factor, 0.2);
+  double h_water = h_water_base * npd_powc(pressure_drop_factor, 0.2);
   double r_steam = 1.0 / h_steam;
   double r_wall = 0.00159 / 385.0;
   double r_water = 1.0 / h_water;

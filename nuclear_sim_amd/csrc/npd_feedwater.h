@@ -195,35 +195,35 @@ NPD_FN void npd_pump_update(npb_pump_t *p, const npd_pump_sysconds_t *sc, double
       case 0: { /* impeller: no entry in component_conditions -> all defaults (load 1, speed 1, 55 C, no cavitation) */
         double temp_factor = npd_pymax(1.0, (55.0 - 80.0) / 40.0);
         double bearing_coupling = 1.0 + (max_bearing_wear / 100.0) * 0.3;
-        wear_rate = (c->base * pow(1.0, c->load_exp) * pow(1.0, c->speed_exp) * (1.0 + 0.0 * 3.0) * temp_factor * bearing_coupling);
+        wear_rate = (c->base * npd_powc(1.0, c->load_exp) * npd_powc(1.0, c->speed_exp) * (1.0 + 0.0 * 3.0) * temp_factor * bearing_coupling);
       } break;
       case 1: {
         double temperature = 60.0 + electrical_load_factor * 25.0;
         double temp_factor = npd_pymax(1.0, (temperature - 60.0) / 25.0);
         double coupling = 1.0 + (impeller_wear / 100.0) * 0.2;
-        wear_rate = (c->base * pow(electrical_load_factor, c->load_exp) * pow(speed_factor, c->speed_exp) * temp_factor * coupling);
+        wear_rate = (c->base * npd_powc(electrical_load_factor, c->load_exp) * npd_powc(speed_factor, c->speed_exp) * temp_factor * coupling);
       } break;
       case 2: {
         double temperature = 50.0 + load_factor * 30.0;
         double cavitation_factor = 1.0 + cav * 2.0;
         double temp_factor = npd_pymax(1.0, (temperature - 50.0) / 30.0);
         double coupling = 1.0 + (impeller_wear / 100.0) * 0.4;
-        wear_rate = (c->base * pow(load_factor, c->load_exp) * pow(speed_factor, c->speed_exp) * cavitation_factor * temp_factor * coupling);
+        wear_rate = (c->base * npd_powc(load_factor, c->load_exp) * npd_powc(speed_factor, c->speed_exp) * cavitation_factor * temp_factor * coupling);
       } break;
       case 3: {
         double axial_load_factor = 1.0 * load_factor;
         double coupling = 1.0 + (impeller_wear / 100.0) * 0.25;
-        wear_rate = (c->base * pow(axial_load_factor, c->load_exp) * pow(speed_factor, c->speed_exp) * coupling);
+        wear_rate = (c->base * npd_powc(axial_load_factor, c->load_exp) * npd_powc(speed_factor, c->speed_exp) * coupling);
       } break;
       case 4: {
         double cavitation_seal_factor = 1.0 + cav * 5.0;
         double impeller_coupling = 1.0 + (impeller_wear / 100.0) * 0.15;
         double bearing_coupling = 1.0 + (max_bearing_wear / 100.0) * 0.2;
-        wear_rate = (c->base * pow(pressure_factor, c->load_exp) * 1.0 * cavitation_seal_factor * impeller_coupling * bearing_coupling);
+        wear_rate = (c->base * npd_powc(pressure_factor, c->load_exp) * 1.0 * cavitation_seal_factor * impeller_coupling * bearing_coupling);
       } break;
       default: {
         double bearing_coupling = 1.0 + (max_bearing_wear / 100.0) * 0.3;
-        wear_rate = (c->base * 1.0 * 1.0 * pow(load_factor, c->load_exp) * bearing_coupling);
+        wear_rate = (c->base * 1.0 * 1.0 * npd_powc(load_factor, c->load_exp) * bearing_coupling);
       } break;
     }
     wear_rate *= 1.0; /* chemistry_wear_factor default */
@@ -432,7 +432,7 @@ NPD_FN void npd_fw_pump_step(npb_pump_t *p, npb_fw_t *fw, npd_fw_acc_t *acc, int
       double npsh_deficit = cavitation_threshold - p->npsh_available;
       double severity = npd_pymin(1.0, npsh_deficit / cavitation_threshold);
       double flow_factor = npd_sq(p->flow_rate / 555.0);
-      double speed_factor = pow(p->speed_percent / 100.0, 1.5);
+      double speed_factor = npd_powc(p->speed_percent / 100.0, 1.5);
       current_intensity = severity * flow_factor * speed_factor;
       fw->cav_time_in_cavitation += dt;
       if (current_intensity > 0.1) { fw->cav_events_count += 1; if (fw->cav_events_count > 100) fw->cav_events_count = 100; }

@@ -104,16 +104,16 @@ NPD_FN void npd_fw_init(npb_fw_t *fw) {
  * TurbineInitialConditions defaults (turbine/config.py); TurbineStage.__init__ stage_system.py:49-96;
  * BearingModel.__init__ rotor_dynamics.py:55-82; apply_unified_initial_conditions
  * turbine_bearing_lubrication.py:187-228 */
-NPD_FN void npd_turb_init(npb_turb_t *t) {
-  memset(t, 0, sizeof(*t));
-  for (int k = 0; k < 14; k++) { t->stage_efficiency_degradation[k] = 0.0; t->stage_deposit_thickness[k] = 0.0; t->stage_blade_wear_factor[k] = 1.0; }
+NPD_FN void npd_turb_init(npb_turb_t *t, npb_tstg_t *g) {
+  memset(t, 0, sizeof(*t)); memset(g, 0, sizeof(*g));
+  for (int k = 0; k < 14; k++) { g->stage_efficiency_degradation[k] = 0.0; g->stage_deposit_thickness[k] = 0.0; g->stage_blade_wear_factor[k] = 1.0; }
   t->rotor_speed = 3600.0; t->rotor_temperature = 450.0; t->thermal_bow = 0.0; t->thermal_expansion = 0.0;
   for (int i = 0; i < 4; i++) { t->bearing_load[i] = 0.0; t->bearing_metal_temp[i] = 80.0; t->bearing_wear_factor[i] = 1.0; }
-  for (int i = 0; i < 8; i++) t->rotor_temperatures[i] = 450.0;
+  for (int i = 0; i < 8; i++) g->rotor_temperatures[i] = 450.0;
   const double casing[6] = {380.0, 360.0, 340.0, 320.0, 300.0, 280.0};
   const double blade[14] = {500.0, 480.0, 460.0, 440.0, 420.0, 400.0, 380.0, 360.0, 340.0, 320.0, 300.0, 280.0, 260.0, 240.0};
-  for (int i = 0; i < 6; i++) t->casing_temperatures[i] = casing[i];
-  for (int i = 0; i < 14; i++) t->blade_temperatures[i] = blade[i];
+  for (int i = 0; i < 6; i++) g->casing_temperatures[i] = casing[i];
+  for (int i = 0; i < 14; i++) g->blade_temperatures[i] = blade[i];
   t->load_demand = 1.0; t->total_power_output = 1000.0; t->vibration_displacement = 0.0;
   t->lub_oil_temperature = 45.0; t->lub_oil_contamination = 5.0; t->lub_oil_moisture = 0.02; t->lub_oil_acidity = 0.15;
   t->lub_oil_viscosity_change = 0.0; t->lub_antioxidant_level = 100.0; t->lub_anti_wear_level = 100.0;

@@ -63,7 +63,7 @@ NPD_FN void npd_update_oil_quality(const npd_oil_t *o, const npd_oil_limits_t *l
   double vf = npd_pymax(0.1, 1.0 - fabs(*o->viscosity_change) / lim->viscosity_change_limit);
   double antioxidant_factor = *o->antioxidant / 100.0;
   double aw_factor = *o->anti_wear / 100.0;
-  double critical = pow(cf * antioxidant_factor * aw_factor, 1.0 / 3);
+  double critical = npd_powc(cf * antioxidant_factor * aw_factor, 1.0 / 3);
   double secondary = (0.0 + af + mf + vf) / 3;
   double eff = critical * 0.7 + secondary * 0.3;
   *o->effectiveness = npd_pymax(0.3, npd_pymin(1.0, eff));

@@ -141,7 +141,7 @@ NPD_FN double npd_core_ua(double coolant_flow_rate) {
   double reynolds = density * velocity * fuel_rod_diameter / viscosity;
   reynolds = npd_pymax(reynolds, 1000.0);
   double prandtl = viscosity * specific_heat / thermal_conductivity;
-  double nusselt = 0.023 * pow(reynolds, 0.8) * pow(prandtl, 0.4);
+  double nusselt = 0.023 * npd_powc(reynolds, 0.8) * npd_powc(prandtl, 0.4);
   double h = nusselt * thermal_conductivity / fuel_rod_diameter;
   double overall_ua = h * heat_transfer_area;
   overall_ua = overall_ua * 0.1;

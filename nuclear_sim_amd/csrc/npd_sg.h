@@ -13,7 +13,7 @@ NPD_FN double npd_sg_tsat(double pressure_mpa) {
   if (pressure_mpa <= 0.001) return 10.0;
   double pressure_bar = pressure_mpa * 10.0;
   double ln_p = log(pressure_bar);
-  double temp_c = 42.6776 + 34.5194 * ln_p + 2.8896 * npd_sq(ln_p) + 0.1153 * pow(ln_p, 3.0);
+  double temp_c = 42.6776 + 34.5194 * ln_p + 2.8896 * npd_sq(ln_p) + 0.1153 * (ln_p * ln_p * ln_p);
   return npd_clip(temp_c, 10.0, 374.0);
 }
 /* :890-906 */
@@ -21,7 +21,7 @@ NPD_FN double npd_sg_hf(double p) { return 4.18 * npd_sg_tsat(p); }
 NPD_FN double npd_sg_hg(double p) {
   double temp = npd_sg_tsat(p);
   double h_f = npd_sg_hf(p);
-  double h_fg = 2257.0 * pow(1.0 - temp / 374.0, 0.38);
+  double h_fg = 2257.0 * npd_powc(1.0 - temp / 374.0, 0.38);
   return h_f + h_fg;
 }
 /* :908-941 */
@@ -49,7 +49,7 @@ NPD_FN double npd_tsp_average_thickness(const npb_sg_t *g) {
 
 /* TSPFoulingModel.calculate_heat_transfer_degradation  tsp_fouling_model.py:342-367 */
 NPD_FN double npd_tsp_ht_degradation(double ff) {
-  double mixing = pow(ff, 1.5);
+  double mixing = npd_powc(ff, 1.5);
   double maldist = ff * 0.3;
   double total = (mixing + maldist) * 0.6;
   return npd_pymin(total, 0.9);
@@ -158,7 +158,7 @@ NPD_FN void npd_scale_update(npb_sg_t *g, double temperature, double flow_veloci
   double boric_acid_factor = 1.0 / (1.0 + boric_acid / 1000.0 * 0.5);
   double lithium_factor = npd_pymax(0.5, 1.0 + (lithium - 2.0) * 0.1);
   double ph_factor = 1.0 + 0.5 * fabs(ph - 7.2);
-  double velocity_factor = npd_clip(pow(flow_velocity / 5.0, -0.6), 0.5, 2.0);
+  double velocity_factor = npd_clip(npd_powc(flow_velocity / 5.0, -0.6), 0.5, 2.0);
   double oxygen_factor = 1.0 + dissolved_oxygen * 10.0;
   double saturation_factor = exp(-g->scale_thickness / 2.0);
   double formation_rate = 0.001 * temp_factor * boric_acid_factor * lithium_factor * ph_factor *
@@ -188,9 +188,9 @@ NPD_FN void npd_sg_update(npb_sg_t *g, const npb_params_t *P, double primary_tem
   double lmtd;
   if (fabs(delta_t1 - delta_t2) < 1.0) lmtd = (delta_t1 + delta_t2) / 2.0;
   else lmtd = (delta_t1 - delta_t2) / log(delta_t1 / delta_t2);
-  double flow_factor = pow(primary_flow / P->sg_primary_design_flow, 0.8);
+  double flow_factor = npd_powc(primary_flow / P->sg_primary_design_flow, 0.8);
   double h_primary = P->sg_primary_htc * flow_factor;
-  double pressure_factor = pow(g->secondary_pressure / P->sg_design_pressure_secondary, 0.15);
+  double pressure_factor = npd_powc(g->secondary_pressure / P->sg_design_pressure_secondary, 0.15);
   double h_secondary = P->sg_secondary_htc * pressure_factor;
   double r_primary = 1.0 / h_primary;
   double r_wall = P->sg_tube_wall_thickness / P->sg_tube_conductivity;

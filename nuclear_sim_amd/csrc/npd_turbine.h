@@ -24,7 +24,13 @@ NPD_FN double npd_tsat_antoine(double pressure_mpa) {
 NPD_FN double npd_hg_antoine(double pressure_mpa) {
   double temp = npd_tsat_antoine(pressure_mpa);
   double h_f = 4.18 * temp;
-  double h_fg = 2257.0 * pow(1.0 - temp / 374.0, 0.38);
+  double h_fg = 2257.0 * npd_powc(1.0 - temp / 374.0, 0.38);
+  return h_f + h_fg;
+}
+/* same, from an already known saturation temperature */
+NPD_FN double npd_hg_from_tsat(double temp) {
+  double h_f = 4.18 * temp;
+  double h_fg = 2257.0 * npd_powc(1.0 - temp / 374.0, 0.38);
   return h_f + h_fg;
 }
 /* TurbineStage._steam_enthalpy  stage_system.py:418-443 */
@@ -104,7 +110,7 @@ NPD_FN void npd_stage_expansion(int k, double actual_efficiency, double blade_co
   }
   double outlet_flow = inlet_flow - extraction_flow;
   double pr = self_outlet_pressure / inlet_pressure;
-  double outlet_temp_isentropic = (inlet_temperature + 273.15) * pow(pr, 0.25) - 273.15;
+  double outlet_temp_isentropic = (inlet_temperature + 273.15) * sqrt(sqrt(pr)) - 273.15;
   double outlet_enthalpy_isentropic = npd_stage_steam_enthalpy(outlet_temp_isentropic, self_outlet_pressure);
   double quality_efficiency_factor = 1.0; /* steam_quality is the hard-coded 0.99 (:206) */
   double total_efficiency = (actual_efficiency * blade_condition_factor * fouling_factor * blade_wear_factor * quality_efficiency_factor);
@@ -145,7 +151,9 @@ NPD_FN double npd_stage_dynamic_pressure_ratio(int k, double current_pressure, d
   if (is_lp) {
     int remaining_stages = 14 - k - 1;
     if (remaining_stages > 0) {
-      double min_outlet_pressure = 0.007 / pow(0.85, (double)remaining_stages);
+      /* 0.85 ** remaining_stages (remaining_stages = 1..5 for LP-1..LP-5), correctly rounded */
+      const double pow085[6] = {1.0, 0.85, 0.7224999999999999, 0.6141249999999999, 0.5220062499999999, 0.44370531249999995};
+      double min_outlet_pressure = 0.007 / pow085[remaining_stages];
       double max_allowable_ratio = min_outlet_pressure / current_pressure;
       min_ratio = npd_pymax(min_ratio, max_allowable_ratio);
     }
@@ -157,51 +165,197 @@ NPD_FN double npd_stage_dynamic_pressure_ratio(int k, double current_pressure, d
 
 typedef struct npd_stagesys_out_t {
   double total_power, total_extraction, lp6_outlet_enthalpy;
-  double stage_outlet_temperature[14];
+  double max_temp_rate, max_thermal_stress; /* MetalTemperatureTracker reductions */
 } npd_stagesys_out_t;
 
-/* TurbineStageSystem.update_state  stage_system.py:928-1016 (+ calculate_stage_by_stage_expansion :760-926,
- * TurbineStage.update_degradation :294-339).  The control-logic pass (:525-651) only fills a command dict. */
-NPD_FN void npd_stage_system_update(npb_turb_t *t, double inlet_pressure, double inlet_temperature, double inlet_flow,
-                                    double load_demand, double pressure_stability_factor, double dt, npd_stagesys_out_t *out) {
-  /* extraction_demands dict  enhanced_physics.py:729-735 */
-  double extraction_demand[14] = {0};
-  extraction_demand[2] = 25.0 * load_demand; extraction_demand[3] = 30.0 * load_demand; extraction_demand[4] = 20.0 * load_demand;
-  extraction_demand[8] = 15.0 * load_demand; extraction_demand[9] = 10.0 * load_demand;
-  double current_pressure = inlet_pressure, current_temperature = inlet_temperature, current_flow = inlet_flow;
+/* per-stage column access: the stage / tracker arrays are streamed from their SoA columns */
+#define NPD_TSTG(member, k) f64[(size_t)(NPB_TSTG_F64_BASE + NPB_F64_SLOT(npb_tstg_t, member) + (k)) * N + p]
+
+/* one stage's share of TurbineStage.update_degradation (stage_system.py:294-339) and of
+ * MetalTemperatureTracker.update_temperatures (enhanced_physics.py:73-166, time constant 1 h, ambient 25 C);
+ * both only touch stage k's own state, so running them right after stage k's expansion is the
+ * reference's result */
+NPD_FN void npd_stage_post(double *__restrict__ f64, size_t N, size_t p, int k, double loading_factor,
+                           double outlet_temperature, double dt, npd_stagesys_out_t *out) {
+  NPD_TSTG(stage_efficiency_degradation, k) += 1e-05 * dt;
+  NPD_TSTG(stage_deposit_thickness, k) += 5e-05 * dt;
+  double blade_wear = (1e-06 * dt) * npd_sq(loading_factor);
+  NPD_TSTG(stage_blade_wear_factor, k) = npd_pymax(0.7, NPD_TSTG(stage_blade_wear_factor, k) - blade_wear);
+  const double time_constant = 3600.0 / 3600.0, ambient = 25.0;
+  if (k < 8) {
+    double rt = NPD_TSTG(rotor_temperatures, k);
+    double tc = ((outlet_temperature - 50.0) - rt) / time_constant * dt;
+    double max_rate = 5.0 * dt;
+    tc = npd_clip(tc, -max_rate, max_rate);
+    rt += tc;
+    NPD_TSTG(rotor_temperatures, k) = rt;
+    double rate = fabs(tc / dt * 60.0);
+    out->max_temp_rate = (k == 0) ? rate : npd_pymax(out->max_temp_rate, rate);
+    double stress = (1.2e-05 * (rt - ambient)) * 200000000000.0 * 0.1;
+    out->max_thermal_stress = (k == 0) ? stress : npd_pymax(out->max_thermal_stress, stress);
+  }
+  if (k < 6) {
+    double ct = NPD_TSTG(casing_temperatures, k);
+    double tc = ((outlet_temperature - 80.0) - ct) / time_constant * dt;
+    tc = npd_clip(tc, -3.0 * dt, 3.0 * dt);
+    NPD_TSTG(casing_temperatures, k) = ct + tc;
+  }
+  {
+    double bt = NPD_TSTG(blade_temperatures, k);
+    double tc = ((outlet_temperature - 20.0) - bt) / (time_constant * 0.5) * dt;
+    tc = npd_clip(tc, -10.0 * dt, 10.0 * dt);
+    NPD_TSTG(blade_temperatures, k) = bt + tc;
+  }
+}
+
+/* requested outlet pressure of stage k  calculate_stage_by_stage_expansion  stage_system.py:870-895 */
+NPD_FN double npd_stage_requested_outlet(int k, double current_pressure, double inlet_flow) {
   const double final_pressure = 0.007;
-  double total_power = 0.0, total_extraction = 0.0;
-  double loading[14];
-  for (int k = 0; k < 14; k++) {
-    double pressure_ratio = npd_stage_dynamic_pressure_ratio(k, current_pressure, inlet_flow);
-    double outlet_pressure = current_pressure * pressure_ratio;
+  double pressure_ratio = npd_stage_dynamic_pressure_ratio(k, current_pressure, inlet_flow);
+  double outlet_pressure = current_pressure * pressure_ratio;
+  outlet_pressure = npd_pymax(outlet_pressure, final_pressure);
+  int remaining_stages = 14 - k - 1;
+  if (remaining_stages == 0) outlet_pressure = final_pressure;
+  else if (remaining_stages == 1) outlet_pressure = npd_pymax(outlet_pressure, final_pressure / 0.5);
+  if (outlet_pressure >= current_pressure) {
+    outlet_pressure = current_pressure * 0.95;
     outlet_pressure = npd_pymax(outlet_pressure, final_pressure);
-    int remaining_stages = 14 - k - 1;
-    if (remaining_stages == 0) outlet_pressure = final_pressure;
-    else if (remaining_stages == 1) outlet_pressure = npd_pymax(outlet_pressure, final_pressure / 0.5);
-    if (outlet_pressure >= current_pressure) {
-      outlet_pressure = current_pressure * 0.95;
-      outlet_pressure = npd_pymax(outlet_pressure, final_pressure);
-    }
-    /* derived per-stage factors (see npb_fields.h) */
-    double fouling_factor = 1.0 / (1.0 + t->stage_deposit_thickness[k] / 0.5);
-    double blade_wear_factor = t->stage_blade_wear_factor[k];
+  }
+  return outlet_pressure;
+}
+
+/* TurbineStageSystem.update_state  stage_system.py:928-1016, reference order, one stage at a time.
+ * Exact for every input; used when a lane of the wave leaves the fast path's assumptions. */
+NPD_FN void npd_stage_system_update_seq(double *__restrict__ f64, size_t N, size_t p, double inlet_pressure,
+                                        double inlet_temperature, double inlet_flow, double load_demand,
+                                        double pressure_stability_factor, double dt, npd_stagesys_out_t *out) {
+  double current_pressure = inlet_pressure, current_temperature = inlet_temperature, current_flow = inlet_flow;
+  double total_power = 0.0, total_extraction = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < 14; k++) {
+    double extraction_demand = (k == 2) ? 25.0 * load_demand : (k == 3) ? 30.0 * load_demand : (k == 4) ? 20.0 * load_demand
+                             : (k == 8) ? 15.0 * load_demand : (k == 9) ? 10.0 * load_demand : 0.0;
+    double outlet_pressure = npd_stage_requested_outlet(k, current_pressure, inlet_flow);
+    double fouling_factor = 1.0 / (1.0 + NPD_TSTG(stage_deposit_thickness, k) / 0.5);
+    double blade_wear_factor = NPD_TSTG(stage_blade_wear_factor, k);
     double blade_condition_factor = npd_pymin(fouling_factor, blade_wear_factor);
-    double actual_efficiency = npd_pymax(0.7, 0.88 - t->stage_efficiency_degradation[k]);
+    double actual_efficiency = npd_pymax(0.7, 0.88 - NPD_TSTG(stage_efficiency_degradation, k));
     npd_stage_out_t so;
     npd_stage_expansion(k, actual_efficiency, blade_condition_factor, fouling_factor, blade_wear_factor, current_pressure,
-                        current_temperature, current_flow, outlet_pressure, extraction_demand[k], &so);
+                        current_temperature, current_flow, outlet_pressure, extraction_demand, &so);
     total_power += so.power_output; total_extraction += so.extraction_flow;
-    out->stage_outlet_temperature[k] = so.outlet_temperature;
     if (k == 13) out->lp6_outlet_enthalpy = so.outlet_enthalpy;
-    loading[k] = so.loading_factor;
+    npd_stage_post(f64, N, p, k, so.loading_factor, so.outlet_temperature, dt, out);
     current_pressure = so.outlet_pressure; current_temperature = so.outlet_temperature; current_flow = so.outlet_flow;
   }
-  for (int k = 0; k < 14; k++) { /* update_degradation */
-    t->stage_efficiency_degradation[k] += 1e-05 * dt;
-    t->stage_deposit_thickness[k] += 5e-05 * dt;
-    double blade_wear = (1e-06 * dt) * npd_sq(loading[k]);
-    t->stage_blade_wear_factor[k] = npd_pymax(0.7, t->stage_blade_wear_factor[k] - blade_wear);
+  out->total_power = total_power * pressure_stability_factor;
+  out->total_extraction = total_extraction;
+}
+
+/* Same result, restructured for instruction-level parallelism (one wave per SIMD has nothing else to
+ * hide latency with): the pressure / flow chain does not depend on the temperature chain unless a stage
+ * takes the "invalid pressure ratio" branch (stage_system.py:146-155), so
+ *   pass A  walks the 14 stages' pressures and flows (no transcendentals),
+ *   pass B  evaluates saturation temperature / vapour enthalpy for all 15 + 5 distinct pressures and
+ *           the 14 isentropic temperature ratios as independent, interleavable streams,
+ *   pass C  walks the temperature / enthalpy chain with plain arithmetic and streams each stage's
+ *           degradation and metal-temperature state.
+ * Lanes that would take a rare branch make the whole wave use npd_stage_system_update_seq. */
+NPD_FN void npd_stage_system_update(double *__restrict__ f64, size_t N, size_t p, double inlet_pressure,
+                                    double inlet_temperature, double inlet_flow, double load_demand,
+                                    double pressure_stability_factor, double dt, npd_stagesys_out_t *out) {
+  double p_in[14], p_self[14], p_arg[14], flow_in[14], flow_out[14], ext_flow[14], p_ext[14];
+  bool rare = !(inlet_pressure >= 0.001 && inlet_pressure <= 22.0);
+  {
+    double cur_p = inlet_pressure, cur_flow = inlet_flow;
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+      double d_in, d_out, design_flow; int has_extraction, is_lp;
+      npd_stage_design(k, &d_in, &d_out, &design_flow, &has_extraction, &is_lp);
+      double design_pressure_ratio = d_out / d_in;
+      double extraction_demand = (k == 2) ? 25.0 * load_demand : (k == 3) ? 30.0 * load_demand : (k == 4) ? 20.0 * load_demand
+                               : (k == 8) ? 15.0 * load_demand : (k == 9) ? 10.0 * load_demand : 0.0;
+      double outlet_pressure = npd_stage_requested_outlet(k, cur_p, inlet_flow);
+      rare = rare || (outlet_pressure >= cur_p);
+      double min_allowed, max_allowed;
+      if (k == 13) { min_allowed = 0.002; max_allowed = 0.009; }
+      else { min_allowed = cur_p * (design_pressure_ratio * 0.7); max_allowed = cur_p * (design_pressure_ratio * 1.3); }
+      double self_out = (outlet_pressure < min_allowed) ? min_allowed : ((outlet_pressure > max_allowed) ? max_allowed : outlet_pressure);
+      double ef = 0.0, pe = cur_p;
+      if (has_extraction && extraction_demand > 0) {
+        ef = npd_clip(extraction_demand, 5.0, npd_pymin(50.0, cur_flow * 0.3));
+        pe = cur_p * 0.7 + outlet_pressure * (1 - 0.7);
+      }
+      p_in[k] = cur_p; p_arg[k] = outlet_pressure; p_self[k] = self_out; flow_in[k] = cur_flow; ext_flow[k] = ef; p_ext[k] = pe;
+      flow_out[k] = cur_flow - ef;
+      rare = rare || !(self_out >= 0.001 && self_out <= 22.0) || !(pe >= 0.001 && pe <= 22.0) || !(outlet_pressure >= 0.001);
+      cur_p = self_out; cur_flow = flow_out[k];
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(rare) != 0) { /* wave-uniform: any lane off the fast path */
+    npd_stage_system_update_seq(f64, N, p, inlet_pressure, inlet_temperature, inlet_flow, load_demand,
+                                pressure_stability_factor, dt, out);
+    return;
+  }
+  /* pass B: independent transcendental streams */
+  double sat_self[14], hg_self[14], tratio[14], sat_ext[14], hg_ext[14], sat_arg[14], hg_arg[14];
+  double sat_in0 = npd_tsat_antoine(inlet_pressure);
+  double hg_in0 = npd_hg_from_tsat(sat_in0);
+  bool mismatch = false;
+#pragma unroll
+  for (int k = 0; k < 14; k++) {
+    sat_self[k] = npd_tsat_antoine(p_self[k]);
+    hg_self[k] = npd_hg_from_tsat(sat_self[k]);
+    tratio[k] = sqrt(sqrt(p_self[k] / p_in[k]));
+    mismatch = mismatch || (p_arg[k] != p_self[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 14; k++) {
+    if (k == 2 || k == 3 || k == 4 || k == 8 || k == 9) { sat_ext[k] = npd_tsat_antoine(p_ext[k]); hg_ext[k] = npd_hg_from_tsat(sat_ext[k]); }
+    else { sat_ext[k] = 0.0; hg_ext[k] = 0.0; }
+  }
+  if (__builtin_amdgcn_ballot_w64(mismatch) != 0) { /* some lane's requested outlet pressure was clamped */
+#pragma unroll
+    for (int k = 0; k < 14; k++) { sat_arg[k] = npd_tsat_antoine(p_arg[k]); hg_arg[k] = npd_hg_from_tsat(sat_arg[k]); }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 14; k++) { sat_arg[k] = sat_self[k]; hg_arg[k] = hg_self[k]; }
+  }
+  /* pass C: temperature / enthalpy chain */
+  double T_in = inlet_temperature, sat_in = sat_in0, hg_in = hg_in0;
+  double total_power = 0.0, total_extraction = 0.0;
+#pragma unroll
+  for (int k = 0; k < 14; k++) {
+    double fouling_factor = 1.0 / (1.0 + NPD_TSTG(stage_deposit_thickness, k) / 0.5);
+    double blade_wear_factor = NPD_TSTG(stage_blade_wear_factor, k);
+    double blade_condition_factor = npd_pymin(fouling_factor, blade_wear_factor);
+    double actual_efficiency = npd_pymax(0.7, 0.88 - NPD_TSTG(stage_efficiency_degradation, k));
+    double cp_in = (p_in[k] > 10.0) ? 2.5 : ((p_in[k] > 1.0) ? 2.2 : 2.0);
+    double T_c = npd_pymax(0.0, npd_pymin(T_in, 800.0));
+    double inlet_enthalpy = (T_c <= sat_in) ? hg_in : hg_in + cp_in * (T_c - sat_in);
+    double T_isen = (T_in + 273.15) * tratio[k] - 273.15;
+    double T_isen_c = npd_pymax(0.0, npd_pymin(T_isen, 800.0));
+    double cp_out = (p_self[k] > 10.0) ? 2.5 : ((p_self[k] > 1.0) ? 2.2 : 2.0);
+    double h_isen = (T_isen_c <= sat_self[k]) ? hg_self[k] : hg_self[k] + cp_out * (T_isen_c - sat_self[k]);
+    double total_efficiency = (actual_efficiency * blade_condition_factor * fouling_factor * blade_wear_factor * 1.0);
+    double isentropic_enthalpy_drop = inlet_enthalpy - h_isen;
+    if (isentropic_enthalpy_drop <= 0) {
+      double min_enthalpy_drop = 50.0 * (1.0 - p_self[k] / p_in[k]);
+      isentropic_enthalpy_drop = npd_pymax(min_enthalpy_drop, 10.0);
+    }
+    double actual_enthalpy_drop = total_efficiency * isentropic_enthalpy_drop;
+    if (actual_enthalpy_drop <= 0) actual_enthalpy_drop = npd_pymax(1.0, isentropic_enthalpy_drop * 0.5);
+    double outlet_enthalpy = inlet_enthalpy - actual_enthalpy_drop;
+    double T_out = (outlet_enthalpy <= hg_arg[k]) ? sat_arg[k] : sat_arg[k] + (outlet_enthalpy - hg_arg[k]) / 2.1;
+    double main_power = flow_out[k] * actual_enthalpy_drop / 1000.0;
+    if (main_power < 0) main_power = 0.0;
+    double extraction_power = 0.0;
+    if (ext_flow[k] > 0) extraction_power = ext_flow[k] * (inlet_enthalpy - hg_ext[k]) / 1000.0;
+    double loading_factor = actual_enthalpy_drop / npd_pymax(1.0, 0.88 * isentropic_enthalpy_drop);
+    total_power += main_power + extraction_power; total_extraction += ext_flow[k];
+    if (k == 13) out->lp6_outlet_enthalpy = outlet_enthalpy;
+    npd_stage_post(f64, N, p, k, loading_factor, T_out, dt, out);
+    T_in = T_out; sat_in = sat_self[k]; hg_in = hg_self[k];
   }
   out->total_power = total_power * pressure_stability_factor;
   out->total_extraction = total_extraction;
@@ -233,7 +387,8 @@ typedef struct npd_turbine_result_t {
   int trip_active;
 } npd_turbine_result_t;
 
-NPD_FN void npd_turbine_update(npb_turb_t *t, double steam_pressure, double steam_temperature, double steam_flow,
+NPD_FN void npd_turbine_update(npb_turb_t *t, double *__restrict__ f64, size_t N, size_t p, double steam_pressure,
+                               double steam_temperature, double steam_flow,
                                const double *sg_pressures, int sg_system_availability, double load_demand,
                                double condenser_pressure, double dt, npd_turbine_result_t *res) {
   /* ================= lubrication wrapper (pre-step, previous step's bearing state) =============
@@ -279,18 +434,18 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, double steam_pressure, double stea
     if (i == 0) {
       double steam_temp_factor = npd_pymax(1.0, (b_temperature[0] - 70.0) / 20.0);
       double load_factor_adj = b_load_factor[0] * 1.2;
-      wear_rate = (NPD_TLUB_BASE[0] * pow(load_factor_adj, NPD_TLUB_LOAD_EXP[0]) * pow(b_speed_factor, NPD_TLUB_SPEED_EXP[0]) * steam_temp_factor);
+      wear_rate = (NPD_TLUB_BASE[0] * npd_powc(load_factor_adj, NPD_TLUB_LOAD_EXP[0]) * npd_powc(b_speed_factor, NPD_TLUB_SPEED_EXP[0]) * steam_temp_factor);
     } else if (i == 1) {
       double moisture_factor = npd_pymax(1.0, (1.0 - 0.99) * 10.0);
       double temp_factor = npd_pymax(1.0, (b_temperature[1] - 60.0) / 25.0);
-      wear_rate = (NPD_TLUB_BASE[1] * pow(b_load_factor[1], NPD_TLUB_LOAD_EXP[1]) * pow(b_speed_factor, NPD_TLUB_SPEED_EXP[1]) * moisture_factor * temp_factor);
+      wear_rate = (NPD_TLUB_BASE[1] * npd_powc(b_load_factor[1], NPD_TLUB_LOAD_EXP[1]) * npd_powc(b_speed_factor, NPD_TLUB_SPEED_EXP[1]) * moisture_factor * temp_factor);
     } else if (i == 2) {
       double axial_load_factor = b_load_factor[2] * 1.0;
       double temp_factor = npd_pymax(1.0, (b_temperature[2] - 50.0) / 30.0);
-      wear_rate = (NPD_TLUB_BASE[2] * pow(axial_load_factor, NPD_TLUB_LOAD_EXP[2]) * pow(b_speed_factor, NPD_TLUB_SPEED_EXP[2]) * temp_factor);
+      wear_rate = (NPD_TLUB_BASE[2] * npd_powc(axial_load_factor, NPD_TLUB_LOAD_EXP[2]) * npd_powc(b_speed_factor, NPD_TLUB_SPEED_EXP[2]) * temp_factor);
     } else if (i == 3) {
       double contamination_factor = 1.0 + t->lub_oil_contamination / 10.0;
-      wear_rate = (NPD_TLUB_BASE[3] * pow(1.0, NPD_TLUB_LOAD_EXP[3]) * contamination_factor);
+      wear_rate = (NPD_TLUB_BASE[3] * 1.0 * contamination_factor);
     } else {
       wear_rate = (NPD_TLUB_BASE[4] * 1.0 * 1.0); /* oil_coolers: no bearing maps to it -> defaults */
     }
@@ -302,7 +457,7 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, double steam_pressure, double stea
   t->load_demand = load_demand;
   double pressure_stability_factor = npd_pressure_stability_factor(sg_pressures);
   npd_stagesys_out_t ss;
-  npd_stage_system_update(t, steam_pressure, steam_temperature, steam_flow, load_demand, pressure_stability_factor, dt, &ss);
+  npd_stage_system_update(f64, N, p, steam_pressure, steam_temperature, steam_flow, load_demand, pressure_stability_factor, dt, &ss);
   double stage_power_mw = ss.total_power;
   double applied_torque = stage_power_mw * 1e6 / (2 * NPD_PI * 3600 / 60);
 
@@ -371,7 +526,7 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, double steam_pressure, double stea
   double frequency_ratio = rotation_frequency / natural_frequency;
   double critical_damping = 2 * sqrt(avg_stiffness * rotor_mass);
   double damping_ratio = avg_damping / critical_damping;
-  double denominator = sqrt(npd_sq(1 - pow(frequency_ratio, 2.0)) + npd_sq(2 * damping_ratio * frequency_ratio));
+  double denominator = sqrt(npd_sq(1 - npd_sq(frequency_ratio)) + npd_sq(2 * damping_ratio * frequency_ratio));
   double unbalance_response = vib_unbalance_force / avg_stiffness / denominator;
   double thermal_response = t->thermal_bow * npd_sq(frequency_ratio) / denominator;
   double displacement_1x = (unbalance_response + thermal_response) * 39.37;
@@ -379,37 +534,8 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, double steam_pressure, double stea
   double total_displacement = sqrt(npd_sq(displacement_1x) + npd_sq(displacement_2x) + npd_sq(displacement_3x));
   t->vibration_displacement = total_displacement;
 
-  /* ---- MetalTemperatureTracker.update_temperatures  enhanced_physics.py:73-166 (time constant 3600 s = 1 h) */
-  const double time_constant = 3600.0 / 3600.0, ambient = 25.0;
-  double max_temp_rate = 0.0, max_stress = 0.0;
-  for (int i = 0; i < 8; i++) {
-    double target_temp = ss.stage_outlet_temperature[i] - 50.0;
-    double tc = (target_temp - t->rotor_temperatures[i]) / time_constant * dt;
-    double max_rate = 5.0 * dt;
-    tc = npd_clip(tc, -max_rate, max_rate);
-    t->rotor_temperatures[i] += tc;
-    double rate = tc / dt * 60.0;
-    max_temp_rate = (i == 0) ? fabs(rate) : npd_pymax(max_temp_rate, fabs(rate));
-  }
-  for (int i = 0; i < 6; i++) {
-    double target_temp = ss.stage_outlet_temperature[i] - 80.0;
-    double tc = (target_temp - t->casing_temperatures[i]) / time_constant * dt;
-    tc = npd_clip(tc, -3.0 * dt, 3.0 * dt);
-    t->casing_temperatures[i] += tc;
-  }
-  for (int i = 0; i < 14; i++) {
-    double target_temp = ss.stage_outlet_temperature[i] - 20.0;
-    double tc = (target_temp - t->blade_temperatures[i]) / (time_constant * 0.5) * dt;
-    tc = npd_clip(tc, -10.0 * dt, 10.0 * dt);
-    t->blade_temperatures[i] += tc;
-  }
-  for (int i = 0; i < 8; i++) {
-    double temp_diff = t->rotor_temperatures[i] - ambient;
-    double thermal_strain = 1.2e-05 * temp_diff;
-    double stress = thermal_strain * 200000000000.0 * 0.1;
-    max_stress = (i == 0) ? stress : npd_pymax(max_stress, stress);
-  }
-  (void)max_temp_rate;
+  /* MetalTemperatureTracker.update_temperatures ran per stage inside the stage pass (npd_stage_post) */
+  double max_stress = ss.max_thermal_stress;
 
   /* ---- TurbineProtectionSystem.check_trip_conditions  enhanced_physics.py:348-436 */
   int trips = 0, latched = t->trip_latched_mask;

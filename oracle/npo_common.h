@@ -28,7 +28,10 @@
 
 #define NPO_PI 3.141592653589793
 
-NPO_FN double npo_clip(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+NPO_FN double npo_clip(double x, double lo, double hi) { /* np.minimum(np.maximum(x, lo), hi): NaN propagates, lo > hi gives hi */
+  double t = (x < lo) ? lo : x;
+  return (t > hi) ? hi : t;
+}
 NPO_FN double npo_pymax(double a, double b) { return (b > a) ? b : a; }
 NPO_FN double npo_pymin(double a, double b) { return (b < a) ? b : a; }
 

@@ -13,6 +13,7 @@ typedef struct npo_plant_t {
   npb_pump_t pump[NPB_NUM_PUMPS];
   npb_fw_t fw;
   npb_turb_t turb;
+  npb_tstg_t tstg;
   npb_chem_t chem[2];
   npb_cond_t cond;
   npb_sec_t sec;

@@ -120,7 +120,7 @@ NPO_FN void npo_secondary_tail(npo_plant_t *pl, const npb_params_t *P, const npo
   double sg_pressures[NPB_NUM_SG];
   for (int i = 0; i < NPB_NUM_SG; i++) sg_pressures[i] = pl->sg[i].secondary_pressure;
   npo_turbine_result_t tr;
-  npo_turbine_update(&pl->turb, sgr->avg_pressure, sgr->avg_temperature, sgr->total_steam_flow, sg_pressures,
+  npo_turbine_update(&pl->turb, &pl->tstg, sgr->avg_pressure, sgr->avg_temperature, sgr->total_steam_flow, sg_pressures,
                      sec->sg_system_availability, sec->load_demand, 0.007, P->dt / 60.0, &tr);
   /* ---- condenser with the ACTUAL LP exhaust quality from LP-6's outlet enthalpy (:591-621) */
   double lp_exhaust_quality = 0.90;

@@ -163,7 +163,7 @@ typedef struct npo_stagesys_out_t {
 
 /* TurbineStageSystem.update_state  stage_system.py:928-1016 (+ calculate_stage_by_stage_expansion :760-926,
  * TurbineStage.update_degradation :294-339).  The control-logic pass (:525-651) only fills a command dict. */
-NPO_FN void npo_stage_system_update(npb_turb_t *t, double inlet_pressure, double inlet_temperature, double inlet_flow,
+NPO_FN void npo_stage_system_update(npb_tstg_t *t, double inlet_pressure, double inlet_temperature, double inlet_flow,
                                     double load_demand, double pressure_stability_factor, double dt, npo_stagesys_out_t *out) {
   /* extraction_demands dict  enhanced_physics.py:729-735 */
   double extraction_demand[14] = {0};
@@ -234,7 +234,7 @@ typedef struct npo_turbine_result_t {
   int trip_active;
 } npo_turbine_result_t;
 
-NPO_FN void npo_turbine_update(npb_turb_t *t, double steam_pressure, double steam_temperature, double steam_flow,
+NPO_FN void npo_turbine_update(npb_turb_t *t, npb_tstg_t *g, double steam_pressure, double steam_temperature, double steam_flow,
                                const double *sg_pressures, int sg_system_availability, double load_demand,
                                double condenser_pressure, double dt, npo_turbine_result_t *res) {
   /* ================= lubrication wrapper (pre-step, previous step's bearing state) =============
@@ -303,7 +303,7 @@ NPO_FN void npo_turbine_update(npb_turb_t *t, double steam_pressure, double stea
   t->load_demand = load_demand;
   double pressure_stability_factor = npo_pressure_stability_factor(sg_pressures);
   npo_stagesys_out_t ss;
-  npo_stage_system_update(t, steam_pressure, steam_temperature, steam_flow, load_demand, pressure_stability_factor, dt, &ss);
+  npo_stage_system_update(g, steam_pressure, steam_temperature, steam_flow, load_demand, pressure_stability_factor, dt, &ss);
   double stage_power_mw = ss.total_power;
   double applied_torque = stage_power_mw * 1e6 / (2 * NPO_PI * 3600 / 60);
 
@@ -385,27 +385,27 @@ NPO_FN void npo_turbine_update(npb_turb_t *t, double steam_pressure, double stea
   double max_temp_rate = 0.0, max_stress = 0.0;
   for (int i = 0; i < 8; i++) {
     double target_temp = ss.stage_outlet_temperature[i] - 50.0;
-    double tc = (target_temp - t->rotor_temperatures[i]) / time_constant * dt;
+    double tc = (target_temp - g->rotor_temperatures[i]) / time_constant * dt;
     double max_rate = 5.0 * dt;
     tc = npo_clip(tc, -max_rate, max_rate);
-    t->rotor_temperatures[i] += tc;
+    g->rotor_temperatures[i] += tc;
     double rate = tc / dt * 60.0;
     max_temp_rate = (i == 0) ? fabs(rate) : npo_pymax(max_temp_rate, fabs(rate));
   }
   for (int i = 0; i < 6; i++) {
     double target_temp = ss.stage_outlet_temperature[i] - 80.0;
-    double tc = (target_temp - t->casing_temperatures[i]) / time_constant * dt;
+    double tc = (target_temp - g->casing_temperatures[i]) / time_constant * dt;
     tc = npo_clip(tc, -3.0 * dt, 3.0 * dt);
-    t->casing_temperatures[i] += tc;
+    g->casing_temperatures[i] += tc;
   }
   for (int i = 0; i < 14; i++) {
     double target_temp = ss.stage_outlet_temperature[i] - 20.0;
-    double tc = (target_temp - t->blade_temperatures[i]) / (time_constant * 0.5) * dt;
+    double tc = (target_temp - g->blade_temperatures[i]) / (time_constant * 0.5) * dt;
     tc = npo_clip(tc, -10.0 * dt, 10.0 * dt);
-    t->blade_temperatures[i] += tc;
+    g->blade_temperatures[i] += tc;
   }
   for (int i = 0; i < 8; i++) {
-    double temp_diff = t->rotor_temperatures[i] - ambient;
+    double temp_diff = g->rotor_temperatures[i] - ambient;
     double thermal_strain = 1.2e-05 * temp_diff;
     double stress = thermal_strain * 200000000000.0 * 0.1;
     max_stress = (i == 0) ? stress : npo_pymax(max_stress, stress);

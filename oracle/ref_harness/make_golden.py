@@ -5,7 +5,8 @@ reference's outputs, plus the value of every schema column's reference attribute
   action[T] magnitude[T] setpoint[T] cooling[T] noise_z[T]     per-step inputs
   obs[T,22] reward[T] done[T] info[T,10]                        per-step outputs
   state_steps[K], state[K,ncol]                                 sampled state trajectory (step 0 = initial)
-  labels[ncol]                                                  schema column labels (f64 then i32 order of SCHEMA.columns())
+  labels[ncol], paths[ncol]                                     schema column labels at generation time and the reference
+                                                                attribute path of each column (the stable key tests match on)
   meta (json)                                                   ctor kwargs / scenario description
 
 Run:  python -m oracle.ref_harness.make_golden        (from the repo root)
@@ -66,6 +67,7 @@ def main(only=None):
     cols = SCHEMA.columns()
     labels = np.array([c[2] for c in cols])
     kinds = np.array([c[0] for c in cols])
+    paths = np.array([c[3] for c in cols])
     for sc in scenarios():
         if only and sc["name"] not in only:
             continue
@@ -77,12 +79,12 @@ def main(only=None):
         meta["pokes"] = {str(k): [[p, float(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
         # pokes expressed in schema labels so tests can replay them without the reference
         path_to_label = {c[3]: (c[0], c[1], c[2]) for c in cols}
-        meta["pokes_schema"] = {str(k): [[path_to_label[p][2], float(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
+        meta["pokes_schema"] = {str(k): [[p, float(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
         np.savez_compressed(os.path.join(OUT, sc["name"] + ".npz"),
                             action=ref["action"], magnitude=ref["magnitude"], setpoint=ref["setpoint"],
                             cooling=ref["cooling"], noise_z=ref["noise_z"], obs=ref["obs"], reward=ref["reward"],
                             done=ref["done"], info=ref["info"], state_steps=np.array(steps),
-                            state=ref["state"][steps], labels=labels, kinds=kinds, meta=json.dumps(meta))
+                            state=ref["state"][steps], labels=labels, kinds=kinds, paths=paths, meta=json.dumps(meta))
         print(sc["name"], "steps", T, "dones", int(ref["done"].sum()), "elec", float(ref["obs"][-1, 12] * 1100))
 
 

@@ -28,11 +28,19 @@ class Golden:
         self.name = name
         self.meta = json.loads(str(z["meta"]))
         for k in ("action", "magnitude", "setpoint", "cooling", "noise_z", "obs", "reward", "done", "info",
-                  "state_steps", "state", "labels", "kinds"):
+                  "state_steps", "labels", "kinds", "paths"):
             setattr(self, k, z[k])
         self.T = len(self.action)
+        # columns are matched by the reference attribute path, so a schema re-ordering does not
+        # invalidate the fixtures; schema columns the fixture does not know become NaN (unchecked)
         cols = SCHEMA.columns()
-        assert [c[2] for c in cols] == list(self.labels), "fixture was generated with a different schema: regenerate"
+        idx = {str(p): j for j, p in enumerate(self.paths) if str(p)}
+        raw = z["state"]
+        st = np.full((raw.shape[0], len(cols)), np.nan)
+        for j, c in enumerate(cols):
+            if c[3] in idx:
+                st[:, j] = raw[:, idx[c[3]]]
+        self.state = st
         self.cols = cols
         self.pokes = {int(k): v for k, v in self.meta.get("pokes_schema", {}).items()}
 
@@ -49,11 +57,12 @@ class Golden:
                 i[slot] = int(v); im[slot] = True
         return f, i, fm, im
 
-    def label_slot(self, label):
-        for kind, slot, lab, _p in self.cols:
-            if lab == label:
+    def label_slot(self, path):
+        """(kind, slot) of the schema column whose reference attribute path is `path`."""
+        for kind, slot, _lab, p in self.cols:
+            if p == path:
                 return kind, slot
-        raise KeyError(label)
+        raise KeyError(path)
 
 
 def compare_state(g, f64, i32, row, where):
