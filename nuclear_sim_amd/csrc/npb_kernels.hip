@@ -202,12 +202,18 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     acc.total_flow = acc.total_power = acc.flow_sum = 0.0;
     acc.total_cavitation_risk = acc.total_wear_level = acc.total_vibration = 0.0;
     acc.running_count = acc.running_mask = acc.trips = 0; acc.trip_mask = 0;
+    /* double-buffered: pump i+1's columns are requested before pump i is computed, so their HBM
+     * latency hides behind ~4k instructions of arithmetic (one wave per SIMD has no other cover) */
+    npb_pump_t pm;
+    NPD_LOAD(PUMP, npb_pump_t, pm, 0);
 #pragma unroll 1
     for (int i = 0; i < NPB_NUM_PUMPS; i++) {
-      npb_pump_t pm;
-      NPD_LOAD(PUMP, npb_pump_t, pm, i);
+      npb_pump_t nxt;
+      if (i + 1 < NPB_NUM_PUMPS) NPD_LOAD(PUMP, npb_pump_t, nxt, i + 1);
+      else nxt = pm;
       npd_fw_pump_step(&pm, &fw, &acc, i, n_prev_running, flow_per_pump, &sc, dt);
       NPD_STORE(PUMP, npb_pump_t, pm, i);
+      pm = nxt;
     }
     npd_fw_result_t fwr;
     npd_fw_finish(&fw, &acc, prev_levels, dt, &fwr);
@@ -226,15 +232,18 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     double total_primary_flow = 0.0;
 #pragma unroll
     for (int i = 0; i < NPB_NUM_SG; i++) total_primary_flow += c.flow[i];
+    npb_sg_t g;
+    NPD_LOAD(SG, npb_sg_t, g, 0);
 #pragma unroll 1
     for (int i = 0; i < ((NPB_ABLATE & 2) ? 0 : NPB_NUM_SG); i++) {
+      npb_sg_t gn;
+      if (i + 1 < NPB_NUM_SG) NPD_LOAD(SG, npb_sg_t, gn, i + 1); /* double-buffered like the pumps */
+      else gn = g;
       double demand = (total_primary_flow > 0) ? actual_total_steam_flow * (c.flow[i] / total_primary_flow)
                                                : actual_total_steam_flow / NPB_NUM_SG;
       /* full mode: equal split of the actual feedwater flow (:500-506 key mismatch); config-2 mode:
        * "perfect mass balance" fallback (enhanced_physics.py:495-497) */
       double fwflow = (P.mode == NPB_MODE_FULL) ? fw_total_flow / NPB_NUM_SG : demand;
-      npb_sg_t g;
-      NPD_LOAD(SG, npb_sg_t, g, i);
       npd_sg_result_t r;
       npd_sg_update(&g, &P, c.inlet_temp[i], c.outlet_temp[i], c.flow[i], demand, fwflow, actual_feedwater_temp, dt * 60, &r);
       NPD_STORE(SG, npb_sg_t, g, i);
@@ -245,6 +254,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       NPD_F64_COLK(SEC, npb_sec_t, prev_sg_levels, 0, i) = g.water_level;
       NPD_F64_COLK(SEC, npb_sec_t, prev_sg_steam_flows, 0, i) = r.steam_flow_rate;
       NPD_F64_COLK(SEC, npb_sec_t, prev_sg_qualities, 0, i) = g.steam_quality;
+      g = gn;
     }
   }
   const double sg_avg_pressure = sg_ap / NPB_NUM_SG, sg_avg_temperature = sg_at / NPB_NUM_SG, sg_avg_quality = sg_aq / NPB_NUM_SG;

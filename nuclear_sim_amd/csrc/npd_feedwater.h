@@ -178,10 +178,14 @@ NPD_FN void npd_pump_update(npb_pump_t *p, const npd_pump_sysconds_t *sc, double
   avg_wear += p->wear_impeller; avg_wear += p->wear_motor_bearings; avg_wear += p->wear_pump_bearings;
   avg_wear += p->wear_thrust_bearing; avg_wear += p->wear_mechanical_seals; avg_wear += p->wear_coupling_system;
   avg_wear = avg_wear / 6;
-  npd_oil_t oil = {&p->oil_temperature, &p->oil_contamination, &p->oil_moisture, &p->oil_acidity, &p->oil_viscosity_change,
-                   &p->antioxidant_level, &p->anti_wear_level, &p->corrosion_inhibitor_level, &p->lubrication_effectiveness};
+  npd_oil_t oil = {p->oil_temperature, p->oil_contamination, p->oil_moisture, p->oil_acidity, p->oil_viscosity_change,
+                   p->antioxidant_level, p->anti_wear_level, p->corrosion_inhibitor_level, p->lubrication_effectiveness};
   const npd_oil_limits_t lim = {15.0, 1.6, 0.08, 10.0};
   npd_update_oil_quality(&oil, &lim, avg_wear, oil_temp, total_contamination_input, 0.0001, dt / 60.0);
+  p->oil_temperature = oil.temperature; p->oil_contamination = oil.contamination; p->oil_moisture = oil.moisture;
+  p->oil_acidity = oil.acidity; p->oil_viscosity_change = oil.viscosity_change; p->antioxidant_level = oil.antioxidant;
+  p->anti_wear_level = oil.anti_wear; p->corrosion_inhibitor_level = oil.corrosion_inhibitor;
+  p->lubrication_effectiveness = oil.effectiveness;
 
   /* update_component_wear  lubrication_base.py:354-401 with calculate_component_wear
    * pump_lubrication.py:275-396; wear levels are read live, so later components see earlier updates */

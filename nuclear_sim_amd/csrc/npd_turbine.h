@@ -423,11 +423,15 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, double *__restrict__ f64, size_t N
   double avg_wear = 0.0;
   for (int i = 0; i < 5; i++) avg_wear += t->lub_wear[i];
   avg_wear = avg_wear / 5;
-  npd_oil_t oil = {&t->lub_oil_temperature, &t->lub_oil_contamination, &t->lub_oil_moisture, &t->lub_oil_acidity,
-                   &t->lub_oil_viscosity_change, &t->lub_antioxidant_level, &t->lub_anti_wear_level,
-                   &t->lub_corrosion_inhibitor_level, &t->lub_effectiveness};
+  npd_oil_t oil = {t->lub_oil_temperature, t->lub_oil_contamination, t->lub_oil_moisture, t->lub_oil_acidity,
+                   t->lub_oil_viscosity_change, t->lub_antioxidant_level, t->lub_anti_wear_level,
+                   t->lub_corrosion_inhibitor_level, t->lub_effectiveness};
   const npd_oil_limits_t lim = {8.0, 0.3, 0.05, 20.0};
   npd_update_oil_quality(&oil, &lim, avg_wear, system_oil_temp, contamination_input, moisture_input, dt);
+  t->lub_oil_temperature = oil.temperature; t->lub_oil_contamination = oil.contamination; t->lub_oil_moisture = oil.moisture;
+  t->lub_oil_acidity = oil.acidity; t->lub_oil_viscosity_change = oil.viscosity_change;
+  t->lub_antioxidant_level = oil.antioxidant; t->lub_anti_wear_level = oil.anti_wear;
+  t->lub_corrosion_inhibitor_level = oil.corrosion_inhibitor; t->lub_effectiveness = oil.effectiveness;
   /* update_component_wear with calculate_component_wear :261-333; map_bearing_to_lubrication_components :931-964 */
   for (int i = 0; i < 5; i++) {
     double wear_rate;
