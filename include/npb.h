@@ -97,6 +97,11 @@ NPB_API int npb_step(NpbHandle *h, const int32_t *action, const double *magnitud
 /* NuclearPlantSimulator.get_observation (sim.py:290-333) */
 NPB_API int npb_observe(NpbHandle *h, double *obs, void *stream);
 
+/* Measurement aid (no reference counterpart): streams every state column through the GPU unchanged,
+ * 2 * npb_state_bytes() * pitch bytes with the step kernel's access shape; used to calibrate the
+ * rocprofv3 FETCH_SIZE / WRITE_SIZE counters (tools/profile_traffic.py). */
+NPB_API int npb_debug_touch(NpbHandle *h, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,7 @@ def load():
     L.npb_state_arena.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
     L.npb_step.argtypes = [vp] + [vp] * 11
     L.npb_observe.argtypes = [vp, vp, vp]
+    L.npb_debug_touch.argtypes = [vp, vp]
     if L.npb_num_f64() != SCHEMA.total_f64 or L.npb_num_i32() != SCHEMA.total_i32:
         raise NpbError("libnpb.so was built against a different include/npb_fields.h (%d/%d vs %d/%d): rebuild"
                        % (L.npb_num_f64(), L.npb_num_i32(), SCHEMA.total_f64, SCHEMA.total_i32))

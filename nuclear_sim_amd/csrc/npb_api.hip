@@ -147,6 +147,14 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
   return NPB_OK;
 }
 
+int npb_debug_touch(NpbHandle *h, void *stream) {
+  if (!h) return NPB_EINVAL;
+  npb_launch_touch(h->pitch, h->f64, h->i32, (hipStream_t)stream);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_debug_touch: kernel launch failed", e);
+  return NPB_OK;
+}
+
 int npb_observe(NpbHandle *h, double *obs, void *stream) {
   if (!h || !obs) return NPB_EINVAL;
   npb_launch_observe(h->params.mode, h->n_plants, h->pitch, h->f64, h->i32, obs, (hipStream_t)stream);

@@ -14,6 +14,7 @@ void npb_launch_observe(int mode, int n_plants, size_t npad, const double *f64, 
                         hipStream_t stream);
 void npb_launch_init(const npb_params_t *P, int n_plants, size_t npad, double *f64, int32_t *i32, const uint8_t *mask,
                      hipStream_t stream);
+void npb_launch_touch(size_t npad, double *f64, int32_t *i32, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

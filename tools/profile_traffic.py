@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 PMC passes: K launches of the calibration kernel (known bytes) followed
+by K launches of the step kernel on the bench workload.  Run once per counter:
+
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d OUT/fetch -- python3 tools/profile_traffic.py
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d OUT/write -- python3 tools/profile_traffic.py
+then  python3 tools/profile_traffic.py --summarize OUT  prints per-launch HBM bytes of npb_step_kernel,
+scaled by (known bytes of npb_touch_kernel) / (counter reading of npb_touch_kernel).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+N = 65536
+K = 10
+
+
+def run():
+    import numpy as np
+    import torch
+    from nuclear_sim_amd.env import BatchedPlantEnv
+    from nuclear_sim_amd import _lib
+    env = BatchedPlantEnv(N, noise_enabled=True)
+    dev = env.device
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    z = torch.randn((K + 3, N), device=dev, dtype=torch.float64, generator=gen)
+    sp = torch.full((N,), 95.0, device=dev, dtype=torch.float64)
+    for t in range(3):
+        env.step(power_setpoint=sp, noise_z=z[t])
+    torch.cuda.synchronize()
+    for _ in range(K):
+        _lib.check(env.L.npb_debug_touch(env._h, env._stream()), env._h)
+    torch.cuda.synchronize()
+    for t in range(K):
+        env.step(power_setpoint=sp, noise_z=z[3 + t])
+    torch.cuda.synchronize()
+
+
+def counter_per_kernel(d, counter):
+    vals = {}
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = row["Kernel_Name"].split("(")[0]
+            vals.setdefault(name, []).append(float(row["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in vals.items()}, {k: len(v) for k, v in vals.items()}
+
+
+def summarize(out):
+    from nuclear_sim_amd.schema import SCHEMA
+    state = SCHEMA.state_bytes()
+    known = state * N  # bytes read == bytes written by one touch launch
+    res = {"plants": N, "known_bytes_per_touch_launch_each_way": known}
+    total = 0.0
+    for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+        avg, cnt = counter_per_kernel(os.path.join(out, sub), counter)
+        touch = avg.get("npb_touch_kernel"); step = avg.get("npb_step_kernel")
+        if touch is None or step is None:
+            res[counter] = "missing"; continue
+        raw_unit_bytes = 1024.0  # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
+        scale = known / (touch * raw_unit_bytes)
+        res[counter] = {"touch_raw_kib": touch, "step_raw_kib": step, "launches": cnt.get("npb_step_kernel"),
+                        "calibration_scale": scale, "step_bytes_calibrated": step * raw_unit_bytes * scale}
+        total += step * raw_unit_bytes * scale
+    res["step_hbm_bytes_per_launch"] = total
+    res["algorithmic_bytes_per_launch"] = (2 * state + 36 + 269) * N
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--summarize":
+        summarize(sys.argv[2])
+    else:
+        run()
