@@ -51,6 +51,21 @@ def cpu_baseline(seconds_budget=15.0):
             "sample": "%d plants x %d steps of the same C3 workload through oracle/libnpo.so (OpenMP over plants, %.1f s)" % (n, steps, dt)}
 
 
+def measured_traffic(n):
+    """HBM bytes per npb_step_kernel launch from the committed rocprofv3 PMC passes (profiles/README.md);
+    only meaningful for the plant count it was measured at."""
+    best = None
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("plants") == n and isinstance(d.get("step_hbm_bytes_per_launch"), (int, float)):
+                best = float(d["step_hbm_bytes_per_launch"])
+        except Exception:
+            pass
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,7 +160,8 @@ def main():
                        "state_bytes_per_plant": BatchedPlantEnv.state_bytes_per_plant(),
                        "algorithmic_bytes_per_plant_step": bytes_per_plant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
+                         "algorithmic_bytes_per_launch": bytes_per_plant * n,
                          "kernel": "npb_step_kernel", "kernel_ms": kernel_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
