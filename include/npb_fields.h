@@ -227,6 +227,26 @@
   F(water_aggressiveness,   "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].water_aggressiveness") \
   F(scaling_tendency,       "=(root.secondary_physics.water_chemistry, root.secondary_physics.condenser.water_chemistry)[{i}].scaling_tendency")
 
+/* ---- pH controller of the secondary system + the effects it leaves pending for the next
+ * WaterChemistry update.  reference: ph_control_system.py:131-190 (PHControllerState),
+ * water_chemistry.py:659-681 (_pending_chemistry_effects).  The controller's sensor noise and random
+ * equipment failures use numpy's unseeded GLOBAL RNG (ph_control_system.py:278,288,409-420) and are
+ * therefore not reproducible in the reference itself; this model is the deterministic limit
+ * (noise 0, no random failures), which is also how the golden vectors were taken. */
+#define NPB_PH_FIELDS(F, A, I) \
+  F(measured_ph,            "secondary_physics.ph_control_system.controller.state.measured_ph") \
+  F(integral_sum,           "secondary_physics.ph_control_system.controller.state.integral_sum") \
+  F(previous_error,         "secondary_physics.ph_control_system.controller.state.previous_error") \
+  F(controller_output,      "secondary_physics.ph_control_system.controller.state.controller_output") \
+  F(ammonia_tank_level,     "secondary_physics.ph_control_system.controller.state.ammonia_tank_level") \
+  F(morpholine_tank_level,  "secondary_physics.ph_control_system.controller.state.morpholine_tank_level") \
+  F(pending_ammonia_dose,   "=root.secondary_physics.water_chemistry._pending_chemistry_effects['ph_control']['ammonia_dose_rate']") \
+  F(pending_morpholine_dose,"=root.secondary_physics.water_chemistry._pending_chemistry_effects['ph_control']['morpholine_dose_rate']") \
+  I(controller_enabled,     "secondary_physics.ph_control_system.controller.state.controller_enabled") \
+  I(ammonia_supply_available, "secondary_physics.ph_control_system.controller.state.ammonia_supply_available") \
+  I(morpholine_supply_available, "secondary_physics.ph_control_system.controller.state.morpholine_supply_available") \
+  I(has_pending_effects,    "")
+
 /* ---- condenser: tube degradation, 3-species fouling, vacuum system with 2 steam-jet ejectors
  * reference: condenser/physics.py:55-71,151-165,540-559, vacuum_system.py:40-52,270-300,
  *            vacuum_pump.py:52-92 */
@@ -287,6 +307,7 @@
   S(turb, TURB, npb_turb_t, 1) \
   S(tstg, TSTG, npb_tstg_t, 1) \
   S(chem, CHEM, npb_chem_t, 2) \
+  S(ph,   PH,   npb_ph_t,   1) \
   S(cond, COND, npb_cond_t, 1) \
   S(sec,  SEC,  npb_sec_t,  1)
 

@@ -25,6 +25,7 @@
 #include "npd_feedwater.h"
 #include "npd_turbine.h"
 #include "npd_condenser.h"
+#include "npd_ph.h"
 #include "npd_init.h"
 #include "npb_kernels.h"
 
@@ -293,6 +294,15 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       NPD_STORE(CHEM, npb_chem_t, ch, 1);
     }
     condenser_pressure = cr.condenser_pressure;
+    /* ================= chemistry sidecar: shared WaterChemistry + pH controller (:634-665) ========= */
+    {
+      npb_chem_t ch; npb_ph_t ph;
+      NPD_LOAD(CHEM, npb_chem_t, ch, 0);
+      NPD_LOAD(PH, npb_ph_t, ph, 0);
+      npd_chemistry_sidecar(&ch, &ph, dt);
+      NPD_STORE(CHEM, npb_chem_t, ch, 0);
+      NPD_STORE(PH, npb_ph_t, ph, 0);
+    }
     /* ================= electrical-power gates (:750-932) ================= */
     double turbine_electrical_power = tr.electrical_power_net;
     total_system_heat_rejection = (primary_thermal_power - turbine_electrical_power) * 1e6;
@@ -428,6 +438,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size
   { npb_turb_t t; npb_tstg_t g; npd_turb_init(&t, &g); NPD_STORE(TURB, npb_turb_t, t, 0); NPD_STORE(TSTG, npb_tstg_t, g, 0); }
 #pragma unroll 1
   for (int i = 0; i < 2; i++) { npb_chem_t ch; npd_chem_init(&ch, i); NPD_STORE(CHEM, npb_chem_t, ch, i); }
+  { npb_ph_t ph; npd_ph_init(&ph); NPD_STORE(PH, npb_ph_t, ph, 0); }
   { npb_cond_t cd; npd_cond_init(&cd); NPD_STORE(COND, npb_cond_t, cd, 0); }
   { npb_sec_t sec; npd_sec_init(&sec); NPD_STORE(SEC, npb_sec_t, sec, 0); }
   (void)P;

@@ -134,6 +134,13 @@ NPO_FN void npo_chem_init(npb_chem_t *c, int index) {
   if (index == 1) { c->ph = 7.5; c->hardness = 150.0; c->chlorine_residual = 1.0; c->dissolved_oxygen = 8.0; }
 }
 
+/* PHControllerState defaults  ph_control_system.py:131-190 */
+NPO_FN void npo_ph_init(npb_ph_t *s) {
+  memset(s, 0, sizeof(*s));
+  s->measured_ph = 9.2; s->ammonia_tank_level = 80.0; s->morpholine_tank_level = 80.0;
+  s->controller_enabled = 1; s->ammonia_supply_available = 1; s->morpholine_supply_available = 1;
+}
+
 /* EnhancedCondenserPhysics.__init__ + _apply_initial_conditions condenser/physics.py:486-562,1374-1555 with
  * CondenserInitialConditions defaults (condenser/config.py); VacuumSystem.__init__ vacuum_system.py:252-300 */
 NPO_FN void npo_cond_init(npb_cond_t *cd) {
@@ -155,6 +162,7 @@ NPO_FN void npo_plant_init(npo_plant_t *pl, const npb_params_t *P) {
   npo_fw_init(&pl->fw);
   npo_turb_init(&pl->turb, &pl->tstg);
   for (int i = 0; i < 2; i++) npo_chem_init(&pl->chem[i], i);
+  npo_ph_init(&pl->ph);
   npo_cond_init(&pl->cond);
   npo_sec_init(&pl->sec);
 }

@@ -15,6 +15,7 @@ typedef struct npo_plant_t {
   npb_turb_t turb;
   npb_tstg_t tstg;
   npb_chem_t chem[2];
+  npb_ph_t ph;
   npb_cond_t cond;
   npb_sec_t sec;
 } npo_plant_t;

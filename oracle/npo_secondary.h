@@ -15,6 +15,7 @@
 #include "npo_feedwater.h"
 #include "npo_turbine.h"
 #include "npo_condenser.h"
+#include "npo_ph.h"
 
 typedef struct npo_secondary_result_t {
   double electrical_power_mw, thermal_efficiency, total_steam_flow, sg_avg_pressure;
@@ -35,7 +36,7 @@ NPO_FN void npo_feedwater_obs(const npo_plant_t *pl, int mode, double *flow, dou
 /* SecondaryReactorPhysics._saturation_temperature  secondary/__init__.py:1455 ff */
 NPO_FN double npo_sec_tsat(double pressure_mpa);
 
-NPO_FN void npo_secondary_chemistry(npo_plant_t *pl, const npb_params_t *P) { (void)pl; (void)P; /* filled in by npo_ph.h */ }
+NPO_FN void npo_secondary_chemistry(npo_plant_t *pl, const npb_params_t *P) { npo_chemistry_sidecar(&pl->chem[0], &pl->ph, P->dt); }
 
 /* turbine -> condenser -> gates */
 NPO_FN void npo_secondary_tail(npo_plant_t *pl, const npb_params_t *P, const npo_coupling_t *c,

@@ -8,9 +8,8 @@ import numpy as np
 from nuclear_sim_amd.schema import SCHEMA
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-# state columns owned by subsystems that are not restated yet (the shared WaterChemistry +
-# pH controller sidecar): present in the schema/fixtures, excluded from parity
-EXEMPT_PREFIXES = ("chem[0].",)
+# state columns excluded from parity (none: every schema column is checked)
+EXEMPT_PREFIXES = ()
 # fp64 tolerance of the parity contract (BASELINE.json north_star: 1e-6 relative on fp64 state)
 RTOL = 1e-6
 # columns that are differences of nearly equal numbers (1 - area ratio ~ 1e-8..1e-7): their relative error
@@ -69,7 +68,7 @@ def compare_state(g, f64, i32, row, where):
     """Assert a stepper's (f64, i32) state against a fixture row."""
     bad = []
     for (kind, slot, label, _p), v in zip(g.cols, row):
-        if np.isnan(v) or label.startswith(EXEMPT_PREFIXES):
+        if np.isnan(v) or (EXEMPT_PREFIXES and label.startswith(EXEMPT_PREFIXES)):
             continue
         if kind == "i32":
             if int(i32[slot]) != int(v):

@@ -117,8 +117,6 @@ def test_hip_matches_oracle_on_random_batch(oracle_lib, heat_source, mode):
     for pl in range(0, n, 37):
         of, oi = ora.state(pl)
         for kind, slot, label, _p in cols:
-            if label.startswith(EXEMPT_PREFIXES):
-                continue
             if kind == "i32":
                 assert int(i[slot, pl]) == int(oi[slot]), (label, pl)
             else:
