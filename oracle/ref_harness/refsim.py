@@ -55,6 +55,15 @@ def _build_dataclass(cls, data):
                 if dataclasses.is_dataclass(arg) and isinstance(v, dict):
                     v = _build_dataclass(arg, v)
                     break
+        # scalar coercion dataclass_wizard would do (PyYAML reads "3000.0e6" as a str)
+        if t is float and isinstance(v, (str, int)) and not isinstance(v, bool):
+            v = float(v)
+        elif t is int and isinstance(v, str):
+            v = int(float(v))
+        elif origin in (list, typing.List) and isinstance(v, list):
+            (arg,) = typing.get_args(t) or (None,)
+            if arg is float:
+                v = [float(x) if isinstance(x, (str, int)) and not isinstance(x, bool) else x for x in v]
         kwargs[f.name] = v
     return cls(**kwargs)
 
@@ -84,8 +93,13 @@ def setup():
             cls.from_dict = classmethod(_build_dataclass)
     # neutralise the unseeded global RNG used only by the pH controller
     import numpy as np
-    np.random.normal = lambda *a, **k: 0.0
-    np.random.random = lambda *a, **k: 1.0
+    def _normal(loc=0.0, scale=1.0, size=None):
+        return 0.0 if size is None else np.zeros(size)
+
+    def _random(size=None):
+        return 1.0 if size is None else np.ones(size)
+    np.random.normal = _normal
+    np.random.random = _random
     _ready = True
 
 
