@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--plants-per-gpu", type=int, default=PLANTS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--maintenance", action="store_true",
+                    help="also run the automatic oil_top_off maintenance kernel after every step (not the headline workload)")
     args = ap.parse_args()
 
     import torch
@@ -97,7 +99,8 @@ def main():
     lo = rank * n
     K, W = args.steps, args.warmup
 
-    env = BatchedPlantEnv(n, dt=1.0, heat_source="constant", noise_enabled=True, noise_std_percent=0.1, device=local_rank)
+    env = BatchedPlantEnv(n, dt=1.0, heat_source="constant", noise_enabled=True, noise_std_percent=0.1, device=local_rank,
+                          maintenance=args.maintenance)
     # synthetic inputs, resident in HBM before the timed region: per-plant load-following setpoint
     # trace (90 % + 10 % sin, period 600 + 60*(i mod 16) steps) and N(0,1) noise samples
     gid = torch.arange(lo, lo + n, device=dev, dtype=torch.float64)
@@ -158,7 +161,7 @@ def main():
                                    "load-following setpoints, dt=1.0, obs+reward+done+trip_flags+info written every step" % (n, n_global),
                        "plants_per_gpu": n, "global_plants": n_global, "parallelism": "plants sharded contiguously, no data-path collective",
                        "state_bytes_per_plant": BatchedPlantEnv.state_bytes_per_plant(),
-                       "algorithmic_bytes_per_plant_step": bytes_per_plant},
+                       "algorithmic_bytes_per_plant_step": bytes_per_plant, "maintenance_kernel": bool(args.maintenance)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
                          "algorithmic_bytes_per_launch": bytes_per_plant * n,

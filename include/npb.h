@@ -57,7 +57,8 @@ NPB_API int npb_num_f64(void);
 NPB_API int npb_num_i32(void);
 /* carried bytes per plant = 8 * num_f64 + 4 * num_i32: S_carry of the roofline accounting */
 NPB_API size_t npb_state_bytes(void);
-/* algorithmic HBM bytes of one plant-step: 2 * state_bytes (read + write every carried column)
+/* algorithmic HBM bytes of one plant-step: 2 * state_bytes (read + write every carried column the
+ * step kernel owns, i.e. all but the maint.* section, which only the maintenance kernel touches)
  * + per-step inputs (action 4 + magnitude/setpoint/noise/cooling 4*8) + outputs (obs 22*8 + reward 8
  * + done 1 + trip_flags 4 + info 10*8) */
 NPB_API size_t npb_step_bytes_per_plant(void);

@@ -298,6 +298,24 @@
   I(has_previous_sg_conditions, "") \
   I(sg_system_availability,   "secondary_physics.steam_generator_system.system_availability")
 
+/* ---- automatic maintenance, oil_top_off action: the emergent rule of
+ * AutoMaintenanceSystem.update + StateManager threshold checks for the feedwater pumps' oil_level
+ * threshold.  Carried only when params.maint_enabled; the step kernel never touches these columns.
+ * reference: systems/maintenance/auto_maintenance.py:200-236 (check cadence), :392-456 (work-order
+ *            creation, duplicate/cooldown rules), :468-488,:504-580 (execution),
+ *            simulator/state/state_manager.py:1267-1369 (threshold cooldown + violation scan).
+ * "=H.*" paths are evaluated by oracle/ref_harness/leaves.py helpers (dict lookups with defaults).
+ * wo_order[k]: 0 = pump k has no open work order, n = its open order was the n-th created
+ * (WorkOrderManager.work_orders is insertion ordered and executed in that order). */
+#define NPB_MAINT_FIELDS(F, A, I) \
+  F(last_check_time,          "maintenance_system.last_check_time") \
+  A(wo_order, 4,              "=H.open_wo(root, {k}, 'order')") \
+  A(wo_planned_start, 4,      "=H.open_wo(root, {k}, 'planned_start_date')") \
+  A(last_violation_time, 4,   "=H.last_violation(root, {k})") \
+  A(last_trigger_time, 4,     "=H.last_trigger(root, {k})") \
+  I(work_orders_created,      "maintenance_system.work_orders_created") \
+  I(maintenance_actions_performed, "maintenance_system.maintenance_actions_performed")
+
 /* section list: S(member, TYPE, struct_type, count) */
 #define NPB_SECTIONS(S) \
   S(prim, PRIM, npb_prim_t, 1) \
@@ -309,7 +327,8 @@
   S(chem, CHEM, npb_chem_t, 2) \
   S(ph,   PH,   npb_ph_t,   1) \
   S(cond, COND, npb_cond_t, 1) \
-  S(sec,  SEC,  npb_sec_t,  1)
+  S(sec,  SEC,  npb_sec_t,  1) \
+  S(maint, MAINT, npb_maint_t, 1)
 
 /* ------------------------------------------------------------------ structs */
 #define NPB__F(name, path)        double name;

@@ -41,7 +41,15 @@
   P(sgchem_copper,                0.05,     "secondary_physics.steam_generator_system.water_chemistry.copper_concentration") \
   P(sgchem_silica,                20.0,     "secondary_physics.steam_generator_system.water_chemistry.silica_concentration") \
   P(sgchem_ph,                    9.2,      "secondary_physics.steam_generator_system.water_chemistry.ph") \
-  P(sgchem_dissolved_oxygen,      0.005,    "secondary_physics.steam_generator_system.water_chemistry.dissolved_oxygen")
+  P(sgchem_dissolved_oxygen,      0.005,    "secondary_physics.steam_generator_system.water_chemistry.dissolved_oxygen") \
+  /* ---- automatic maintenance, oil_top_off (used only when maint_enabled; values of the data-gen \
+   *      action-test scenario: auto_maintenance.py:121-160 aggressive mode, feedwater thresholds YAML) */ \
+  P(maint_check_interval_hours,   0.25,     "maintenance_system.check_interval_hours") \
+  P(maint_oil_level_threshold,    58.0,     "state_manager.maintenance_thresholds['FWP-1']['oil_level']['threshold']") \
+  P(maint_oil_level_cooldown_hours, 168.0,  "state_manager.maintenance_thresholds['FWP-1']['oil_level']['cooldown_hours']") \
+  P(maint_work_order_cooldown,    24.0,     "maintenance_system.work_order_cooldown_hours") \
+  P(maint_start_delay_hours,      0.0,      "maintenance_system.high_priority_delay_hours") \
+  P(maint_top_off_target,         95.0,     "")
 
 typedef struct npb_params_t {
 #define NPB__P(name, dflt, path) double name;
@@ -52,7 +60,7 @@ typedef struct npb_params_t {
   int heat_source;         /* NPB_HEAT_CONSTANT | NPB_HEAT_REACTOR */
   int hs_noise_enabled;    /* ConstantHeatSource(noise_enabled=...) */
   int mode;                /* NPB_MODE_FULL | NPB_MODE_PRIMARY_SG */
-  int reserved_;
+  int maint_enabled;       /* 1: run the oil_top_off maintenance rule after every step (maint.* columns) */
 } npb_params_t;
 
 enum { NPB_HEAT_CONSTANT = 0, NPB_HEAT_REACTOR = 1 };
@@ -66,7 +74,7 @@ static inline void npb_params_default(npb_params_t *p) {
   p->heat_source = NPB_HEAT_CONSTANT;
   p->hs_noise_enabled = 0;
   p->mode = NPB_MODE_FULL;
-  p->reserved_ = 0;
+  p->maint_enabled = 0;
 }
 
 #endif /* NPB_PARAMS_H */

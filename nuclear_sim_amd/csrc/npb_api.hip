@@ -37,7 +37,8 @@ int npb_num_f64(void) { return NPB_TOTAL_F64; }
 int npb_num_i32(void) { return NPB_TOTAL_I32; }
 size_t npb_state_bytes(void) { return (size_t)NPB_TOTAL_F64 * 8 + (size_t)NPB_TOTAL_I32 * 4; }
 size_t npb_step_bytes_per_plant(void) {
-  return 2 * npb_state_bytes() + (4 + 4 * 8) + (NPB_OBS_DIM * 8 + 8 + 1 + 4 + NPB_INFO_DIM * 8);
+  const size_t maint = (size_t)NPB_MAINT_NF64 * 8 + (size_t)NPB_MAINT_NI32 * 4; /* not touched by the step kernel */
+  return 2 * (npb_state_bytes() - maint) + (4 + 4 * 8) + (NPB_OBS_DIM * 8 + 8 + 1 + 4 + NPB_INFO_DIM * 8);
 }
 void npb_default_params(npb_params_t *p) { npb_params_default(p); }
 
@@ -142,6 +143,7 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
   if (!h) return NPB_EINVAL;
   npb_launch_step(&h->params, h->n_plants, h->pitch, h->f64, h->i32, action, magnitude, power_setpoint, noise_z,
                   cooling_water_temp, obs, reward, done, trip_flags, info, (hipStream_t)stream);
+  if (h->params.maint_enabled) npb_launch_maint(&h->params, h->pitch, h->f64, h->i32, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_step: kernel launch failed", e);
   return NPB_OK;

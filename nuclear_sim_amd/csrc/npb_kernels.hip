@@ -26,6 +26,7 @@
 #include "npd_turbine.h"
 #include "npd_condenser.h"
 #include "npd_ph.h"
+#include "npd_maintenance.h"
 #include "npd_init.h"
 #include "npb_kernels.h"
 
@@ -441,7 +442,35 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size
   { npb_ph_t ph; npd_ph_init(&ph); NPD_STORE(PH, npb_ph_t, ph, 0); }
   { npb_cond_t cd; npd_cond_init(&cd); NPD_STORE(COND, npb_cond_t, cd, 0); }
   { npb_sec_t sec; npd_sec_init(&sec); NPD_STORE(SEC, npb_sec_t, sec, 0); }
+  { npb_maint_t m; npd_maint_init(&m); NPD_STORE(MAINT, npb_maint_t, m, 0); }
   (void)P;
+}
+
+/* automatic maintenance after a step (params.maint_enabled): AutoMaintenanceSystem.update then the
+ * state manager's threshold scan (npd_maintenance.h).  HBM-bound and small: per plant it reads
+ * sim_time, the maint section and four oil levels (184 B); it writes only what changed -- the
+ * maint section when a check ran or a violation was recorded, one pump record when a top-off ran. */
+__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, size_t N, double *__restrict__ f64,
+                                                             int32_t *__restrict__ i32) {
+  const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
+  const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
+  npb_maint_t m;
+  NPD_LOAD(MAINT, npb_maint_t, m, 0);
+  double oil_level[NPB_NUM_PUMPS];
+#pragma unroll
+  for (int k = 0; k < NPB_NUM_PUMPS; k++) oil_level[k] = NPD_F64_COL(PUMP, npb_pump_t, oil_level, k);
+  int dirty = 0;
+  const int pick = npd_maint_pick_due(&m, &P, t, &dirty);
+  if (pick >= 0) {
+    npb_pump_t pm;
+    NPD_LOAD(PUMP, npb_pump_t, pm, pick);
+    npd_oil_top_off(&pm, P.maint_top_off_target);
+    NPD_STORE(PUMP, npb_pump_t, pm, pick);
+#pragma unroll
+    for (int k = 0; k < NPB_NUM_PUMPS; k++) if (k == pick) oil_level[k] = pm.oil_level;
+  }
+  npd_maint_scan(&m, &P, t, oil_level, &dirty);
+  if (dirty) NPD_STORE(MAINT, npb_maint_t, m, 0);
 }
 
 /* calibration aid for the HBM traffic counters: reads every state column and writes it back unchanged,
@@ -467,6 +496,10 @@ extern "C" void npb_launch_step(const npb_params_t *P, int n_plants, size_t npad
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
   hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, f64, i32, action, magnitude, setpoint,
                      noise_z, cw_temp, obs, reward, done, trip_flags, info);
+}
+extern "C" void npb_launch_maint(const npb_params_t *P, size_t npad, double *f64, int32_t *i32, hipStream_t stream) {
+  dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
+  hipLaunchKernelGGL(npb_maint_kernel, grid, block, 0, stream, *P, npad, f64, i32);
 }
 extern "C" void npb_launch_observe(int mode, int n_plants, size_t npad, const double *f64, const int32_t *i32, double *obs,
                                    hipStream_t stream) {

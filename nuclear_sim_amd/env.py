@@ -104,7 +104,7 @@ class BatchedPlantEnv:
 
     def __init__(self, n_envs: int, dt: float = 1.0, heat_source: str = "constant", noise_enabled: bool = False,
                  noise_std_percent: float = 0.1, noise_seeds: Optional[Sequence[int]] = None,
-                 mode: str = "full", device: int = 0, params: Optional[dict] = None):
+                 mode: str = "full", device: int = 0, params: Optional[dict] = None, maintenance: bool = False):
         if not torch.cuda.is_available():
             raise _lib.NpbError("BatchedPlantEnv needs a HIP device (torch.cuda.is_available() is False); "
                                 "there is no CPU fallback")
@@ -117,6 +117,9 @@ class BatchedPlantEnv:
         p.hs_noise_enabled = int(bool(noise_enabled))
         p.hs_noise_std_percent = float(noise_std_percent)
         p.mode = {"full": _lib.MODE_FULL, "primary_sg": _lib.MODE_PRIMARY_SG}[mode]
+        # automatic oil_top_off maintenance after every step, as the data-gen runner's simulator has it
+        # (maintenance_scenario_runner.py:210-244); thresholds/cadence via params["maint_*"]
+        p.maint_enabled = int(bool(maintenance))
         for k, v in (params or {}).items():
             setattr(p, k, v)
         self.params = p

@@ -66,7 +66,7 @@ class Params:
             return float(self._dview()[self._names.index(k)])
         if k == "dt":
             return float(self._dview()[len(self._names)])
-        ints = ["heat_source", "hs_noise_enabled", "mode"]
+        ints = ["heat_source", "hs_noise_enabled", "mode", "maint_enabled"]
         if k in ints:
             return int(self._iview()[ints.index(k)])
         raise AttributeError(k)
@@ -78,8 +78,8 @@ class Params:
             self._dview()[self._names.index(k)] = v
         elif k == "dt":
             self._dview()[len(self._names)] = v
-        elif k in ("heat_source", "hs_noise_enabled", "mode"):
-            self._iview()[["heat_source", "hs_noise_enabled", "mode"].index(k)] = v
+        elif k in ("heat_source", "hs_noise_enabled", "mode", "maint_enabled"):
+            self._iview()[["heat_source", "hs_noise_enabled", "mode", "maint_enabled"].index(k)] = v
         else:
             raise AttributeError(k)
 
@@ -122,6 +122,14 @@ class OraclePlants:
         i = np.zeros(self.schema.total_i32, dtype=np.int32)
         self.L.npo_get_all(_ptr(self._buf), plant, _ptr(f), _ptr(i))
         return f, i
+
+    def state_all(self):
+        """(f64[n, total_f64], i32[n, total_i32]) of every plant."""
+        F = np.zeros((self.n, self.schema.total_f64))
+        I = np.zeros((self.n, self.schema.total_i32), dtype=np.int32)
+        for pl in range(self.n):
+            self.L.npo_get_all(_ptr(self._buf), pl, _ptr(F[pl]), _ptr(I[pl]))
+        return F, I
 
     def set_state(self, f64, i32, plant=0):
         for s, v in enumerate(f64):

@@ -154,6 +154,13 @@ NPO_FN void npo_cond_init(npb_cond_t *cd) {
   cd->ej_operating_mask = 0; cd->lead_ejector = -1; cd->lag_ejector = -1;
 }
 
+/* AutoMaintenanceSystem.__init__ auto_maintenance.py:60-100, WorkOrderManager / StateManager empty dicts
+ * (-1 = "key absent" for the two last-time dicts) */
+NPO_FN void npo_maint_init(npb_maint_t *m) {
+  memset(m, 0, sizeof(*m));
+  for (int k = 0; k < NPB_NUM_PUMPS; k++) { m->last_violation_time[k] = -1.0; m->last_trigger_time[k] = -1.0; }
+}
+
 NPO_FN void npo_plant_init(npo_plant_t *pl, const npb_params_t *P) {
   (void)P;
   npo_prim_init(&pl->prim);
@@ -165,5 +172,6 @@ NPO_FN void npo_plant_init(npo_plant_t *pl, const npb_params_t *P) {
   npo_ph_init(&pl->ph);
   npo_cond_init(&pl->cond);
   npo_sec_init(&pl->sec);
+  npo_maint_init(&pl->maint);
 }
 #endif

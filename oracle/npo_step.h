@@ -12,6 +12,7 @@
 #include "npo_primary.h"
 #include "npo_sg.h"
 #include "npo_secondary.h"
+#include "npo_maintenance.h"
 
 /* get_observation  sim.py:290-333 */
 NPO_FN void npo_observation(const npo_plant_t *pl, int mode, double *obs) {
@@ -111,6 +112,10 @@ NPO_FN void npo_step(npo_plant_t *pl, const npb_params_t *P, const npo_inputs_t 
   out->info[NPB_INFO_CONDENSER_HEAT_REJECTION] = npo_finite_or(r.total_system_heat_rejection, 0.0);
   out->info[NPB_INFO_TIME] = s->sim_time;
   out->info[NPB_INFO_FEEDWATER_FLOW] = r.feedwater_total_flow;
+
+  /* maintenance_system.update + state_manager.collect_states  sim.py:208-223; nothing they touch
+   * feeds the observation, reward or info built above */
+  if (P->maint_enabled) npo_maintenance_update(pl, P);
 }
 
 #endif

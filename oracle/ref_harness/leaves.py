@@ -56,7 +56,30 @@ def walk(obj, path="", out=None, seen=None, depth=0, skip=SKIP_ATTRS):
     return out
 
 
+class H:
+    """Lookups the maint.* schema columns use (include/npb_fields.h NPB_MAINT_FIELDS): the
+    reference keeps this state in dicts keyed by component id, absent until first use."""
+
+    @staticmethod
+    def open_wo(root, k, what):
+        ms = root.maintenance_system
+        for w in ms.work_order_manager.work_orders.values():
+            if w.component_id == "FWP-%d" % (k + 1) and w.status.name == "SCHEDULED":
+                if what == "order":
+                    return float(int(w.work_order_id.split("-")[1]))
+                return float(getattr(w, what))
+        return 0.0
+
+    @staticmethod
+    def last_violation(root, k):
+        return root.state_manager.threshold_last_violation_times.get("FWP-%d" % (k + 1), {}).get("oil_level", -1.0)
+
+    @staticmethod
+    def last_trigger(root, k):
+        return root.maintenance_system.recent_work_order_triggers.get("FWP-%d:oil_top_off" % (k + 1), -1.0)
+
+
 def resolve(root, path):
     if path.startswith("="):
-        return eval(path[1:], {"root": root})
+        return eval(path[1:], {"root": root, "H": H})
     return eval("root." + path if not path.startswith("[") else "root" + path, {"root": root})

@@ -59,6 +59,13 @@ def scenarios():
     # S6: oil_top_off initial conditions (feedwater_conditions.py:81-96 base values, pump 1 near the 58 % threshold)
     S.append(dict(name="s6_oil_levels", steps=120, noise=True, noise_seed=42, every=4,
                   secondary={"feedwater": {"initial_conditions": {"pump_oil_levels": [59.4, 62.0, 64.0, 90.0]}}}))
+    # M1/M2: the data-gen action-test scenario for oil_top_off exactly as MaintenanceScenarioRunner builds
+    # it (dt = 5 min, state management + AutoMaintenanceSystem on): staggered and simultaneous threshold
+    # crossings, one execution per 15-min check, 4 h
+    S.append(dict(name="m1_oil_top_off_staggered", steps=48, dt=5.0, noise=True, noise_seed=42, every=1,
+                  runner=dict(action="oil_top_off", duration_hours=4.0, feedwater_ic={"pump_oil_levels": [58.3, 58.1, 98.0, 57.0]})))
+    S.append(dict(name="m2_oil_top_off_simultaneous", steps=48, dt=5.0, noise=True, noise_seed=42, every=1,
+                  runner=dict(action="oil_top_off", duration_hours=4.0, feedwater_ic={"pump_oil_levels": [57.0, 57.5, 56.0, 57.2]})))
     return S
 
 

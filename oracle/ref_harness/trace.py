@@ -10,6 +10,10 @@ Scenario dict keys:
   setpoints: callable(step)->percent or None,
   cooling: callable(step)->degC or None,
   pokes: {step: [(python_path, value), ...]} applied to the sim before that step.
+  runner: {"action": name, "duration_hours": h, "feedwater_ic": {...}} -> build the simulator the
+          way data_gen's MaintenanceScenarioRunner does (state management + AutoMaintenanceSystem
+          on, ComprehensiveComposer action-test config, maintenance_scenario_runner.py:210-244)
+          and drive it with the runner's own ramped power profile (:383-411, :651-671).
 """
 import enum
 
@@ -38,7 +42,12 @@ def _val(sim, path):
 def run_reference(sc, columns):
     """columns: SCHEMA.columns(). Returns dict of arrays."""
     refsim.setup()
-    sim = refsim.make_sim(dt=sc.get("dt", 1.0), heat_source=sc.get("heat_source", "constant"),
+    runner = None
+    if sc.get("runner") is not None:
+        runner, sim = refsim.make_runner_sim(**sc["runner"])
+        profile = runner._generate_power_profile(sc["steps"])
+    else:
+      sim = refsim.make_sim(dt=sc.get("dt", 1.0), heat_source=sc.get("heat_source", "constant"),
                           noise=sc.get("noise", False), noise_std_percent=sc.get("noise_std_percent", 0.1),
                           noise_seed=sc.get("noise_seed", 42), secondary=sc.get("secondary"))
     from systems.primary import ControlAction
@@ -70,6 +79,10 @@ def run_reference(sc, columns):
             a = actions(t) if callable(actions) else actions.get(t)
             if a is not None:
                 act[t], mag[t] = a
+        if runner is not None:
+            with refsim.quiet():
+                runner._set_target_power(profile[t])
+            sp[t] = sim.primary_physics.heat_source.power_setpoint_percent
         if sc.get("setpoints") is not None:
             v = sc["setpoints"](t)
             if v is not None:

@@ -17,6 +17,7 @@ def _env(g=None, n=1, **kw):
         kw.setdefault("heat_source", m.get("heat_source", "constant"))
         kw.setdefault("noise_enabled", bool(m.get("noise")))
         kw.setdefault("noise_std_percent", m.get("noise_std_percent", 0.1))
+        kw.setdefault("maintenance", bool(m.get("runner")))
     return BatchedPlantEnv(n, **kw)
 
 
@@ -121,6 +122,42 @@ def test_hip_matches_oracle_on_random_batch(oracle_lib, heat_source, mode):
                 assert int(i[slot, pl]) == int(oi[slot]), (label, pl)
             else:
                 assert abs(f[slot, pl] - of[slot]) <= RTOL * abs(of[slot]) + ATOL_SMALL, (label, pl, f[slot, pl], of[slot])
+
+
+def test_hip_maintenance_matches_oracle_on_random_batch(oracle_lib):
+    """Automatic oil_top_off maintenance on a ragged batch: oil levels scattered around the
+    58 % threshold, shortened cooldowns so that orders re-trigger, every maint.* and pump.* column
+    compared with the oracle after every step; plus the counting identities of the rule."""
+    n, T = 333, 90
+    rng = np.random.default_rng(99)
+    mp = {"maint_oil_level_cooldown_hours": 1.0, "maint_work_order_cooldown": 24.0, "maint_start_delay_hours": 0.1,
+          "maint_top_off_target": 58.5}   # top off just above the threshold so pumps cross it again within the run
+    env = _env(n=n, dt=5.0, noise_enabled=True, maintenance=True, params=mp)
+    P = oracle_lib.Params(); P.dt = 5.0; P.hs_noise_enabled = 1; P.maint_enabled = 1
+    for k, v in mp.items():
+        setattr(P, k, v)
+    ora = oracle_lib.OraclePlants(n, P)
+    for k in range(4):
+        v = rng.uniform(57.0, 59.5, n)
+        env.set_field("pump.oil_level", v, instance=k); ora.set("pump.oil_level", v, instance=k)
+    z = rng.standard_normal((T, n))
+    cols = [c for c in env_cols() if c[2].startswith(("maint", "pump"))]
+    for t in range(T):
+        ora.step(setpoint=np.full(n, 90.0), noise_z=z[t])
+        env.step(power_setpoint=np.full(n, 90.0), noise_z=z[t])
+        f, i = _host_state(env)
+        of, oi = ora.state_all()
+        for kind, slot, label, _p in cols:
+            if kind == "i32":
+                assert np.array_equal(i[slot, :n], oi[:, slot]), (label, t)
+            else:
+                np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg="%s step %d" % (label, t))
+    created = env.get_field("maint.work_orders_created").cpu().numpy()
+    done_ = env.get_field("maint.maintenance_actions_performed").cpu().numpy()
+    open_ = sum((env.get_field("maint.wo_order", k=k).cpu().numpy() > 0).astype(np.int64) for k in range(4))
+    assert created.max() > 4, "cooldowns were shortened so that pumps re-trigger"
+    assert np.array_equal(created, done_ + open_)          # every order is either executed or still open
+    assert done_.max() <= (T * 5.0) / 15.0 + 1             # at most one execution per 15-min check
 
 
 def env_cols():

@@ -13,6 +13,7 @@ def _configure(npo, g):
     P.heat_source = 1 if m.get("heat_source") == "reactor" else 0
     P.hs_noise_enabled = 1 if m.get("noise") else 0
     P.hs_noise_std_percent = m.get("noise_std_percent", 0.1)
+    P.maint_enabled = 1 if m.get("runner") else 0  # fixtures made through the data-gen runner have auto-maintenance on
     return P
 
 
