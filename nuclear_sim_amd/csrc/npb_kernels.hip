@@ -20,6 +20,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "npd_common.h"
+/* diagnostic build only (-DNPB_STAMPS, tools/phase_stamps.py): lane 0 of every wave records s_memtime
+ * at phase boundaries so the kernel's time can be attributed to phases on the GPU */
+#ifdef NPB_STAMPS
+__device__ unsigned long long *npb_stamp_buf;
+#define NPD_STAMP(k) do { if (threadIdx.x == 0 && npb_stamp_buf) npb_stamp_buf[(size_t)blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" __attribute__((visibility("default"))) int npb_debug_set_stamp_buffer(unsigned long long *dev) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(npb_stamp_buf), &dev, sizeof(dev));
+}
+#define NPD_WAIT_ACC_STORE() do { if (threadIdx.x == 0 && npb_stamp_buf) npb_stamp_buf[(size_t)blockIdx.x * 32 + 23] = npd_wait_acc_s; } while (0)
+#else
+#define NPD_STAMP(k)
+#define NPD_WAIT_ACC_STORE()
+#endif
+#include "npd_stage.h"
 #include "npd_primary.h"
 #include "npd_sg.h"
 #include "npd_feedwater.h"
@@ -30,7 +44,6 @@
 #include "npd_init.h"
 #include "npb_kernels.h"
 
-#define NPB_WAVE 64
 /* diagnostic builds only (-DNPB_ABLATE=mask): skip phases to attribute kernel time. 1 FW, 2 SG, 4 turbine, 8 condenser */
 #ifndef NPB_ABLATE
 #define NPB_ABLATE 0
@@ -80,15 +93,17 @@ __device__ __forceinline__ void npd_store_rows(const double *row, double *__rest
   const int lane = threadIdx.x;
 #pragma unroll
   for (int j = 0; j < W; j++) lds[lane * NPB_OBS_PAD + j] = row[j];
-  __syncthreads();
+  NPD_LDS_DRAIN(); /* the block is one wave: LDS ordering inside a wave needs no barrier (and no vmcnt drain) */
 #pragma unroll
   for (int k = 0; k < W; k++) {
     int idx = k * NPB_WAVE + lane;
     int r = idx / W, c = idx % W;
     if (block_base + r < n_valid) out[block_base * W + idx] = lds[r * NPB_OBS_PAD + c];
   }
-  __syncthreads();
+  NPD_LDS_DRAIN();
 }
+
+__device__ __forceinline__ double npd_sel3(int i, double a0, double a1, double a2) { return (i == 0) ? a0 : ((i == 1) ? a1 : a2); }
 
 /* get_observation  sim.py:290-333 (primary part) */
 __device__ __forceinline__ void npd_obs_primary(const npb_prim_t &s, double *obs) {
@@ -112,18 +127,26 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,
     double *__restrict__ reward_out, uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out,
     double *__restrict__ info_out) {
-  __shared__ double lds[NPB_WAVE * NPB_OBS_PAD];
+  /* staging region of the LDS-DMA pipeline (npd_stage.h); the obs / info transposes at the very end reuse it */
+  __shared__ __attribute__((aligned(16))) double lds[NPB_STAGE_SLOTS * NPB_WAVE];
+  static_assert(NPB_STAGE_SLOTS >= NPB_OBS_PAD, "the transposes alias the staging region");
   const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
   const size_t p = block_base + threadIdx.x; /* always < N (arena is padded to a multiple of 64) */
   const bool live = p < (size_t)n_plants;
   const double dt = P.dt;
+  const bool full = P.mode == NPB_MODE_FULL;
+  npd_stage_t st;
+  st.lds = lds; st.f64 = f64; st.i32 = i32; st.N = N; st.block_base = block_base;
 
+  /* per-step inputs first (plain loads), then the first staged group: primary + secondary-level scalars */
   npd_inputs_t in;
   in.action = (live && action) ? action[p] : 8;
   in.magnitude = (live && magnitude) ? magnitude[p] : 1.0;
   in.power_setpoint = (live && setpoint) ? setpoint[p] : NAN;
   in.noise_z = (live && noise_z) ? noise_z[p] : 0.0;
   in.cooling_water_temp = (live && cw_temp) ? cw_temp[p] : NAN;
+  NPD_DMA(PRIM, 0, NPD_LS_PRIM);
+  NPD_DMA(SEC, 0, NPD_LS_SEC);
 
   double obs[NPB_OBS_DIM];
   double info[NPB_INFO_DIM];
@@ -131,10 +154,30 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   int scram_fired, nan_reset, scram_status;
   npd_coupling_t c;
 
+  NPD_STAMP(0);
+  NPD_WAIT_ACC_INIT();
+  npb_prim_t s;
+  double prev_feedwater_temp, operating_hours;
+  double prev_levels[NPB_NUM_SG], prev_flows[NPB_NUM_SG], prev_quals[NPB_NUM_SG];
+  int has_prev;
+  NPD_DMA_WAIT();
+  NPD_CONSUME(PRIM, npb_prim_t, s, NPD_LS_PRIM);
+  cooling_water_temperature = NPD_STAGED_F64(SEC, npb_sec_t, cooling_water_temperature, 0, NPD_LS_SEC);
+  prev_feedwater_temp = NPD_STAGED_F64(SEC, npb_sec_t, previous_feedwater_temp, 0, NPD_LS_SEC);
+  operating_hours = NPD_STAGED_F64(SEC, npb_sec_t, operating_hours, 0, NPD_LS_SEC);
+  has_prev = NPD_STAGED_I32(SEC, npb_sec_t, has_previous_sg_conditions, NPD_LS_SEC);
+#pragma unroll
+  for (int i = 0; i < NPB_NUM_SG; i++) {
+    prev_levels[i] = NPD_STAGED_F64(SEC, npb_sec_t, prev_sg_levels, i, NPD_LS_SEC);
+    prev_flows[i] = NPD_STAGED_F64(SEC, npb_sec_t, prev_sg_steam_flows, i, NPD_LS_SEC);
+    prev_quals[i] = NPD_STAGED_F64(SEC, npb_sec_t, prev_sg_qualities, i, NPD_LS_SEC);
+  }
+  NPD_LDS_DRAIN();
+  if (full) { NPD_DMA(FW, 0, NPD_LS_FW); NPD_DMA(PUMP, 0, NPD_LS_PUMP0); }
+  else NPD_DMA(SG, 0, 0);
+
   /* ================= phase 0: primary side + coupling (sim.py:141-161) ================= */
   {
-    npb_prim_t s;
-    NPD_LOAD(PRIM, npb_prim_t, s, 0);
     if (!isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
     scram_fired = npd_primary_update(&s, &P, &in, &nan_reset);
     npd_primary_to_secondary(&s, &c);
@@ -152,46 +195,43 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     info[NPB_INFO_THERMAL_POWER] = s.thermal_power_mw;
     info[NPB_INFO_REACTIVITY_PCM] = s.total_reactivity_pcm;
     info[NPB_INFO_TIME] = s.sim_time;
-    NPD_STORE(PRIM, npb_prim_t, s, 0);
   }
 
   /* ================= secondary prelude (secondary/__init__.py:371-453) ================= */
-  cooling_water_temperature = NPD_F64_COL(SEC, npb_sec_t, cooling_water_temperature, 0);
   if (!isnan(in.cooling_water_temp)) cooling_water_temperature = in.cooling_water_temp; /* sim.py:138-139 */
   double actual_feedwater_temp;
   {
-    double prev = NPD_F64_COL(SEC, npb_sec_t, previous_feedwater_temp, 0);
     double estimated_feedwater_temp = 40.0 + 187.0;
     double alpha = 0.1;
-    actual_feedwater_temp = (alpha * estimated_feedwater_temp + (1 - alpha) * prev);
-    NPD_F64_COL(SEC, npb_sec_t, previous_feedwater_temp, 0) = actual_feedwater_temp;
+    actual_feedwater_temp = (alpha * estimated_feedwater_temp + (1 - alpha) * prev_feedwater_temp);
   }
   double primary_thermal_power = 0.0;
 #pragma unroll
   for (int i = 0; i < NPB_NUM_SG; i++) primary_thermal_power += c.thermal_power[i];
   double load_demand_fraction = npd_pymin(1.0, primary_thermal_power / 3000.0);
   load_demand_fraction = npd_pymax(load_demand_fraction, 0.2);
-  const int has_prev = NPD_I32_COL(SEC, npb_sec_t, has_previous_sg_conditions, 0);
+  if (!has_prev) { /* :447-453 hard-coded first-step values, not the SG initial conditions */
+#pragma unroll
+    for (int i = 0; i < NPB_NUM_SG; i++) { prev_levels[i] = 12.5; prev_flows[i] = 555.0 * load_demand_fraction; prev_quals[i] = 0.99; }
+  }
 
   double fw_total_flow = 0.0, fw_total_power = 0.0;
   int fw_available = 1;
   uint32_t trip_flags = 0;
+  npb_sg_t g;
 
-  if (P.mode == NPB_MODE_FULL && !(NPB_ABLATE & 1)) {
+  NPD_STAMP(1);
+  if (full) {
     /* ================= phase 1: feedwater system (physics.py:662-863) ================= */
-    double prev_levels[NPB_NUM_SG], prev_flows[NPB_NUM_SG], prev_quals[NPB_NUM_SG];
-#pragma unroll
-    for (int i = 0; i < NPB_NUM_SG; i++) {
-      if (has_prev) { /* the stored copy of the previous SG conditions (:530-535), not the SG objects */
-        prev_levels[i] = NPD_F64_COLK(SEC, npb_sec_t, prev_sg_levels, 0, i);
-        prev_flows[i] = NPD_F64_COLK(SEC, npb_sec_t, prev_sg_steam_flows, 0, i);
-        prev_quals[i] = NPD_F64_COLK(SEC, npb_sec_t, prev_sg_qualities, 0, i);
-      } else { /* :447-453 hard-coded first-step values, not the SG initial conditions */
-        prev_levels[i] = 12.5; prev_flows[i] = 555.0 * load_demand_fraction; prev_quals[i] = 0.99;
-      }
-    }
     npb_fw_t fw;
-    NPD_LOAD(FW, npb_fw_t, fw, 0);
+    npb_pump_t pm;
+    /* boundary: fw + pump 0 are staged; store the primary section, stage pump 1 */
+    NPD_DMA_WAIT();
+    NPD_STORE(PRIM, npb_prim_t, s, 0);
+    NPD_CONSUME(FW, npb_fw_t, fw, NPD_LS_FW);
+    NPD_CONSUME(PUMP, npb_pump_t, pm, NPD_LS_PUMP0);
+    NPD_LDS_DRAIN();
+    NPD_DMA(PUMP, 1, 0);
     double total_flow_demand = npd_fw_level_control(&fw, prev_levels, prev_flows, prev_quals, dt);
     int n_prev_running = 0;
 #pragma unroll
@@ -204,27 +244,41 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     acc.total_flow = acc.total_power = acc.flow_sum = 0.0;
     acc.total_cavitation_risk = acc.total_wear_level = acc.total_vibration = 0.0;
     acc.running_count = acc.running_mask = acc.trips = 0; acc.trip_mask = 0;
-    /* double-buffered: pump i+1's columns are requested before pump i is computed, so their HBM
-     * latency hides behind ~4k instructions of arithmetic (one wave per SIMD has no other cover) */
-    npb_pump_t pm;
-    NPD_LOAD(PUMP, npb_pump_t, pm, 0);
 #pragma unroll 1
     for (int i = 0; i < NPB_NUM_PUMPS; i++) {
-      npb_pump_t nxt;
-      if (i + 1 < NPB_NUM_PUMPS) NPD_LOAD(PUMP, npb_pump_t, nxt, i + 1);
-      else nxt = pm;
-      npd_fw_pump_step(&pm, &fw, &acc, i, n_prev_running, flow_per_pump, &sc, dt);
+      NPD_STAMP(2 + i);
+      if (!(NPB_ABLATE & 1)) npd_fw_pump_step(&pm, &fw, &acc, i, n_prev_running, flow_per_pump, &sc, dt);
+      /* boundary: pump i -> HBM, pump i+1 (staged during this pump's arithmetic) -> the same registers,
+       * then stage pump i+2, or SG 0 once the last pump is on its way */
+      NPD_DMA_WAIT();
       NPD_STORE(PUMP, npb_pump_t, pm, i);
-      pm = nxt;
+      if (i + 1 < NPB_NUM_PUMPS) NPD_CONSUME(PUMP, npb_pump_t, pm, 0);
+      NPD_LDS_DRAIN();
+      if (i + 2 < NPB_NUM_PUMPS) NPD_DMA(PUMP, i + 2, 0);
+      else if (i + 2 == NPB_NUM_PUMPS) NPD_DMA(SG, 0, 0);
     }
+    NPD_STAMP(6);
     npd_fw_result_t fwr;
     npd_fw_finish(&fw, &acc, prev_levels, dt, &fwr);
-    NPD_STORE(FW, npb_fw_t, fw, 0);
     fw_total_flow = fwr.total_flow_rate; fw_total_power = fwr.total_power_consumption;
     fw_available = fwr.system_availability;
     trip_flags |= (fwr.pump_trip_mask << 8) | (fw.system_trip_active ? NPB_TRIP_FW_SYSTEM : 0);
+    /* boundary: SG 0 -> registers (its DMA ran during pump 3), fw -> HBM, stage SG 1 */
+    NPD_DMA_WAIT();
+    NPD_STORE(FW, npb_fw_t, fw, 0);
+    NPD_CONSUME(SG, npb_sg_t, g, 0);
+    NPD_LDS_DRAIN();
+    NPD_DMA(SG, 1, 0);
+  } else {
+    /* config-2 mode: no feedwater system; boundary straight to SG 0 */
+    NPD_DMA_WAIT();
+    NPD_STORE(PRIM, npb_prim_t, s, 0);
+    NPD_CONSUME(SG, npb_sg_t, g, 0);
+    NPD_LDS_DRAIN();
+    NPD_DMA(SG, 1, 0);
   }
 
+  NPD_STAMP(7);
   /* ================= phase 2: steam generators (enhanced_physics.py:433-547) ================= */
   double sg_total_thermal = 0.0, sg_total_steam = 0.0, sg_ap = 0.0, sg_at = 0.0, sg_aq = 0.0;
   double sg_pressures[NPB_NUM_SG];
@@ -234,29 +288,39 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     double total_primary_flow = 0.0;
 #pragma unroll
     for (int i = 0; i < NPB_NUM_SG; i++) total_primary_flow += c.flow[i];
-    npb_sg_t g;
-    NPD_LOAD(SG, npb_sg_t, g, 0);
 #pragma unroll 1
-    for (int i = 0; i < ((NPB_ABLATE & 2) ? 0 : NPB_NUM_SG); i++) {
-      npb_sg_t gn;
-      if (i + 1 < NPB_NUM_SG) NPD_LOAD(SG, npb_sg_t, gn, i + 1); /* double-buffered like the pumps */
-      else gn = g;
-      double demand = (total_primary_flow > 0) ? actual_total_steam_flow * (c.flow[i] / total_primary_flow)
+    for (int i = 0; i < NPB_NUM_SG; i++) {
+      /* the loop is rolled (code size), so per-SG values are picked by selects: a dynamically indexed
+       * private array would live in scratch, and every scratch load drains vmcnt, i.e. waits for the
+       * whole staged prefetch and the previous stores */
+      const double c_flow = npd_sel3(i, c.flow[0], c.flow[1], c.flow[2]);
+      const double c_inlet = npd_sel3(i, c.inlet_temp[0], c.inlet_temp[1], c.inlet_temp[2]);
+      const double c_outlet = npd_sel3(i, c.outlet_temp[0], c.outlet_temp[1], c.outlet_temp[2]);
+      double demand = (total_primary_flow > 0) ? actual_total_steam_flow * (c_flow / total_primary_flow)
                                                : actual_total_steam_flow / NPB_NUM_SG;
       /* full mode: equal split of the actual feedwater flow (:500-506 key mismatch); config-2 mode:
        * "perfect mass balance" fallback (enhanced_physics.py:495-497) */
-      double fwflow = (P.mode == NPB_MODE_FULL) ? fw_total_flow / NPB_NUM_SG : demand;
+      double fwflow = full ? fw_total_flow / NPB_NUM_SG : demand;
+      NPD_STAMP(8 + i);
       npd_sg_result_t r;
-      npd_sg_update(&g, &P, c.inlet_temp[i], c.outlet_temp[i], c.flow[i], demand, fwflow, actual_feedwater_temp, dt * 60, &r);
-      NPD_STORE(SG, npb_sg_t, g, i);
+      r.heat_transfer_rate = 0.0; r.steam_flow_rate = 0.0; r.thermal_efficiency = 0.0;
+      if (!(NPB_ABLATE & 2)) npd_sg_update(&g, &P, c_inlet, c_outlet, c_flow, demand, fwflow, actual_feedwater_temp, dt * 60, &r);
       sg_total_thermal += r.heat_transfer_rate; sg_total_steam += r.steam_flow_rate;
       sg_ap += g.secondary_pressure; sg_at += g.secondary_temperature; sg_aq += g.steam_quality;
-      sg_pressures[i] = g.secondary_pressure;
+      if (i == 0) sg_pressures[0] = g.secondary_pressure;
+      else if (i == 1) sg_pressures[1] = g.secondary_pressure;
+      else sg_pressures[2] = g.secondary_pressure;
       if (r.thermal_efficiency > 0.1) sg_effective++;
+      /* boundary: SG i -> HBM, SG i+1 -> the same registers, stage SG i+2 / the turbine scalars */
+      NPD_DMA_WAIT();
+      NPD_STORE(SG, npb_sg_t, g, i);
       NPD_F64_COLK(SEC, npb_sec_t, prev_sg_levels, 0, i) = g.water_level;
       NPD_F64_COLK(SEC, npb_sec_t, prev_sg_steam_flows, 0, i) = r.steam_flow_rate;
       NPD_F64_COLK(SEC, npb_sec_t, prev_sg_qualities, 0, i) = g.steam_quality;
-      g = gn;
+      if (i + 1 < NPB_NUM_SG) NPD_CONSUME(SG, npb_sg_t, g, 0);
+      NPD_LDS_DRAIN();
+      if (i + 2 < NPB_NUM_SG) NPD_DMA(SG, i + 2, 0);
+      else if (i + 2 == NPB_NUM_SG && full) NPD_DMA(TURB, 0, 0);
     }
   }
   const double sg_avg_pressure = sg_ap / NPB_NUM_SG, sg_avg_temperature = sg_at / NPB_NUM_SG, sg_avg_quality = sg_aq / NPB_NUM_SG;
@@ -264,16 +328,20 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
 
   double electrical_power = 0.0, thermal_efficiency = 0.0, condenser_pressure = 0.007;
   double total_system_heat_rejection = 0.0;
-  if (P.mode == NPB_MODE_FULL) {
+  if (full) {
+    NPD_STAMP(11);
     /* ================= phase 3: turbine (dt in hours, load demand in PERCENT, :564-569) ========== */
     npd_turbine_result_t tr;
-    {
-      npb_turb_t t;
-      NPD_LOAD(TURB, npb_turb_t, t, 0);
-      if (!(NPB_ABLATE & 4)) npd_turbine_update(&t, f64, N, p, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
-                         load_demand, 0.007, dt / 60.0, &tr);
-      NPD_STORE(TURB, npb_turb_t, t, 0);
-    }
+    npb_turb_t t;
+    /* boundary: turbine scalars (staged during SG 2) -> registers; stage the 70 stage-array columns, which
+     * land while the lubrication step and stage passes A / B run */
+    NPD_DMA_WAIT();
+    NPD_CONSUME(TURB, npb_turb_t, t, 0);
+    NPD_LDS_DRAIN();
+    NPD_DMA(TSTG, 0, 0);
+    if (!(NPB_ABLATE & 4)) npd_turbine_update(&t, f64, st, N, p, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
+                       load_demand, 0.007, dt / 60.0, &tr);
+    NPD_STAMP(18);
     /* ================= phase 4: condenser (:591-621) ================= */
     double lp_exhaust_quality = 0.90;
     {
@@ -285,25 +353,30 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       }
     }
     npd_condenser_result_t cr;
+    npb_chem_t ch0; npb_ph_t ph;
     {
       npb_cond_t cd; npb_chem_t ch;
-      NPD_LOAD(COND, npb_cond_t, cd, 0);
-      NPD_LOAD(CHEM, npb_chem_t, ch, 1);
+      /* boundary: the condenser group was staged by npd_turbine_update right after the stage pass */
+      NPD_DMA_WAIT();
+      NPD_STORE(TURB, npb_turb_t, t, 0);
+      NPD_CONSUME(COND, npb_cond_t, cd, NPD_LS_COND);
+      NPD_CONSUME(CHEM, npb_chem_t, ch, NPD_LS_CHEM1);
+      NPD_LDS_DRAIN();
       if (!(NPB_ABLATE & 8)) npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
                            cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr);
       NPD_STORE(COND, npb_cond_t, cd, 0);
       NPD_STORE(CHEM, npb_chem_t, ch, 1);
+      NPD_CONSUME(CHEM, npb_chem_t, ch0, NPD_LS_CHEM0);
+      NPD_CONSUME(PH, npb_ph_t, ph, NPD_LS_PH);
+      NPD_LDS_DRAIN();
     }
     condenser_pressure = cr.condenser_pressure;
+    NPD_STAMP(19);
     /* ================= chemistry sidecar: shared WaterChemistry + pH controller (:634-665) ========= */
-    {
-      npb_chem_t ch; npb_ph_t ph;
-      NPD_LOAD(CHEM, npb_chem_t, ch, 0);
-      NPD_LOAD(PH, npb_ph_t, ph, 0);
-      npd_chemistry_sidecar(&ch, &ph, dt);
-      NPD_STORE(CHEM, npb_chem_t, ch, 0);
-      NPD_STORE(PH, npb_ph_t, ph, 0);
-    }
+    npd_chemistry_sidecar(&ch0, &ph, dt);
+    NPD_STORE(CHEM, npb_chem_t, ch0, 0);
+    NPD_STORE(PH, npb_ph_t, ph, 0);
+    NPD_STAMP(20);
     /* ================= electrical-power gates (:750-932) ================= */
     double turbine_electrical_power = tr.electrical_power_net;
     total_system_heat_rejection = (primary_thermal_power - turbine_electrical_power) * 1e6;
@@ -322,6 +395,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   }
 
   /* ================= secondary-level state write-back ================= */
+  NPD_F64_COL(SEC, npb_sec_t, previous_feedwater_temp, 0) = actual_feedwater_temp;
   NPD_F64_COL(SEC, npb_sec_t, electrical_power_output, 0) = electrical_power;
   NPD_F64_COL(SEC, npb_sec_t, thermal_efficiency, 0) = thermal_efficiency;
   NPD_F64_COL(SEC, npb_sec_t, total_steam_flow, 0) = sg_total_steam;
@@ -329,7 +403,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   NPD_F64_COL(SEC, npb_sec_t, total_feedwater_flow, 0) = fw_total_flow;
   NPD_F64_COL(SEC, npb_sec_t, load_demand, 0) = load_demand;
   NPD_F64_COL(SEC, npb_sec_t, cooling_water_temperature, 0) = cooling_water_temperature;
-  NPD_F64_COL(SEC, npb_sec_t, operating_hours, 0) += dt / 3600.0;
+  NPD_F64_COL(SEC, npb_sec_t, operating_hours, 0) = operating_hours + dt / 3600.0;
   NPD_F64_COL(SEC, npb_sec_t, sg_avg_pressure, 0) = sg_avg_pressure;
   NPD_F64_COL(SEC, npb_sec_t, sg_avg_temperature, 0) = sg_avg_temperature;
   NPD_F64_COL(SEC, npb_sec_t, sg_avg_quality, 0) = sg_avg_quality;
@@ -376,6 +450,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     if (done_out) done_out[p] = (uint8_t)scram_fired;
     if (trip_out) trip_out[p] = trip_flags;
   }
+  NPD_STAMP(21);
   if (obs_out) npd_store_rows<NPB_OBS_DIM>(obs, obs_out, lds, block_base, (size_t)n_plants);
   if (info_out) {
     /* info  sim.py:199-250 with the non-finite substitutions of :231-240 */
@@ -388,6 +463,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     info[NPB_INFO_FEEDWATER_FLOW] = fw_total_flow;
     npd_store_rows<NPB_INFO_DIM>(info, info_out, lds, block_base, (size_t)n_plants);
   }
+  NPD_STAMP(22);
+  NPD_WAIT_ACC_STORE();
 }
 
 /* get_observation() without stepping (after reset / set_field): sim.py:290-333 */

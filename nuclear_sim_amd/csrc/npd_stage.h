@@ -1,0 +1,133 @@
+/*
+ * npd_stage.h -- LDS staging pipeline of the fused step kernel (product code).
+ *
+ * Why: at BASELINE size (65 536 plants = 1 024 waves) every SIMD holds exactly one wave, so nothing
+ * covers a wave's HBM latency but the wave itself, and all waves run the same phase at the same time
+ * (measured with tools/phase_stamps.py: every "cold" section load cost 7-9 us, 41 % of the kernel was
+ * SQ_WAIT_ANY).  A plant's state does not fit in registers, so the next section cannot be prefetched
+ * into VGPRs either.  Instead each section is copied global -> LDS by the LDS-DMA path
+ * (global_load_lds_dwordx4 / _dword: no VGPR destination, asynchronous) one phase ahead:
+ *
+ *   boundary between phase j and j+1:
+ *     s_waitcnt vmcnt(0)         DMA(j+1) was issued a whole compute phase ago -> normally free
+ *     ds_read   section j+1      LDS -> registers (conflict-free: lane l reads word l of each column)
+ *     s_waitcnt lgkmcnt(0)
+ *     store     section j        deferred to here so that the NEXT boundary's vmcnt(0) does not have
+ *                                to wait for freshly issued stores
+ *     issue DMA(j+2)             into the same LDS region, lands while phase j+1 computes
+ *
+ * One staging region of NPB_STAGE_SLOTS column slots (512 B = 64 lanes x 8 B) per wave; an int32 column
+ * takes half a slot.  36 KB per wave, 4 waves per CU = 144 KB of the CU's 160 KB.
+ *
+ * hipcc (ROCm 7.2) does not insert the vmcnt wait between an LDS-DMA and a later ds_read of the same
+ * bytes, so the waits here are explicit and carry a "memory" clobber so nothing moves across them.
+ */
+#ifndef NPD_STAGE_H
+#define NPD_STAGE_H
+#include "npd_common.h"
+
+#define NPB_STAGE_SLOTS 72
+#define NPB_WAVE 64
+
+typedef __attribute__((address_space(1))) const void npd_gptr_t;
+typedef __attribute__((address_space(3))) void npd_lptr_t;
+
+typedef struct npd_stage_t {
+  double *lds;            /* staging region base (wave-uniform) */
+  const double *f64;      /* SoA arena */
+  const int32_t *i32;
+  size_t N;               /* column pitch */
+  size_t block_base;      /* first plant of this wave */
+} npd_stage_t;
+
+#ifdef NPB_STAMPS
+/* diagnostic build: ticks this wave spent inside the staging pipeline's waits (lane 0 keeps the sum in LDS) */
+__shared__ unsigned long long npd_wait_acc_s;
+#define NPD_WAIT_ACC_INIT() do { if (threadIdx.x == 0) npd_wait_acc_s = 0; } while (0)
+#define NPD_DMA_WAIT() do { unsigned long long w0__ = __builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); \
+                            if (threadIdx.x == 0) npd_wait_acc_s += __builtin_readcyclecounter() - w0__; } while (0)
+#else
+#define NPD_WAIT_ACC_INIT()
+#define NPD_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+#define NPD_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+/* slots a section occupies in the staging region */
+#define NPD_SLOTS(T) (NPB_##T##_NF64 + (NPB_##T##_NI32 + 1) / 2)
+
+/* issue the LDS-DMA of NF fp64 columns starting at arena column fslot and NI int32 columns starting at
+ * islot into staging slot ls: fp64 column c -> slot ls + c; int32 column k -> the k-th 256-B half slot
+ * after the fp64 slots.  One dwordx4 instruction moves two fp64 columns: lanes 0-31 carry column c
+ * (16 B = 2 plants each), lanes 32-63 column c + 1, and the LDS image (base + lane * 16) is the two
+ * columns back to back. */
+template <int NF, int NI>
+__device__ __forceinline__ void npd_dma(const npd_stage_t &st, int fslot, int islot, int ls) {
+  const int lane = threadIdx.x;
+  const double *g = st.f64 + (size_t)(fslot + (lane >> 5)) * st.N + st.block_base + (size_t)(lane & 31) * 2;
+  double *l = st.lds + ls * NPB_WAVE;
+#pragma unroll
+  for (int c = 0; c + 1 < NF; c += 2)
+    __builtin_amdgcn_global_load_lds((npd_gptr_t *)(g + (size_t)c * st.N), (npd_lptr_t *)(l + c * NPB_WAVE), 16, 0, 0);
+  if (NF & 1) { /* odd last column: two dword pieces of 256 B */
+    const uint32_t *g4 = (const uint32_t *)(st.f64 + (size_t)(fslot + NF - 1) * st.N + st.block_base) + lane;
+    uint32_t *l4 = (uint32_t *)(l + (NF - 1) * NPB_WAVE);
+    __builtin_amdgcn_global_load_lds((npd_gptr_t *)g4, (npd_lptr_t *)l4, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((npd_gptr_t *)(g4 + NPB_WAVE), (npd_lptr_t *)(l4 + NPB_WAVE), 4, 0, 0);
+  }
+  if (NI > 0) {
+    const int32_t *gi = st.i32 + (size_t)islot * st.N + st.block_base + lane;
+    int32_t *li = (int32_t *)(l + NF * NPB_WAVE);
+#pragma unroll
+    for (int k = 0; k < NI; k++)
+      __builtin_amdgcn_global_load_lds((npd_gptr_t *)(gi + (size_t)k * st.N), (npd_lptr_t *)(li + k * NPB_WAVE), 4, 0, 0);
+  }
+}
+#define NPD_DMA(T, inst, ls) \
+  npd_dma<NPB_##T##_NF64, NPB_##T##_NI32>(st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
+                                          NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32, ls)
+
+/* staging slot ls -> register struct (all fp64 members first, then the int32 members) */
+template <int NF, int NI, typename S>
+__device__ __forceinline__ void npd_consume(S &s, const double *lds, int ls) {
+  const int lane = threadIdx.x;
+  double *d = reinterpret_cast<double *>(&s);
+#pragma unroll
+  for (int k = 0; k < NF; k++) d[k] = lds[(ls + k) * NPB_WAVE + lane];
+  const int32_t *li = (const int32_t *)(lds + (ls + NF) * NPB_WAVE);
+  int32_t *q = reinterpret_cast<int32_t *>(d + NF);
+#pragma unroll
+  for (int k = 0; k < NI; k++) q[k] = li[k * NPB_WAVE + lane];
+}
+#define NPD_CONSUME(T, stype, s, ls) npd_consume<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, st.lds, ls)
+
+/* single staged members */
+#define NPD_STAGED_F64(T, stype, member, k, ls) st.lds[((ls) + NPB_F64_SLOT(stype, member) + (k)) * NPB_WAVE + threadIdx.x]
+#define NPD_STAGED_I32(T, stype, member, ls) \
+  ((const int32_t *)(st.lds + ((ls) + NPB_##T##_NF64) * NPB_WAVE))[NPB_I32_SLOT(stype, T, member) * NPB_WAVE + threadIdx.x]
+
+/* fixed slot plan (see the kernel): groups that are staged together */
+#define NPD_LS_PRIM 0
+#define NPD_LS_SEC (NPD_LS_PRIM + NPD_SLOTS(PRIM))
+#define NPD_LS_FW 0
+#define NPD_LS_PUMP0 (NPD_LS_FW + NPD_SLOTS(FW))
+#define NPD_LS_COND 0
+#define NPD_LS_CHEM1 (NPD_LS_COND + NPD_SLOTS(COND))
+#define NPD_LS_CHEM0 (NPD_LS_CHEM1 + NPD_SLOTS(CHEM))
+#define NPD_LS_PH (NPD_LS_CHEM0 + NPD_SLOTS(CHEM))
+
+static_assert(NPD_LS_SEC + NPD_SLOTS(SEC) <= NPB_STAGE_SLOTS, "prim + sec must fit the staging region");
+static_assert(NPD_LS_PUMP0 + NPD_SLOTS(PUMP) <= NPB_STAGE_SLOTS, "fw + pump must fit the staging region");
+static_assert(NPD_SLOTS(SG) <= NPB_STAGE_SLOTS && NPD_SLOTS(TURB) <= NPB_STAGE_SLOTS, "sg / turb must fit");
+static_assert(NPD_SLOTS(TSTG) <= NPB_STAGE_SLOTS, "turbine stage arrays must fit the staging region");
+static_assert(NPD_LS_PH + NPD_SLOTS(PH) <= NPB_STAGE_SLOTS, "condenser + chemistry + pH must fit");
+
+/* condenser, its chemistry, the shared chemistry and the pH controller, staged together right after the
+ * turbine stage pass has finished with the stage arrays */
+__device__ __forceinline__ void npd_dma_condenser_group(const npd_stage_t &st) {
+  NPD_DMA(COND, 0, NPD_LS_COND);
+  NPD_DMA(CHEM, 1, NPD_LS_CHEM1);
+  NPD_DMA(CHEM, 0, NPD_LS_CHEM0);
+  NPD_DMA(PH, 0, NPD_LS_PH);
+}
+
+#endif

@@ -168,43 +168,47 @@ typedef struct npd_stagesys_out_t {
   double max_temp_rate, max_thermal_stress; /* MetalTemperatureTracker reductions */
 } npd_stagesys_out_t;
 
-/* per-stage column access: the stage / tracker arrays are streamed from their SoA columns */
-#define NPD_TSTG(member, k) f64[(size_t)(NPB_TSTG_F64_BASE + NPB_F64_SLOT(npb_tstg_t, member) + (k)) * N + p]
+/* per-stage column access: the stage / tracker arrays are read from the LDS staging region (the whole
+ * tstg section is LDS-DMA'd there while the lubrication step and passes A/B run, npd_stage.h) and each
+ * updated value is written straight to its SoA column; every column is read before it is written and
+ * never re-read within a step, so the staged copy does not need the update */
+#define NPD_TSTG_RD(member, k) stg[(NPB_F64_SLOT(npb_tstg_t, member) + (k)) * NPB_WAVE]
+#define NPD_TSTG_WR(member, k, v) f64[(size_t)(NPB_TSTG_F64_BASE + NPB_F64_SLOT(npb_tstg_t, member) + (k)) * N + p] = (v)
 
 /* one stage's share of TurbineStage.update_degradation (stage_system.py:294-339) and of
  * MetalTemperatureTracker.update_temperatures (enhanced_physics.py:73-166, time constant 1 h, ambient 25 C);
  * both only touch stage k's own state, so running them right after stage k's expansion is the
  * reference's result */
-NPD_FN void npd_stage_post(double *__restrict__ f64, size_t N, size_t p, int k, double loading_factor,
+NPD_FN void npd_stage_post(double *__restrict__ f64, const double *stg, size_t N, size_t p, int k, double loading_factor,
                            double outlet_temperature, double dt, npd_stagesys_out_t *out) {
-  NPD_TSTG(stage_efficiency_degradation, k) += 1e-05 * dt;
-  NPD_TSTG(stage_deposit_thickness, k) += 5e-05 * dt;
+  NPD_TSTG_WR(stage_efficiency_degradation, k, NPD_TSTG_RD(stage_efficiency_degradation, k) + 1e-05 * dt);
+  NPD_TSTG_WR(stage_deposit_thickness, k, NPD_TSTG_RD(stage_deposit_thickness, k) + 5e-05 * dt);
   double blade_wear = (1e-06 * dt) * npd_sq(loading_factor);
-  NPD_TSTG(stage_blade_wear_factor, k) = npd_pymax(0.7, NPD_TSTG(stage_blade_wear_factor, k) - blade_wear);
+  NPD_TSTG_WR(stage_blade_wear_factor, k, npd_pymax(0.7, NPD_TSTG_RD(stage_blade_wear_factor, k) - blade_wear));
   const double time_constant = 3600.0 / 3600.0, ambient = 25.0;
   if (k < 8) {
-    double rt = NPD_TSTG(rotor_temperatures, k);
+    double rt = NPD_TSTG_RD(rotor_temperatures, k);
     double tc = ((outlet_temperature - 50.0) - rt) / time_constant * dt;
     double max_rate = 5.0 * dt;
     tc = npd_clip(tc, -max_rate, max_rate);
     rt += tc;
-    NPD_TSTG(rotor_temperatures, k) = rt;
+    NPD_TSTG_WR(rotor_temperatures, k, rt);
     double rate = fabs(tc / dt * 60.0);
     out->max_temp_rate = (k == 0) ? rate : npd_pymax(out->max_temp_rate, rate);
     double stress = (1.2e-05 * (rt - ambient)) * 200000000000.0 * 0.1;
     out->max_thermal_stress = (k == 0) ? stress : npd_pymax(out->max_thermal_stress, stress);
   }
   if (k < 6) {
-    double ct = NPD_TSTG(casing_temperatures, k);
+    double ct = NPD_TSTG_RD(casing_temperatures, k);
     double tc = ((outlet_temperature - 80.0) - ct) / time_constant * dt;
     tc = npd_clip(tc, -3.0 * dt, 3.0 * dt);
-    NPD_TSTG(casing_temperatures, k) = ct + tc;
+    NPD_TSTG_WR(casing_temperatures, k, ct + tc);
   }
   {
-    double bt = NPD_TSTG(blade_temperatures, k);
+    double bt = NPD_TSTG_RD(blade_temperatures, k);
     double tc = ((outlet_temperature - 20.0) - bt) / (time_constant * 0.5) * dt;
     tc = npd_clip(tc, -10.0 * dt, 10.0 * dt);
-    NPD_TSTG(blade_temperatures, k) = bt + tc;
+    NPD_TSTG_WR(blade_temperatures, k, bt + tc);
   }
 }
 
@@ -226,26 +230,27 @@ NPD_FN double npd_stage_requested_outlet(int k, double current_pressure, double 
 
 /* TurbineStageSystem.update_state  stage_system.py:928-1016, reference order, one stage at a time.
  * Exact for every input; used when a lane of the wave leaves the fast path's assumptions. */
-NPD_FN void npd_stage_system_update_seq(double *__restrict__ f64, size_t N, size_t p, double inlet_pressure,
+NPD_FN void npd_stage_system_update_seq(double *__restrict__ f64, const double *stg, size_t N, size_t p, double inlet_pressure,
                                         double inlet_temperature, double inlet_flow, double load_demand,
                                         double pressure_stability_factor, double dt, npd_stagesys_out_t *out) {
   double current_pressure = inlet_pressure, current_temperature = inlet_temperature, current_flow = inlet_flow;
   double total_power = 0.0, total_extraction = 0.0;
+  NPD_DMA_WAIT(); /* the staged stage arrays are read from here on */
 #pragma unroll 1
   for (int k = 0; k < 14; k++) {
     double extraction_demand = (k == 2) ? 25.0 * load_demand : (k == 3) ? 30.0 * load_demand : (k == 4) ? 20.0 * load_demand
                              : (k == 8) ? 15.0 * load_demand : (k == 9) ? 10.0 * load_demand : 0.0;
     double outlet_pressure = npd_stage_requested_outlet(k, current_pressure, inlet_flow);
-    double fouling_factor = 1.0 / (1.0 + NPD_TSTG(stage_deposit_thickness, k) / 0.5);
-    double blade_wear_factor = NPD_TSTG(stage_blade_wear_factor, k);
+    double fouling_factor = 1.0 / (1.0 + NPD_TSTG_RD(stage_deposit_thickness, k) / 0.5);
+    double blade_wear_factor = NPD_TSTG_RD(stage_blade_wear_factor, k);
     double blade_condition_factor = npd_pymin(fouling_factor, blade_wear_factor);
-    double actual_efficiency = npd_pymax(0.7, 0.88 - NPD_TSTG(stage_efficiency_degradation, k));
+    double actual_efficiency = npd_pymax(0.7, 0.88 - NPD_TSTG_RD(stage_efficiency_degradation, k));
     npd_stage_out_t so;
     npd_stage_expansion(k, actual_efficiency, blade_condition_factor, fouling_factor, blade_wear_factor, current_pressure,
                         current_temperature, current_flow, outlet_pressure, extraction_demand, &so);
     total_power += so.power_output; total_extraction += so.extraction_flow;
     if (k == 13) out->lp6_outlet_enthalpy = so.outlet_enthalpy;
-    npd_stage_post(f64, N, p, k, so.loading_factor, so.outlet_temperature, dt, out);
+    npd_stage_post(f64, stg, N, p, k, so.loading_factor, so.outlet_temperature, dt, out);
     current_pressure = so.outlet_pressure; current_temperature = so.outlet_temperature; current_flow = so.outlet_flow;
   }
   out->total_power = total_power * pressure_stability_factor;
@@ -261,10 +266,13 @@ NPD_FN void npd_stage_system_update_seq(double *__restrict__ f64, size_t N, size
  *   pass C  walks the temperature / enthalpy chain with plain arithmetic and streams each stage's
  *           degradation and metal-temperature state.
  * Lanes that would take a rare branch make the whole wave use npd_stage_system_update_seq. */
-NPD_FN void npd_stage_system_update(double *__restrict__ f64, size_t N, size_t p, double inlet_pressure,
+NPD_FN void npd_stage_system_update(double *__restrict__ f64, const double *stg, size_t N, size_t p, double inlet_pressure,
                                     double inlet_temperature, double inlet_flow, double load_demand,
                                     double pressure_stability_factor, double dt, npd_stagesys_out_t *out) {
-  double p_in[14], p_self[14], p_arg[14], flow_in[14], flow_out[14], ext_flow[14], p_ext[14];
+  /* extraction stages 2, 3, 4, 8, 9 -> compact index 0..4 */
+#define NPD_EXT_IDX(k) ((k) == 2 ? 0 : (k) == 3 ? 1 : (k) == 4 ? 2 : (k) == 8 ? 3 : 4)
+#define NPD_IS_EXT(k) ((k) == 2 || (k) == 3 || (k) == 4 || (k) == 8 || (k) == 9)
+  double p_self[14], flow_out[14], p_ext[5], ext_flow[5];
   bool rare = !(inlet_pressure >= 0.001 && inlet_pressure <= 22.0);
   {
     double cur_p = inlet_pressure, cur_flow = inlet_flow;
@@ -281,56 +289,56 @@ NPD_FN void npd_stage_system_update(double *__restrict__ f64, size_t N, size_t p
       if (k == 13) { min_allowed = 0.002; max_allowed = 0.009; }
       else { min_allowed = cur_p * (design_pressure_ratio * 0.7); max_allowed = cur_p * (design_pressure_ratio * 1.3); }
       double self_out = (outlet_pressure < min_allowed) ? min_allowed : ((outlet_pressure > max_allowed) ? max_allowed : outlet_pressure);
+      /* a clamped request makes the stage's own outlet state differ from the one handed to the next stage
+       * (stage_system.py:146-155 vs :915): left to the sequential path */
+      rare = rare || (self_out != outlet_pressure);
       double ef = 0.0, pe = cur_p;
       if (has_extraction && extraction_demand > 0) {
         ef = npd_clip(extraction_demand, 5.0, npd_pymin(50.0, cur_flow * 0.3));
         pe = cur_p * 0.7 + outlet_pressure * (1 - 0.7);
       }
-      p_in[k] = cur_p; p_arg[k] = outlet_pressure; p_self[k] = self_out; flow_in[k] = cur_flow; ext_flow[k] = ef; p_ext[k] = pe;
+      if (NPD_IS_EXT(k)) { ext_flow[NPD_EXT_IDX(k)] = ef; p_ext[NPD_EXT_IDX(k)] = pe; }
+      p_self[k] = self_out;
       flow_out[k] = cur_flow - ef;
       rare = rare || !(self_out >= 0.001 && self_out <= 22.0) || !(pe >= 0.001 && pe <= 22.0) || !(outlet_pressure >= 0.001);
       cur_p = self_out; cur_flow = flow_out[k];
     }
   }
   if (__builtin_amdgcn_ballot_w64(rare) != 0) { /* wave-uniform: any lane off the fast path */
-    npd_stage_system_update_seq(f64, N, p, inlet_pressure, inlet_temperature, inlet_flow, load_demand,
+    npd_stage_system_update_seq(f64, stg, N, p, inlet_pressure, inlet_temperature, inlet_flow, load_demand,
                                 pressure_stability_factor, dt, out);
     return;
   }
+  NPD_STAMP(13);
   /* pass B: independent transcendental streams */
-  double sat_self[14], hg_self[14], tratio[14], sat_ext[14], hg_ext[14], sat_arg[14], hg_arg[14];
+  double sat_self[14], hg_self[14], tratio[14], hg_ext[5];
   double sat_in0 = npd_tsat_antoine(inlet_pressure);
   double hg_in0 = npd_hg_from_tsat(sat_in0);
-  bool mismatch = false;
 #pragma unroll
   for (int k = 0; k < 14; k++) {
     sat_self[k] = npd_tsat_antoine(p_self[k]);
     hg_self[k] = npd_hg_from_tsat(sat_self[k]);
-    tratio[k] = sqrt(sqrt(p_self[k] / p_in[k]));
-    mismatch = mismatch || (p_arg[k] != p_self[k]);
+    tratio[k] = sqrt(sqrt(p_self[k] / ((k == 0) ? inlet_pressure : p_self[k > 0 ? k - 1 : 0])));
   }
 #pragma unroll
-  for (int k = 0; k < 14; k++) {
-    if (k == 2 || k == 3 || k == 4 || k == 8 || k == 9) { sat_ext[k] = npd_tsat_antoine(p_ext[k]); hg_ext[k] = npd_hg_from_tsat(sat_ext[k]); }
-    else { sat_ext[k] = 0.0; hg_ext[k] = 0.0; }
-  }
-  if (__builtin_amdgcn_ballot_w64(mismatch) != 0) { /* some lane's requested outlet pressure was clamped */
-#pragma unroll
-    for (int k = 0; k < 14; k++) { sat_arg[k] = npd_tsat_antoine(p_arg[k]); hg_arg[k] = npd_hg_from_tsat(sat_arg[k]); }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 14; k++) { sat_arg[k] = sat_self[k]; hg_arg[k] = hg_self[k]; }
-  }
+  for (int e = 0; e < 5; e++) hg_ext[e] = npd_hg_from_tsat(npd_tsat_antoine(p_ext[e]));
+  NPD_STAMP(14);
+  NPD_DMA_WAIT(); /* the staged stage arrays are read from here on */
   /* pass C: temperature / enthalpy chain */
   double T_in = inlet_temperature, sat_in = sat_in0, hg_in = hg_in0;
   double total_power = 0.0, total_extraction = 0.0;
 #pragma unroll
   for (int k = 0; k < 14; k++) {
-    double fouling_factor = 1.0 / (1.0 + NPD_TSTG(stage_deposit_thickness, k) / 0.5);
-    double blade_wear_factor = NPD_TSTG(stage_blade_wear_factor, k);
+    const double p_in = (k == 0) ? inlet_pressure : p_self[k > 0 ? k - 1 : 0];
+    if (k == 1) NPD_STAMP(24);
+    if (k == 2) NPD_STAMP(25);
+    if (k == 7) NPD_STAMP(26);
+    if (k == 13) NPD_STAMP(27);
+    double fouling_factor = 1.0 / (1.0 + NPD_TSTG_RD(stage_deposit_thickness, k) / 0.5);
+    double blade_wear_factor = NPD_TSTG_RD(stage_blade_wear_factor, k);
     double blade_condition_factor = npd_pymin(fouling_factor, blade_wear_factor);
-    double actual_efficiency = npd_pymax(0.7, 0.88 - NPD_TSTG(stage_efficiency_degradation, k));
-    double cp_in = (p_in[k] > 10.0) ? 2.5 : ((p_in[k] > 1.0) ? 2.2 : 2.0);
+    double actual_efficiency = npd_pymax(0.7, 0.88 - NPD_TSTG_RD(stage_efficiency_degradation, k));
+    double cp_in = (p_in > 10.0) ? 2.5 : ((p_in > 1.0) ? 2.2 : 2.0);
     double T_c = npd_pymax(0.0, npd_pymin(T_in, 800.0));
     double inlet_enthalpy = (T_c <= sat_in) ? hg_in : hg_in + cp_in * (T_c - sat_in);
     double T_isen = (T_in + 273.15) * tratio[k] - 273.15;
@@ -340,25 +348,30 @@ NPD_FN void npd_stage_system_update(double *__restrict__ f64, size_t N, size_t p
     double total_efficiency = (actual_efficiency * blade_condition_factor * fouling_factor * blade_wear_factor * 1.0);
     double isentropic_enthalpy_drop = inlet_enthalpy - h_isen;
     if (isentropic_enthalpy_drop <= 0) {
-      double min_enthalpy_drop = 50.0 * (1.0 - p_self[k] / p_in[k]);
+      double min_enthalpy_drop = 50.0 * (1.0 - p_self[k] / p_in);
       isentropic_enthalpy_drop = npd_pymax(min_enthalpy_drop, 10.0);
     }
     double actual_enthalpy_drop = total_efficiency * isentropic_enthalpy_drop;
     if (actual_enthalpy_drop <= 0) actual_enthalpy_drop = npd_pymax(1.0, isentropic_enthalpy_drop * 0.5);
     double outlet_enthalpy = inlet_enthalpy - actual_enthalpy_drop;
-    double T_out = (outlet_enthalpy <= hg_arg[k]) ? sat_arg[k] : sat_arg[k] + (outlet_enthalpy - hg_arg[k]) / 2.1;
+    /* requested outlet pressure == the stage's own outlet pressure on this path */
+    double T_out = (outlet_enthalpy <= hg_self[k]) ? sat_self[k] : sat_self[k] + (outlet_enthalpy - hg_self[k]) / 2.1;
     double main_power = flow_out[k] * actual_enthalpy_drop / 1000.0;
     if (main_power < 0) main_power = 0.0;
     double extraction_power = 0.0;
-    if (ext_flow[k] > 0) extraction_power = ext_flow[k] * (inlet_enthalpy - hg_ext[k]) / 1000.0;
+    double ef = NPD_IS_EXT(k) ? ext_flow[NPD_EXT_IDX(k)] : 0.0;
+    if (ef > 0) extraction_power = ef * (inlet_enthalpy - hg_ext[NPD_EXT_IDX(k)]) / 1000.0;
     double loading_factor = actual_enthalpy_drop / npd_pymax(1.0, 0.88 * isentropic_enthalpy_drop);
-    total_power += main_power + extraction_power; total_extraction += ext_flow[k];
+    total_power += main_power + extraction_power; total_extraction += ef;
     if (k == 13) out->lp6_outlet_enthalpy = outlet_enthalpy;
-    npd_stage_post(f64, N, p, k, loading_factor, T_out, dt, out);
+    npd_stage_post(f64, stg, N, p, k, loading_factor, T_out, dt, out);
     T_in = T_out; sat_in = sat_self[k]; hg_in = hg_self[k];
   }
+  NPD_STAMP(28);
   out->total_power = total_power * pressure_stability_factor;
   out->total_extraction = total_extraction;
+#undef NPD_EXT_IDX
+#undef NPD_IS_EXT
 }
 
 /* _calculate_pressure_variation_effects  enhanced_physics.py:1312-1350 */
@@ -387,7 +400,7 @@ typedef struct npd_turbine_result_t {
   int trip_active;
 } npd_turbine_result_t;
 
-NPD_FN void npd_turbine_update(npb_turb_t *t, double *__restrict__ f64, size_t N, size_t p, double steam_pressure,
+NPD_FN void npd_turbine_update(npb_turb_t *t, double *__restrict__ f64, const npd_stage_t &st, size_t N, size_t p, double steam_pressure,
                                double steam_temperature, double steam_flow,
                                const double *sg_pressures, int sg_system_availability, double load_demand,
                                double condenser_pressure, double dt, npd_turbine_result_t *res) {
@@ -457,11 +470,20 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, double *__restrict__ f64, size_t N
     t->lub_wear[i] += (wear_rate * lubrication_wear_factor) * dt;
   }
 
+  NPD_STAMP(12);
   /* ================= EnhancedTurbinePhysics.update_state  enhanced_physics.py:694-890 ========= */
   t->load_demand = load_demand;
   double pressure_stability_factor = npd_pressure_stability_factor(sg_pressures);
   npd_stagesys_out_t ss;
-  npd_stage_system_update(f64, N, p, steam_pressure, steam_temperature, steam_flow, load_demand, pressure_stability_factor, dt, &ss);
+  npd_stage_system_update(f64, st.lds + threadIdx.x, N, p, steam_pressure, steam_temperature, steam_flow, load_demand,
+                          pressure_stability_factor, dt, &ss);
+  /* the stage arrays are consumed: stage the condenser group into the same LDS region while the rotor,
+   * bearing and protection arithmetic below runs */
+  NPD_STAMP(29);
+  NPD_LDS_DRAIN();
+  NPD_STAMP(30);
+  npd_dma_condenser_group(st);
+  NPD_STAMP(15);
   double stage_power_mw = ss.total_power;
   double applied_torque = stage_power_mw * 1e6 / (2 * NPD_PI * 3600 / 60);
 
