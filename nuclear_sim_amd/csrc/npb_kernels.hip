@@ -86,6 +86,24 @@ __device__ __forceinline__ void npd_store(const S &s, double *__restrict__ f64, 
 #define NPD_I32_COL(T, stype, member, inst) \
   i32[(size_t)(NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32 + NPB_I32_SLOT(stype, T, member)) * N + p]
 
+/* step kernel: section / column stores through the pinned 32-bit-offset addressing of npd_stage.h */
+template <int NF, int NI, typename S>
+__device__ __forceinline__ void npd_st_store(const S &s, const npd_stage_t &st, int fbase, int ibase) {
+  const double *d = reinterpret_cast<const double *>(&s);
+#pragma unroll
+  for (int k = 0; k < NF; k++) *NPD_F64P(double, fbase + k, st.lane8) = d[k];
+  const int32_t *q = reinterpret_cast<const int32_t *>(d + NF);
+#pragma unroll
+  for (int k = 0; k < NI; k++) *NPD_I32P(int32_t, ibase + k, st.lane4) = q[k];
+}
+#define NPD_ST_STORE(T, stype, s, inst) \
+  npd_st_store<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
+                                                      NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32)
+#define NPD_ST_F64(T, stype, member, inst, k) \
+  (*NPD_F64P(double, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64 + NPB_F64_SLOT(stype, member) + (k), st.lane8))
+#define NPD_ST_I32(T, stype, member, inst) \
+  (*NPD_I32P(int32_t, NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32 + NPB_I32_SLOT(stype, T, member), st.lane4))
+
 /* wave-cooperative store of a [64][W] block held one row per lane into row-major global memory */
 template <int W>
 __device__ __forceinline__ void npd_store_rows(const double *row, double *__restrict__ out, double *lds,
@@ -136,7 +154,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   const double dt = P.dt;
   const bool full = P.mode == NPB_MODE_FULL;
   npd_stage_t st;
-  st.lds = lds; st.f64 = f64; st.i32 = i32; st.N = N; st.block_base = block_base;
+  npd_stage_init(st, lds, f64, i32, N, block_base);
 
   /* per-step inputs first (plain loads), then the first staged group: primary + secondary-level scalars */
   npd_inputs_t in;
@@ -227,7 +245,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     npb_pump_t pm;
     /* boundary: fw + pump 0 are staged; store the primary section, stage pump 1 */
     NPD_DMA_WAIT();
-    NPD_STORE(PRIM, npb_prim_t, s, 0);
+    NPD_ST_STORE(PRIM, npb_prim_t, s, 0);
     NPD_CONSUME(FW, npb_fw_t, fw, NPD_LS_FW);
     NPD_CONSUME(PUMP, npb_pump_t, pm, NPD_LS_PUMP0);
     NPD_LDS_DRAIN();
@@ -251,7 +269,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       /* boundary: pump i -> HBM, pump i+1 (staged during this pump's arithmetic) -> the same registers,
        * then stage pump i+2, or SG 0 once the last pump is on its way */
       NPD_DMA_WAIT();
-      NPD_STORE(PUMP, npb_pump_t, pm, i);
+      NPD_ST_STORE(PUMP, npb_pump_t, pm, i);
       if (i + 1 < NPB_NUM_PUMPS) NPD_CONSUME(PUMP, npb_pump_t, pm, 0);
       NPD_LDS_DRAIN();
       if (i + 2 < NPB_NUM_PUMPS) NPD_DMA(PUMP, i + 2, 0);
@@ -265,14 +283,14 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     trip_flags |= (fwr.pump_trip_mask << 8) | (fw.system_trip_active ? NPB_TRIP_FW_SYSTEM : 0);
     /* boundary: SG 0 -> registers (its DMA ran during pump 3), fw -> HBM, stage SG 1 */
     NPD_DMA_WAIT();
-    NPD_STORE(FW, npb_fw_t, fw, 0);
+    NPD_ST_STORE(FW, npb_fw_t, fw, 0);
     NPD_CONSUME(SG, npb_sg_t, g, 0);
     NPD_LDS_DRAIN();
     NPD_DMA(SG, 1, 0);
   } else {
     /* config-2 mode: no feedwater system; boundary straight to SG 0 */
     NPD_DMA_WAIT();
-    NPD_STORE(PRIM, npb_prim_t, s, 0);
+    NPD_ST_STORE(PRIM, npb_prim_t, s, 0);
     NPD_CONSUME(SG, npb_sg_t, g, 0);
     NPD_LDS_DRAIN();
     NPD_DMA(SG, 1, 0);
@@ -313,10 +331,10 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       if (r.thermal_efficiency > 0.1) sg_effective++;
       /* boundary: SG i -> HBM, SG i+1 -> the same registers, stage SG i+2 / the turbine scalars */
       NPD_DMA_WAIT();
-      NPD_STORE(SG, npb_sg_t, g, i);
-      NPD_F64_COLK(SEC, npb_sec_t, prev_sg_levels, 0, i) = g.water_level;
-      NPD_F64_COLK(SEC, npb_sec_t, prev_sg_steam_flows, 0, i) = r.steam_flow_rate;
-      NPD_F64_COLK(SEC, npb_sec_t, prev_sg_qualities, 0, i) = g.steam_quality;
+      NPD_ST_STORE(SG, npb_sg_t, g, i);
+      NPD_ST_F64(SEC, npb_sec_t, prev_sg_levels, 0, i) = g.water_level;
+      NPD_ST_F64(SEC, npb_sec_t, prev_sg_steam_flows, 0, i) = r.steam_flow_rate;
+      NPD_ST_F64(SEC, npb_sec_t, prev_sg_qualities, 0, i) = g.steam_quality;
       if (i + 1 < NPB_NUM_SG) NPD_CONSUME(SG, npb_sg_t, g, 0);
       NPD_LDS_DRAIN();
       if (i + 2 < NPB_NUM_SG) NPD_DMA(SG, i + 2, 0);
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     NPD_CONSUME(TURB, npb_turb_t, t, 0);
     NPD_LDS_DRAIN();
     NPD_DMA(TSTG, 0, 0);
-    if (!(NPB_ABLATE & 4)) npd_turbine_update(&t, f64, st, N, p, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
+    if (!(NPB_ABLATE & 4)) npd_turbine_update(&t, st, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
                        load_demand, 0.007, dt / 60.0, &tr);
     NPD_STAMP(18);
     /* ================= phase 4: condenser (:591-621) ================= */
@@ -358,14 +376,14 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       npb_cond_t cd; npb_chem_t ch;
       /* boundary: the condenser group was staged by npd_turbine_update right after the stage pass */
       NPD_DMA_WAIT();
-      NPD_STORE(TURB, npb_turb_t, t, 0);
+      NPD_ST_STORE(TURB, npb_turb_t, t, 0);
       NPD_CONSUME(COND, npb_cond_t, cd, NPD_LS_COND);
       NPD_CONSUME(CHEM, npb_chem_t, ch, NPD_LS_CHEM1);
       NPD_LDS_DRAIN();
       if (!(NPB_ABLATE & 8)) npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
                            cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr);
-      NPD_STORE(COND, npb_cond_t, cd, 0);
-      NPD_STORE(CHEM, npb_chem_t, ch, 1);
+      NPD_ST_STORE(COND, npb_cond_t, cd, 0);
+      NPD_ST_STORE(CHEM, npb_chem_t, ch, 1);
       NPD_CONSUME(CHEM, npb_chem_t, ch0, NPD_LS_CHEM0);
       NPD_CONSUME(PH, npb_ph_t, ph, NPD_LS_PH);
       NPD_LDS_DRAIN();
@@ -374,8 +392,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     NPD_STAMP(19);
     /* ================= chemistry sidecar: shared WaterChemistry + pH controller (:634-665) ========= */
     npd_chemistry_sidecar(&ch0, &ph, dt);
-    NPD_STORE(CHEM, npb_chem_t, ch0, 0);
-    NPD_STORE(PH, npb_ph_t, ph, 0);
+    NPD_ST_STORE(CHEM, npb_chem_t, ch0, 0);
+    NPD_ST_STORE(PH, npb_ph_t, ph, 0);
     NPD_STAMP(20);
     /* ================= electrical-power gates (:750-932) ================= */
     double turbine_electrical_power = tr.electrical_power_net;
@@ -395,27 +413,27 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   }
 
   /* ================= secondary-level state write-back ================= */
-  NPD_F64_COL(SEC, npb_sec_t, previous_feedwater_temp, 0) = actual_feedwater_temp;
-  NPD_F64_COL(SEC, npb_sec_t, electrical_power_output, 0) = electrical_power;
-  NPD_F64_COL(SEC, npb_sec_t, thermal_efficiency, 0) = thermal_efficiency;
-  NPD_F64_COL(SEC, npb_sec_t, total_steam_flow, 0) = sg_total_steam;
-  NPD_F64_COL(SEC, npb_sec_t, total_heat_transfer, 0) = sg_total_thermal;
-  NPD_F64_COL(SEC, npb_sec_t, total_feedwater_flow, 0) = fw_total_flow;
-  NPD_F64_COL(SEC, npb_sec_t, load_demand, 0) = load_demand;
-  NPD_F64_COL(SEC, npb_sec_t, cooling_water_temperature, 0) = cooling_water_temperature;
-  NPD_F64_COL(SEC, npb_sec_t, operating_hours, 0) = operating_hours + dt / 3600.0;
-  NPD_F64_COL(SEC, npb_sec_t, sg_avg_pressure, 0) = sg_avg_pressure;
-  NPD_F64_COL(SEC, npb_sec_t, sg_avg_temperature, 0) = sg_avg_temperature;
-  NPD_F64_COL(SEC, npb_sec_t, sg_avg_quality, 0) = sg_avg_quality;
-  NPD_I32_COL(SEC, npb_sec_t, has_previous_sg_conditions, 0) = 1;
-  NPD_I32_COL(SEC, npb_sec_t, sg_system_availability, 0) = sg_system_availability;
+  NPD_ST_F64(SEC, npb_sec_t, previous_feedwater_temp, 0, 0) = actual_feedwater_temp;
+  NPD_ST_F64(SEC, npb_sec_t, electrical_power_output, 0, 0) = electrical_power;
+  NPD_ST_F64(SEC, npb_sec_t, thermal_efficiency, 0, 0) = thermal_efficiency;
+  NPD_ST_F64(SEC, npb_sec_t, total_steam_flow, 0, 0) = sg_total_steam;
+  NPD_ST_F64(SEC, npb_sec_t, total_heat_transfer, 0, 0) = sg_total_thermal;
+  NPD_ST_F64(SEC, npb_sec_t, total_feedwater_flow, 0, 0) = fw_total_flow;
+  NPD_ST_F64(SEC, npb_sec_t, load_demand, 0, 0) = load_demand;
+  NPD_ST_F64(SEC, npb_sec_t, cooling_water_temperature, 0, 0) = cooling_water_temperature;
+  NPD_ST_F64(SEC, npb_sec_t, operating_hours, 0, 0) = operating_hours + dt / 3600.0;
+  NPD_ST_F64(SEC, npb_sec_t, sg_avg_pressure, 0, 0) = sg_avg_pressure;
+  NPD_ST_F64(SEC, npb_sec_t, sg_avg_temperature, 0, 0) = sg_avg_temperature;
+  NPD_ST_F64(SEC, npb_sec_t, sg_avg_quality, 0, 0) = sg_avg_quality;
+  NPD_ST_I32(SEC, npb_sec_t, has_previous_sg_conditions, 0) = 1;
+  NPD_ST_I32(SEC, npb_sec_t, sg_system_availability, 0) = sg_system_availability;
 
   /* ================= _apply_secondary_to_primary_feedback  sim.py:429-498 ================= */
   double heat_removal_factor = sg_total_steam / 1665.0;
   if (!fw_available) heat_removal_factor *= 0.5;
-  NPD_F64_COL(PRIM, npb_prim_t, steam_flow_rate, 0) = sg_total_steam;
-  NPD_F64_COL(PRIM, npb_prim_t, last_heat_removal_factor, 0) = heat_removal_factor;
-  NPD_I32_COL(PRIM, npb_prim_t, has_heat_removal_factor, 0) = 1;
+  NPD_ST_F64(PRIM, npb_prim_t, steam_flow_rate, 0, 0) = sg_total_steam;
+  NPD_ST_F64(PRIM, npb_prim_t, last_heat_removal_factor, 0, 0) = heat_removal_factor;
+  NPD_ST_I32(PRIM, npb_prim_t, has_heat_removal_factor, 0) = 1;
 
   /* ================= observation / reward / done / flags / info ================= */
   obs[7] = sg_total_steam / 3000;

@@ -32,13 +32,38 @@
 typedef __attribute__((address_space(1))) const void npd_gptr_t;
 typedef __attribute__((address_space(3))) void npd_lptr_t;
 
+/* Arena addresses are (one wave-uniform 64-bit base for the whole kernel) + (32-bit byte offset = column *
+ * pitch + this lane's part): the SGPR-base form of global_load_lds / global_store with a 32-bit VGPR offset.
+ * One s_mul + one v_add per access instead of 64-bit per-lane arithmetic and an address register pair per
+ * column.  The offsets are computed by a volatile asm where they are used: as plain C the optimiser hoists
+ * these one-instruction values out of the phases and keeps hundreds of them live.  32-bit offsets bound an
+ * arena at 4 GiB per kind; npb_create enforces it (about one million plants per handle). */
+typedef __attribute__((address_space(1))) char npd_gchar_t;
 typedef struct npd_stage_t {
   double *lds;            /* staging region base (wave-uniform) */
-  const double *f64;      /* SoA arena */
-  const int32_t *i32;
-  size_t N;               /* column pitch */
-  size_t block_base;      /* first plant of this wave */
+  npd_gchar_t *f64b;      /* SoA arenas, offset to this wave's first plant (wave-uniform) */
+  npd_gchar_t *i32b;
+  uint32_t n8, n4;        /* column pitch in bytes: fp64 and int32 arena */
+  uint32_t lane8, lane4;  /* lane * 8, lane * 4: this lane's plant within a column */
+  uint32_t pair16;        /* two-column LDS-DMA: lanes 0-31 carry column c (2 plants = 16 B each), lanes 32-63
+                           * column c + 1:  (lane >> 5) * n8 + (lane & 31) * 16 */
 } npd_stage_t;
+
+__device__ __forceinline__ void npd_stage_init(npd_stage_t &st, double *lds, double *f64, int32_t *i32, size_t N, size_t block_base) {
+  const uint32_t lane = threadIdx.x;
+  st.lds = lds;
+  st.f64b = (npd_gchar_t *)(f64 + block_base); st.i32b = (npd_gchar_t *)(i32 + block_base);
+  st.n8 = (uint32_t)(N * 8); st.n4 = (uint32_t)(N * 4);
+  st.lane8 = lane * 8u; st.lane4 = lane * 4u;
+  st.pair16 = (lane >> 5) * st.n8 + (lane & 31u) * 16u;
+}
+__device__ __forceinline__ uint32_t npd_voff(uint32_t col, uint32_t pitch, uint32_t lane_off) {
+  uint32_t v, t;
+  asm volatile("s_mul_i32 %1, %2, %3\n\tv_add_u32 %0, %1, %4" : "=v"(v), "=&s"(t) : "s"(col), "s"(pitch), "v"(lane_off));
+  return v;
+}
+#define NPD_F64P(type, col, off) ((__attribute__((address_space(1))) type *)(st.f64b + npd_voff((uint32_t)(col), st.n8, (off))))
+#define NPD_I32P(type, col, off) ((__attribute__((address_space(1))) type *)(st.i32b + npd_voff((uint32_t)(col), st.n4, (off))))
 
 #ifdef NPB_STAMPS
 /* diagnostic build: ticks this wave spent inside the staging pipeline's waits (lane 0 keeps the sum in LDS) */
@@ -62,24 +87,21 @@ __shared__ unsigned long long npd_wait_acc_s;
  * columns back to back. */
 template <int NF, int NI>
 __device__ __forceinline__ void npd_dma(const npd_stage_t &st, int fslot, int islot, int ls) {
-  const int lane = threadIdx.x;
-  const double *g = st.f64 + (size_t)(fslot + (lane >> 5)) * st.N + st.block_base + (size_t)(lane & 31) * 2;
   double *l = st.lds + ls * NPB_WAVE;
 #pragma unroll
   for (int c = 0; c + 1 < NF; c += 2)
-    __builtin_amdgcn_global_load_lds((npd_gptr_t *)(g + (size_t)c * st.N), (npd_lptr_t *)(l + c * NPB_WAVE), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_F64P(double, fslot + c, st.pair16), (npd_lptr_t *)(l + c * NPB_WAVE), 16, 0, 0);
   if (NF & 1) { /* odd last column: two dword pieces of 256 B */
-    const uint32_t *g4 = (const uint32_t *)(st.f64 + (size_t)(fslot + NF - 1) * st.N + st.block_base) + lane;
+    const __attribute__((address_space(1))) uint32_t *g4 = NPD_F64P(const uint32_t, fslot + NF - 1, st.lane4);
     uint32_t *l4 = (uint32_t *)(l + (NF - 1) * NPB_WAVE);
     __builtin_amdgcn_global_load_lds((npd_gptr_t *)g4, (npd_lptr_t *)l4, 4, 0, 0);
     __builtin_amdgcn_global_load_lds((npd_gptr_t *)(g4 + NPB_WAVE), (npd_lptr_t *)(l4 + NPB_WAVE), 4, 0, 0);
   }
   if (NI > 0) {
-    const int32_t *gi = st.i32 + (size_t)islot * st.N + st.block_base + lane;
     int32_t *li = (int32_t *)(l + NF * NPB_WAVE);
 #pragma unroll
     for (int k = 0; k < NI; k++)
-      __builtin_amdgcn_global_load_lds((npd_gptr_t *)(gi + (size_t)k * st.N), (npd_lptr_t *)(li + k * NPB_WAVE), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_I32P(int32_t, islot + k, st.lane4), (npd_lptr_t *)(li + k * NPB_WAVE), 4, 0, 0);
   }
 }
 #define NPD_DMA(T, inst, ls) \

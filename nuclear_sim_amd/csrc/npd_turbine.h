@@ -173,13 +173,13 @@ typedef struct npd_stagesys_out_t {
  * updated value is written straight to its SoA column; every column is read before it is written and
  * never re-read within a step, so the staged copy does not need the update */
 #define NPD_TSTG_RD(member, k) stg[(NPB_F64_SLOT(npb_tstg_t, member) + (k)) * NPB_WAVE]
-#define NPD_TSTG_WR(member, k, v) f64[(size_t)(NPB_TSTG_F64_BASE + NPB_F64_SLOT(npb_tstg_t, member) + (k)) * N + p] = (v)
+#define NPD_TSTG_WR(member, k, v) *NPD_F64P(double, NPB_TSTG_F64_BASE + NPB_F64_SLOT(npb_tstg_t, member) + (k), st.lane8) = (v)
 
 /* one stage's share of TurbineStage.update_degradation (stage_system.py:294-339) and of
  * MetalTemperatureTracker.update_temperatures (enhanced_physics.py:73-166, time constant 1 h, ambient 25 C);
  * both only touch stage k's own state, so running them right after stage k's expansion is the
  * reference's result */
-NPD_FN void npd_stage_post(double *__restrict__ f64, const double *stg, size_t N, size_t p, int k, double loading_factor,
+NPD_FN void npd_stage_post(const npd_stage_t &st, const double *stg, int k, double loading_factor,
                            double outlet_temperature, double dt, npd_stagesys_out_t *out) {
   NPD_TSTG_WR(stage_efficiency_degradation, k, NPD_TSTG_RD(stage_efficiency_degradation, k) + 1e-05 * dt);
   NPD_TSTG_WR(stage_deposit_thickness, k, NPD_TSTG_RD(stage_deposit_thickness, k) + 5e-05 * dt);
@@ -230,7 +230,7 @@ NPD_FN double npd_stage_requested_outlet(int k, double current_pressure, double 
 
 /* TurbineStageSystem.update_state  stage_system.py:928-1016, reference order, one stage at a time.
  * Exact for every input; used when a lane of the wave leaves the fast path's assumptions. */
-NPD_FN void npd_stage_system_update_seq(double *__restrict__ f64, const double *stg, size_t N, size_t p, double inlet_pressure,
+NPD_FN void npd_stage_system_update_seq(const npd_stage_t &st, const double *stg, double inlet_pressure,
                                         double inlet_temperature, double inlet_flow, double load_demand,
                                         double pressure_stability_factor, double dt, npd_stagesys_out_t *out) {
   double current_pressure = inlet_pressure, current_temperature = inlet_temperature, current_flow = inlet_flow;
@@ -250,7 +250,7 @@ NPD_FN void npd_stage_system_update_seq(double *__restrict__ f64, const double *
                         current_temperature, current_flow, outlet_pressure, extraction_demand, &so);
     total_power += so.power_output; total_extraction += so.extraction_flow;
     if (k == 13) out->lp6_outlet_enthalpy = so.outlet_enthalpy;
-    npd_stage_post(f64, stg, N, p, k, so.loading_factor, so.outlet_temperature, dt, out);
+    npd_stage_post(st, stg, k, so.loading_factor, so.outlet_temperature, dt, out);
     current_pressure = so.outlet_pressure; current_temperature = so.outlet_temperature; current_flow = so.outlet_flow;
   }
   out->total_power = total_power * pressure_stability_factor;
@@ -266,7 +266,7 @@ NPD_FN void npd_stage_system_update_seq(double *__restrict__ f64, const double *
  *   pass C  walks the temperature / enthalpy chain with plain arithmetic and streams each stage's
  *           degradation and metal-temperature state.
  * Lanes that would take a rare branch make the whole wave use npd_stage_system_update_seq. */
-NPD_FN void npd_stage_system_update(double *__restrict__ f64, const double *stg, size_t N, size_t p, double inlet_pressure,
+NPD_FN void npd_stage_system_update(const npd_stage_t &st, const double *stg, double inlet_pressure,
                                     double inlet_temperature, double inlet_flow, double load_demand,
                                     double pressure_stability_factor, double dt, npd_stagesys_out_t *out) {
   /* extraction stages 2, 3, 4, 8, 9 -> compact index 0..4 */
@@ -305,7 +305,7 @@ NPD_FN void npd_stage_system_update(double *__restrict__ f64, const double *stg,
     }
   }
   if (__builtin_amdgcn_ballot_w64(rare) != 0) { /* wave-uniform: any lane off the fast path */
-    npd_stage_system_update_seq(f64, stg, N, p, inlet_pressure, inlet_temperature, inlet_flow, load_demand,
+    npd_stage_system_update_seq(st, stg, inlet_pressure, inlet_temperature, inlet_flow, load_demand,
                                 pressure_stability_factor, dt, out);
     return;
   }
@@ -364,7 +364,7 @@ NPD_FN void npd_stage_system_update(double *__restrict__ f64, const double *stg,
     double loading_factor = actual_enthalpy_drop / npd_pymax(1.0, 0.88 * isentropic_enthalpy_drop);
     total_power += main_power + extraction_power; total_extraction += ef;
     if (k == 13) out->lp6_outlet_enthalpy = outlet_enthalpy;
-    npd_stage_post(f64, stg, N, p, k, loading_factor, T_out, dt, out);
+    npd_stage_post(st, stg, k, loading_factor, T_out, dt, out);
     T_in = T_out; sat_in = sat_self[k]; hg_in = hg_self[k];
   }
   NPD_STAMP(28);
@@ -400,7 +400,7 @@ typedef struct npd_turbine_result_t {
   int trip_active;
 } npd_turbine_result_t;
 
-NPD_FN void npd_turbine_update(npb_turb_t *t, double *__restrict__ f64, const npd_stage_t &st, size_t N, size_t p, double steam_pressure,
+NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double steam_pressure,
                                double steam_temperature, double steam_flow,
                                const double *sg_pressures, int sg_system_availability, double load_demand,
                                double condenser_pressure, double dt, npd_turbine_result_t *res) {
@@ -475,7 +475,7 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, double *__restrict__ f64, const np
   t->load_demand = load_demand;
   double pressure_stability_factor = npd_pressure_stability_factor(sg_pressures);
   npd_stagesys_out_t ss;
-  npd_stage_system_update(f64, st.lds + threadIdx.x, N, p, steam_pressure, steam_temperature, steam_flow, load_demand,
+  npd_stage_system_update(st, st.lds + threadIdx.x, steam_pressure, steam_temperature, steam_flow, load_demand,
                           pressure_stability_factor, dt, &ss);
   /* the stage arrays are consumed: stage the condenser group into the same LDS region while the rotor,
    * bearing and protection arithmetic below runs */
