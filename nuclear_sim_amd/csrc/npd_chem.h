@@ -13,9 +13,9 @@ NPD_FN void npd_chem_composites(npb_chem_t *c) {
   double ph_effect = fabs(c->ph - 7.0) * 0.2;
   double hardness_effect = npd_pymax(0.0, (c->hardness - 150.0) / 150.0) * 0.3;
   c->water_aggressiveness = npd_clip(1.0 + iron_effect + chloride_effect + ph_effect + hardness_effect, 0.5, 3.0);
-  double A = (log10(c->total_dissolved_solids) - 1) / 10;
+  double A = (npd_log10(c->total_dissolved_solids) - 1) / 10;
   double B = -13.12 * log10(25.0 + 273) + 34.55;
-  double C = log10(c->hardness) - 0.4;
+  double C = npd_log10(c->hardness) - 0.4;
   double D = log10(120.0);
   double ph_saturation = (9.3 + A + B) - (C + D);
   c->scaling_tendency = c->ph - ph_saturation;
@@ -50,7 +50,7 @@ NPD_FN void npd_chem_update(npb_chem_t *c, double dt) {
   c->antiscalant_concentration += (5.0 - c->antiscalant_concentration) * dose_rate;
   c->corrosion_inhibitor_level += (10.0 - c->corrosion_inhibitor_level) * dose_rate;
   double chlorine_decay = 0.1 * dt_hours;
-  c->chlorine_residual *= exp(-chlorine_decay);
+  c->chlorine_residual *= npd_exp(-chlorine_decay);
   c->chlorine_residual += (1.0 - c->chlorine_residual) * dose_rate;
   double chlorine_effectiveness = (c->chlorine_residual > 0.2) ? 1.0 : 0.5;
   double antiscalant_effectiveness = (c->antiscalant_concentration > 2.0) ? 1.0 : 0.7;

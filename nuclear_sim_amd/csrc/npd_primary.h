@@ -62,7 +62,7 @@ NPD_FN double npd_total_reactivity_pcm(const npb_prim_t *s) {
   double xenon = (s->xenon_concentration / 1.0e15) * -1800.0;
   double samarium = (s->samarium_concentration / 5.0e14) * -600.0;
   double depletion = 3340.0 + -0.15 * s->fuel_burnup;
-  double bp = s->burnable_poison_worth * exp(-0.0002 * s->fuel_burnup);
+  double bp = s->burnable_poison_worth * npd_exp(-0.0002 * s->fuel_burnup);
   double total = 0.0;
   total += rods; total += boron; total += doppler; total += mod_temp; total += mod_void;
   total += pressure; total += xenon; total += samarium; total += depletion; total += bp;

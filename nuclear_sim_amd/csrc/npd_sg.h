@@ -12,7 +12,7 @@
 NPD_FN double npd_sg_tsat(double pressure_mpa) {
   if (pressure_mpa <= 0.001) return 10.0;
   double pressure_bar = pressure_mpa * 10.0;
-  double ln_p = log(pressure_bar);
+  double ln_p = npd_log(pressure_bar);
   double temp_c = 42.6776 + 34.5194 * ln_p + 2.8896 * npd_sq(ln_p) + 0.1153 * (ln_p * ln_p * ln_p);
   return npd_clip(temp_c, 10.0, 374.0);
 }
@@ -84,15 +84,15 @@ NPD_FN void npd_tsp_update(npb_sg_t *g, const npb_params_t *P, double temperatur
   double dt_years = dt_hours / (365.25 * 24.0);
 
   double temp_kelvin = temperature + 273.15;
-  double temp_factor = exp(-45000.0 / (8.314 * temp_kelvin));
-  temp_factor = temp_factor / exp(-45000.0 / (8.314 * 573.15));
+  double temp_factor = npd_exp(-45000.0 / (8.314 * temp_kelvin));
+  temp_factor = temp_factor / npd_exp(-45000.0 / (8.314 * 573.15));
   double ph_factor = 1.0 + 0.5 * fabs(P->sgchem_ph - 9.2);
   double velocity_factor = sqrt(flow_velocity / 3.0);
   velocity_factor = npd_clip(velocity_factor, 0.5, 2.0);
   double magnetite_rate = 2.5 * (1.0 + P->sgchem_iron * 1.5) * temp_factor * ph_factor * velocity_factor;
   double copper_rate = 0.8 * (1.0 + P->sgchem_copper * 2.0) * temp_factor * velocity_factor;
   double silica_rate = 1.2 * (1.0 + P->sgchem_silica / 100.0 * 1.8) * temp_factor * ph_factor;
-  double bio_temp_factor = (temperature < 60) ? 1.0 : exp(-(temperature - 60) / 20);
+  double bio_temp_factor = (temperature < 60) ? 1.0 : npd_exp(-(temperature - 60) / 20);
   double biological_rate = 0.5 * (1.0 + P->sgchem_dissolved_oxygen * 10.0) * bio_temp_factor * velocity_factor;
 
   const double max_thickness = 0.023 / 2.0 * 1000.0 * 0.9;
@@ -154,13 +154,13 @@ NPD_FN void npd_scale_update(npb_sg_t *g, double temperature, double flow_veloci
   g->scale_operating_years += dt_seconds / (365.25 * 24.0 * 3600.0);
   const double boric_acid = 1000.0, lithium = 2.0, ph = 7.2, dissolved_oxygen = 0.005;
   double temp_kelvin = temperature + 273.15, ref_kelvin = 320.0 + 273.15;
-  double temp_factor = exp(-65000.0 / (8.314 * temp_kelvin)) / exp(-65000.0 / (8.314 * ref_kelvin));
+  double temp_factor = npd_exp(-65000.0 / (8.314 * temp_kelvin)) / npd_exp(-65000.0 / (8.314 * ref_kelvin));
   double boric_acid_factor = 1.0 / (1.0 + boric_acid / 1000.0 * 0.5);
   double lithium_factor = npd_pymax(0.5, 1.0 + (lithium - 2.0) * 0.1);
   double ph_factor = 1.0 + 0.5 * fabs(ph - 7.2);
   double velocity_factor = npd_clip(npd_powc(flow_velocity / 5.0, -0.6), 0.5, 2.0);
   double oxygen_factor = 1.0 + dissolved_oxygen * 10.0;
-  double saturation_factor = exp(-g->scale_thickness / 2.0);
+  double saturation_factor = npd_exp(-g->scale_thickness / 2.0);
   double formation_rate = 0.001 * temp_factor * boric_acid_factor * lithium_factor * ph_factor *
                           velocity_factor * oxygen_factor * saturation_factor;
   formation_rate = npd_clip(formation_rate, 0.0, 0.1);
@@ -187,7 +187,7 @@ NPD_FN void npd_sg_update(npb_sg_t *g, const npb_params_t *P, double primary_tem
   double delta_t2 = primary_temp_out - sat_temp;
   double lmtd;
   if (fabs(delta_t1 - delta_t2) < 1.0) lmtd = (delta_t1 + delta_t2) / 2.0;
-  else lmtd = (delta_t1 - delta_t2) / log(delta_t1 / delta_t2);
+  else lmtd = (delta_t1 - delta_t2) / npd_log(delta_t1 / delta_t2);
   double flow_factor = npd_powc(primary_flow / P->sg_primary_design_flow, 0.8);
   double h_primary = P->sg_primary_htc * flow_factor;
   double pressure_factor = npd_powc(g->secondary_pressure / P->sg_design_pressure_secondary, 0.15);
@@ -255,7 +255,7 @@ NPD_FN void npd_sg_update(npb_sg_t *g, const npb_params_t *P, double primary_tem
   double steam_demand_factor = (P->sg_secondary_design_flow > 0) ? actual_steam_flow / P->sg_secondary_design_flow : 0.0;
   equilibrium_pressure += -steam_demand_factor * 0.5;
   equilibrium_pressure = npd_clip(equilibrium_pressure, 3.0, 8.5);
-  double decay_factor = exp(-dt / 60.0);
+  double decay_factor = npd_exp(-dt / 60.0);
   double base_new_pressure = equilibrium_pressure + (p - equilibrium_pressure) * decay_factor;
   double pressure_corrections = 0.0;
   if (actual_feedwater_flow < 0.1 && actual_steam_flow > 100.0) {

@@ -17,7 +17,7 @@ NPD_FN double npd_tsat_antoine(double pressure_mpa) {
   if (pressure_mpa <= 0.001) return 10.0;
   const double A = 8.07131, B = 1730.63, C = 233.426;
   double pressure_bar = npd_clip(pressure_mpa * 10.0, 0.01, 100.0);
-  double temp_c = B / (A - log10(pressure_bar)) - C;
+  double temp_c = B / (A - npd_log10(pressure_bar)) - C;
   return npd_clip(temp_c, 10.0, 374.0);
 }
 /* _saturation_enthalpy_vapor  stage_system.py:468-473 */
