@@ -96,6 +96,18 @@ __device__ __forceinline__ void npd_st_store(const S &s, const npd_stage_t &st, 
 #pragma unroll
   for (int k = 0; k < NI; k++) *NPD_I32P(int32_t, ibase + k, st.lane4) = q[k];
 }
+template <int NF, int NI, typename S>
+__device__ __forceinline__ void npd_st_load(S &s, const npd_stage_t &st, int fbase, int ibase) {
+  double *d = reinterpret_cast<double *>(&s);
+#pragma unroll
+  for (int k = 0; k < NF; k++) d[k] = *NPD_F64P(const double, fbase + k, st.lane8);
+  int32_t *q = reinterpret_cast<int32_t *>(d + NF);
+#pragma unroll
+  for (int k = 0; k < NI; k++) q[k] = *NPD_I32P(const int32_t, ibase + k, st.lane4);
+}
+#define NPD_ST_LOAD(T, stype, s, inst) \
+  npd_st_load<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
+                                                     NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32)
 #define NPD_ST_STORE(T, stype, s, inst) \
   npd_st_store<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
                                                       NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32)
@@ -357,6 +369,15 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     NPD_CONSUME(TURB, npb_turb_t, t, 0);
     NPD_LDS_DRAIN();
     NPD_DMA(TSTG, 0, 0);
+    /* the condenser, both WaterChemistry instances and the pH controller go to REGISTERS now, by plain loads
+     * issued behind the stage-array DMA: vector memory completes in issue order, so they have long landed
+     * when pass C's 70 stores are still draining, and the condenser needs neither an LDS-DMA issued into a
+     * full store queue after pass C (measured: 17k cycles of blocked issue) nor a wait for it */
+    npb_cond_t cd; npb_chem_t ch; npb_chem_t ch0; npb_ph_t ph;
+    NPD_ST_LOAD(COND, npb_cond_t, cd, 0);
+    NPD_ST_LOAD(CHEM, npb_chem_t, ch, 1);
+    NPD_ST_LOAD(CHEM, npb_chem_t, ch0, 0);
+    NPD_ST_LOAD(PH, npb_ph_t, ph, 0);
     if (!(NPB_ABLATE & 4)) npd_turbine_update(&t, st, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
                        load_demand, 0.007, dt / 60.0, &tr);
     NPD_STAMP(18);
@@ -371,22 +392,12 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       }
     }
     npd_condenser_result_t cr;
-    npb_chem_t ch0; npb_ph_t ph;
     {
-      npb_cond_t cd; npb_chem_t ch;
-      /* boundary: the condenser group was staged by npd_turbine_update right after the stage pass */
-      NPD_DMA_WAIT();
       NPD_ST_STORE(TURB, npb_turb_t, t, 0);
-      NPD_CONSUME(COND, npb_cond_t, cd, NPD_LS_COND);
-      NPD_CONSUME(CHEM, npb_chem_t, ch, NPD_LS_CHEM1);
-      NPD_LDS_DRAIN();
       if (!(NPB_ABLATE & 8)) npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
                            cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr);
       NPD_ST_STORE(COND, npb_cond_t, cd, 0);
       NPD_ST_STORE(CHEM, npb_chem_t, ch, 1);
-      NPD_CONSUME(CHEM, npb_chem_t, ch0, NPD_LS_CHEM0);
-      NPD_CONSUME(PH, npb_ph_t, ph, NPD_LS_PH);
-      NPD_LDS_DRAIN();
     }
     condenser_pressure = cr.condenser_pressure;
     NPD_STAMP(19);

@@ -132,24 +132,10 @@ __device__ __forceinline__ void npd_consume(S &s, const double *lds, int ls) {
 #define NPD_LS_SEC (NPD_LS_PRIM + NPD_SLOTS(PRIM))
 #define NPD_LS_FW 0
 #define NPD_LS_PUMP0 (NPD_LS_FW + NPD_SLOTS(FW))
-#define NPD_LS_COND 0
-#define NPD_LS_CHEM1 (NPD_LS_COND + NPD_SLOTS(COND))
-#define NPD_LS_CHEM0 (NPD_LS_CHEM1 + NPD_SLOTS(CHEM))
-#define NPD_LS_PH (NPD_LS_CHEM0 + NPD_SLOTS(CHEM))
 
 static_assert(NPD_LS_SEC + NPD_SLOTS(SEC) <= NPB_STAGE_SLOTS, "prim + sec must fit the staging region");
 static_assert(NPD_LS_PUMP0 + NPD_SLOTS(PUMP) <= NPB_STAGE_SLOTS, "fw + pump must fit the staging region");
 static_assert(NPD_SLOTS(SG) <= NPB_STAGE_SLOTS && NPD_SLOTS(TURB) <= NPB_STAGE_SLOTS, "sg / turb must fit");
 static_assert(NPD_SLOTS(TSTG) <= NPB_STAGE_SLOTS, "turbine stage arrays must fit the staging region");
-static_assert(NPD_LS_PH + NPD_SLOTS(PH) <= NPB_STAGE_SLOTS, "condenser + chemistry + pH must fit");
-
-/* condenser, its chemistry, the shared chemistry and the pH controller, staged together right after the
- * turbine stage pass has finished with the stage arrays */
-__device__ __forceinline__ void npd_dma_condenser_group(const npd_stage_t &st) {
-  NPD_DMA(COND, 0, NPD_LS_COND);
-  NPD_DMA(CHEM, 1, NPD_LS_CHEM1);
-  NPD_DMA(CHEM, 0, NPD_LS_CHEM0);
-  NPD_DMA(PH, 0, NPD_LS_PH);
-}
 
 #endif

@@ -477,12 +477,6 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
   npd_stagesys_out_t ss;
   npd_stage_system_update(st, st.lds + threadIdx.x, steam_pressure, steam_temperature, steam_flow, load_demand,
                           pressure_stability_factor, dt, &ss);
-  /* the stage arrays are consumed: stage the condenser group into the same LDS region while the rotor,
-   * bearing and protection arithmetic below runs */
-  NPD_STAMP(29);
-  NPD_LDS_DRAIN();
-  NPD_STAMP(30);
-  npd_dma_condenser_group(st);
   NPD_STAMP(15);
   double stage_power_mw = ss.total_power;
   double applied_torque = stage_power_mw * 1e6 / (2 * NPD_PI * 3600 / 60);
