@@ -48,6 +48,9 @@ int npb_num_plants(const NpbHandle *h) { return h ? h->n_plants : 0; }
 int npb_create(const npb_params_t *params, int n_plants, int device, NpbHandle **out) {
   if (!out || n_plants <= 0) return fail(nullptr, NPB_EINVAL, "npb_create: bad arguments");
   *out = nullptr;
+  /* the step kernel addresses a column as (one 64-bit base) + (32-bit byte offset), nuclear_sim_amd/csrc/npd_stage.h */
+  if ((((size_t)n_plants + 63) / 64 * 64) * NPB_TOTAL_F64 * sizeof(double) >= ((size_t)1 << 32))
+    return fail(nullptr, NPB_EINVAL, "npb_create: more than 4 GiB of fp64 state per handle (about one million plants); use several handles");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) return fail(nullptr, NPB_EHIP, "npb_create: no HIP device", e);

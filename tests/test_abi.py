@@ -78,3 +78,16 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), (dirpath, f)
+
+
+def test_create_rejects_arena_beyond_32bit_offsets():
+    """npb_create refuses, before touching any device, a handle whose fp64 arena would pass 4 GiB
+    (the kernel's column offsets are 32-bit)."""
+    import ctypes
+    from nuclear_sim_amd import _lib
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    rc = L.npb_create(None, 1_100_000, 0, ctypes.byref(h))
+    assert rc != 0 and not h.value
+    L.npb_last_error.restype = ctypes.c_char_p
+    assert b"4 GiB" in L.npb_last_error(None)
