@@ -51,7 +51,10 @@ class HeatSourceNoise:
     RandomState reproduces it exactly.  Drawn on the host in blocks."""
 
     def __init__(self, seeds: Sequence[int], block: int = 256):
-        self._rngs = [np.random.RandomState(int(s)) for s in seeds]
+        # one generator per DISTINCT seed (the data-gen runner seeds every plant's heat source with 42, so a
+        # 262 144-plant batch needs one stream, not 262 144 generator objects)
+        uniq, self._index = np.unique(np.asarray(seeds, dtype=np.int64), return_inverse=True)
+        self._rngs = [np.random.RandomState(int(s)) for s in uniq]
         self._block = block
         self._buf = None
         self._pos = block
@@ -60,7 +63,7 @@ class HeatSourceNoise:
         if self._pos >= self._block:
             self._buf = np.stack([r.standard_normal(self._block) for r in self._rngs])
             self._pos = 0
-        out = np.ascontiguousarray(self._buf[:, self._pos])
+        out = np.ascontiguousarray(self._buf[self._index, self._pos])
         self._pos += 1
         return out
 
@@ -136,6 +139,20 @@ class BatchedPlantEnv:
         if noise_enabled and noise_seeds is not None:
             self._noise = HeatSourceNoise(noise_seeds)
         self._keep = []
+
+    @classmethod
+    def action_test(cls, action: str, seeds: Sequence[int], dt: float = 5.0, device: int = 0, randomize: bool = True,
+                    params: Optional[dict] = None) -> "BatchedPlantEnv":
+        """One plant per seed, as data_gen's MaintenanceScenarioRunner builds them for
+        ``compose_action_test_scenario(action, randomize=True, randomization_seed=seed)``
+        (maintenance_scenario_runner.py:210-244): dt in minutes, ConstantHeatSource with 0.1 % noise seeded 42,
+        automatic maintenance on, initial conditions from nuclear_sim_amd.scenarios (BASELINE config 4)."""
+        from . import scenarios
+        env = cls(len(seeds), dt=dt, heat_source="constant", noise_enabled=True, noise_std_percent=0.1,
+                  noise_seeds=[42] * len(seeds), device=device, maintenance=True, params=params)
+        eff = float(env.get_field("pump.lubrication_effectiveness")[0].item())
+        env.set_fields(scenarios.action_test_fields(action, seeds, eff, randomize=randomize))
+        return env
 
     # ------------------------------------------------------------------ helpers
     def close(self):

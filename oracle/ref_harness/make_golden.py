@@ -95,5 +95,24 @@ def main(only=None):
         print(sc["name"], "steps", T, "dones", int(ref["done"].sum()), "elec", float(ref["obs"][-1, 12] * 1100))
 
 
+def make_ic_fixture(action="oil_top_off", seeds=tuple(range(12))):
+    """tests/golden/ic_<action>.npz: the initial state (every schema column) of the simulator that
+    MaintenanceScenarioRunner builds for compose_action_test_scenario(action, randomize=True, randomization_seed=s),
+    one row per seed, plus row 0 = the un-randomised catalog entry.  Pins nuclear_sim_amd/scenarios.py."""
+    from . import refsim
+    cols = SCHEMA.columns()
+    rows = []
+    for s in (None,) + tuple(seeds):
+        _runner, sim = refsim.make_runner_sim(action=action, duration_hours=2.0, randomization_seed=s)
+        rows.append([trace._val(sim, c[3]) for c in cols])
+    np.savez_compressed(os.path.join(OUT, "ic_%s.npz" % action), state=np.array(rows), seeds=np.array(seeds),
+                        labels=np.array([c[2] for c in cols]), kinds=np.array([c[0] for c in cols]),
+                        paths=np.array([c[3] for c in cols]))
+    print("ic_%s: %d seeds" % (action, len(seeds)))
+
+
 if __name__ == "__main__":
-    main(only=set(sys.argv[1:]) or None)
+    if sys.argv[1:] == ["ic"]:
+        make_ic_fixture()
+    else:
+        main(only=set(sys.argv[1:]) or None)

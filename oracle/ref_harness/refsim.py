@@ -128,16 +128,19 @@ def make_sim(dt=1.0, heat_source="constant", noise=False, noise_std_percent=0.1,
     return sim
 
 
-def make_runner_sim(action="oil_top_off", duration_hours=4.0, feedwater_ic=None):
+def make_runner_sim(action="oil_top_off", duration_hours=4.0, feedwater_ic=None, randomization_seed=None):
     """The simulator as data_gen's MaintenanceScenarioRunner builds it for an action-test scenario
     (maintenance_scenario_runner.py:210-244): composed config, dt = 5 min, state management and
     AutoMaintenanceSystem on.  feedwater_ic overrides entries of
-    secondary_system.feedwater.initial_conditions (e.g. pump_oil_levels)."""
+    secondary_system.feedwater.initial_conditions (e.g. pump_oil_levels); randomization_seed switches the
+    composer's per-seed randomisation on (comprehensive_composer.py:183-252)."""
     setup()
     with quiet():
         from data_gen.config_engine.composers.comprehensive_composer import ComprehensiveComposer
         from data_gen.runners.maintenance_scenario_runner import MaintenanceScenarioRunner
-        cfg = ComprehensiveComposer().compose_action_test_scenario(target_action=action, duration_hours=duration_hours)
+        cfg = ComprehensiveComposer().compose_action_test_scenario(
+            target_action=action, duration_hours=duration_hours, randomize=randomization_seed is not None,
+            randomization_seed=randomization_seed)
         for k, v in (feedwater_ic or {}).items():
             cfg["secondary_system"]["feedwater"]["initial_conditions"][k] = v
         runner = MaintenanceScenarioRunner(cfg, verbose=False)

@@ -160,6 +160,37 @@ def test_hip_maintenance_matches_oracle_on_random_batch(oracle_lib):
     assert done_.max() <= (T * 5.0) / 15.0 + 1             # at most one execution per 15-min check
 
 
+def test_config4_randomized_oil_top_off_scenario(oracle_lib):
+    """BASELINE config 4 at test size: plants with per-seed randomised initial conditions from the scenario
+    catalog (nuclear_sim_amd.scenarios), the data-gen runner's settings (dt = 5 min, seeded heat-source noise,
+    automatic maintenance), 2 h; every column against the oracle started from the same columns, and the
+    event counts bit-exact."""
+    from nuclear_sim_amd.env import BatchedPlantEnv
+    from nuclear_sim_amd import scenarios
+    n, T = 700, 24
+    seeds = list(range(1000, 1000 + n))
+    env = BatchedPlantEnv.action_test("oil_top_off", seeds)
+    P = oracle_lib.Params(); P.dt = 5.0; P.hs_noise_enabled = 1; P.maint_enabled = 1
+    ora = oracle_lib.OraclePlants(n, P)
+    eff = float(ora.get("pump.lubrication_effectiveness"))
+    for key, v in scenarios.action_test_fields("oil_top_off", seeds, eff).items():
+        name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
+        ora.set(name, v, instance=inst, k=k)
+    z = np.random.RandomState(42).standard_normal(T)          # every plant's heat source is seeded 42
+    for t in range(T):
+        ora.step(setpoint=np.full(n, 90.0), noise_z=np.full(n, z[t]))
+        obs, rew, done, info = env.step(power_setpoint=np.full(n, 90.0))   # noise drawn by the env's own seeded streams
+    f, i = _host_state(env)
+    of, oi = ora.state_all()
+    for kind, slot, label, _p in env_cols():
+        if kind == "i32":
+            assert np.array_equal(i[slot, :n], oi[:, slot]), label
+        else:
+            np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)
+    created = env.get_field("maint.work_orders_created").cpu().numpy()
+    assert created.max() >= 1 and created.min() == 0, "the scenario mix has plants that trigger within 2 h and plants that do not"
+
+
 def env_cols():
     from nuclear_sim_amd.schema import SCHEMA
     return SCHEMA.columns()

@@ -1,0 +1,72 @@
+"""CPU: nuclear_sim_amd/scenarios.py (vectorised initial conditions of the data-gen action-test scenario,
+SURVEY.md 8f-2) against the reference's own constructor: tests/golden/ic_oil_top_off.npz holds the initial
+state of the simulator MaintenanceScenarioRunner builds for compose_action_test_scenario("oil_top_off",
+randomize=True, randomization_seed=s), for 12 seeds plus the un-randomised catalog entry (row 0)."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN_DIR
+from nuclear_sim_amd.schema import SCHEMA
+from nuclear_sim_amd import scenarios
+
+
+def _load():
+    z = np.load(os.path.join(GOLDEN_DIR, "ic_oil_top_off.npz"), allow_pickle=False)
+    cols = SCHEMA.columns()
+    idx = {str(p): j for j, p in enumerate(z["paths"]) if str(p)}
+    st = np.full((z["state"].shape[0], len(cols)), np.nan)
+    for j, c in enumerate(cols):
+        if c[3] in idx:
+            st[:, j] = z["state"][:, idx[c[3]]]
+    return st, [int(s) for s in z["seeds"]], cols
+
+
+def _apply(oracle_lib, fields, n):
+    o = oracle_lib.OraclePlants(n, oracle_lib.Params())
+    for key, v in fields.items():
+        if isinstance(key, tuple):
+            name, inst = key[0], key[1]
+            k = key[2] if len(key) > 2 else 0
+        else:
+            name, inst, k = key, 0, 0
+        o.set(name, v, instance=inst, k=k)
+    return o
+
+
+def _check(o, ref_rows, cols):
+    F, I = o.state_all()
+    bad = []
+    for row, ref in enumerate(ref_rows):
+        for (kind, slot, label, _p), v in zip(cols, ref):
+            if np.isnan(v) or label.startswith("maint"):
+                continue
+            mine = F[row, slot] if kind == "f64" else I[row, slot]
+            if not abs(mine - v) <= 1e-12 * abs(v):
+                bad.append((row, label, float(mine), float(v)))
+    assert not bad, "%d mismatching columns, first: %s" % (len(bad), bad[:6])
+
+
+def test_randomized_oil_levels_match_reference(oracle_lib):
+    st, seeds, cols = _load()
+    lv = scenarios.randomized_oil_top_off_levels(seeds)
+    for k in range(4):
+        j = [i for i, c in enumerate(cols) if c[2] == "pump[%d].oil_level" % k][0]
+        np.testing.assert_array_equal(lv[:, k], st[1:, j])
+
+
+def test_action_test_state_matches_reference_constructor(oracle_lib):
+    st, seeds, cols = _load()
+    eff = oracle_lib.OraclePlants(1, oracle_lib.Params()).get("pump.lubrication_effectiveness")
+    # row 0: catalog entry as is; rows 1..: randomised per seed
+    o = _apply(oracle_lib, scenarios.action_test_fields("oil_top_off", [0], float(eff), randomize=False), 1)
+    _check(o, st[:1], cols)
+    o = _apply(oracle_lib, scenarios.action_test_fields("oil_top_off", seeds, float(eff)), len(seeds))
+    _check(o, st[1:], cols)
+
+
+def test_scenario_mix_follows_the_catalog_probabilities():
+    lv = scenarios.randomized_oil_top_off_levels(range(4000))[:, 0]
+    low, mid, high = (lv < 60.0).mean(), ((lv > 60.0) & (lv < 61.3)).mean(), (lv > 61.4).mean()
+    assert abs(low - 0.3) < 0.03 and abs(mid - 0.4) < 0.03 and abs(high - 0.3) < 0.03
