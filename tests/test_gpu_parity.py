@@ -93,8 +93,10 @@ def test_hip_matches_oracle_on_random_batch(oracle_lib, heat_source, mode):
     P.mode = 1 if mode == "primary_sg" else 0
     ora = oracle_lib.OraclePlants(n, P)
     # heterogeneous initial conditions through the field API on both sides
-    ics = {"prim.coolant_flow_rate": rng.uniform(15000, 25000, n), "prim.control_rod_position": rng.uniform(80, 100, n),
-           "prim.fuel_temperature": rng.uniform(400, 600, n)}
+    flow0 = rng.uniform(15000, 25000, n); flow0[::17] = rng.uniform(3000, 4900, len(flow0[::17]))      # low-flow scrams
+    fuel0 = rng.uniform(400, 600, n); fuel0[5::23] = rng.uniform(1210, 1400, len(fuel0[5::23]))         # fuel-temperature scrams
+    ics = {"prim.coolant_flow_rate": flow0, "prim.control_rod_position": rng.uniform(80, 100, n),
+           "prim.fuel_temperature": fuel0, "prim.coolant_pressure": np.where(rng.random(n) < 0.05, 17.4, 15.5)}
     per_inst = {("pump.oil_level", k): rng.uniform(8.0, 100.0, n) for k in range(4)}
     per_inst.update({("sg.water_level", k): rng.uniform(11.5, 13.5, n) for k in range(3)})
     for name, v in ics.items():
@@ -122,6 +124,77 @@ def test_hip_matches_oracle_on_random_batch(oracle_lib, heat_source, mode):
                 assert int(i[slot, pl]) == int(oi[slot]), (label, pl)
             else:
                 assert abs(f[slot, pl] - of[slot]) <= RTOL * abs(of[slot]) + ATOL_SMALL, (label, pl, f[slot, pl], of[slot])
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 129])
+def test_ragged_batch_sizes(oracle_lib, n):
+    """Batch sizes around the wave width (padding lanes must neither disturb live lanes nor be written to outputs)."""
+    import torch
+    rng = np.random.default_rng(n)
+    env = _env(n=n, noise_enabled=True)
+    P = oracle_lib.Params(); P.hs_noise_enabled = 1
+    ora = oracle_lib.OraclePlants(n, P)
+    guard_obs = torch.full((n + 64, 22), -7.0, dtype=torch.float64, device=env.device)
+    env._obs = guard_obs[:n]                       # output buffer with a guard band behind it
+    for t in range(12):
+        z = rng.standard_normal(n); sp = rng.uniform(60, 100, n)
+        o_obs, o_rew, o_done, o_flags, o_info = ora.step(setpoint=sp, noise_z=z)
+        obs, rew, done, info = env.step(power_setpoint=sp, noise_z=z)
+        np.testing.assert_allclose(obs.cpu().numpy(), o_obs, rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(rew.cpu().numpy(), o_rew, rtol=RTOL, atol=1e-9)
+    assert bool((guard_obs[n:] == -7.0).all()), "rows beyond n_plants were written"
+
+
+def test_config2_reactor_and_sg_only_at_4096(oracle_lib):
+    """BASELINE config 2 shape: 4096 plants, point-kinetics heat source + steam generators only, dt = 0.1, random
+    actuator actions (the reference integrates with clipped Euler; there is no RK4 to compare with)."""
+    n, T = 4096, 40
+    rng = np.random.default_rng(4096)
+    env = _env(n=n, dt=0.1, heat_source="reactor", mode="primary_sg")
+    env.set_fields(__import__("nuclear_sim_amd.env", fromlist=["equilibrium_state"]).equilibrium_state())
+    P = oracle_lib.Params(); P.dt = 0.1; P.heat_source = 1; P.mode = 1
+    ora = oracle_lib.OraclePlants(n, P)
+    from nuclear_sim_amd.env import equilibrium_state
+    for key, v in equilibrium_state().items():
+        name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
+        ora.set(name, v, instance=inst, k=k)
+    rods = rng.uniform(85, 100, n)
+    env.set_field("prim.control_rod_position", rods); ora.set("prim.control_rod_position", rods)
+    for t in range(T):
+        acts = rng.choice([0, 1, 2, 3, 4, 5, 8, 9, 10], size=n).astype(np.int32); mags = rng.uniform(0, 1, n)
+        o_obs, o_rew, o_done, o_flags, o_info = ora.step(action=acts, magnitude=mags)
+        obs, rew, done, info = env.step(action=acts, magnitude=mags)
+        np.testing.assert_allclose(obs.cpu().numpy(), o_obs, rtol=RTOL, atol=1e-12, err_msg="obs step %d" % t)
+        assert np.array_equal(done.cpu().numpy(), o_done)
+    f, i = _host_state(env)
+    of, oi = ora.state_all()
+    for kind, slot, label, _p in env_cols():
+        if kind == "i32":
+            assert np.array_equal(i[slot, :n], oi[:, slot]), label
+        else:
+            np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)
+
+
+def test_long_run_stays_on_the_oracle(oracle_lib):
+    """1500 steps of one wave of heterogeneous plants: the last-bit differences of the device arithmetic
+    (reciprocal multiplication, lean exp/log) must not grow past the parity budget."""
+    n, T = 64, 1500
+    rng = np.random.default_rng(15)
+    env = _env(n=n, noise_enabled=True)
+    P = oracle_lib.Params(); P.hs_noise_enabled = 1
+    ora = oracle_lib.OraclePlants(n, P)
+    lv = rng.uniform(30, 100, n)
+    env.set_field("pump.oil_level", lv, instance=1); ora.set("pump.oil_level", lv, instance=1)
+    for t in range(T):
+        z = rng.standard_normal(n); sp = 85.0 + 15.0 * np.sin(t / 40.0 + np.arange(n))
+        ora.step(setpoint=sp, noise_z=z); env.step(power_setpoint=sp, noise_z=z)
+    f, i = _host_state(env)
+    of, oi = ora.state_all()
+    for kind, slot, label, _p in env_cols():
+        if kind == "i32":
+            assert np.array_equal(i[slot, :n], oi[:, slot]), label
+        else:
+            np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)
 
 
 def test_hip_maintenance_matches_oracle_on_random_batch(oracle_lib):
