@@ -11,11 +11,13 @@
  *   primary -> coupling -> feedwater (4 pumps, one at a time) -> 3 steam generators (one at a time)
  *   -> turbine -> condenser -> electrical-power gates -> feedback -> observation / reward / done
  *
- * Each phase loads its section struct from the SoA columns, updates it in registers and stores it
- * back; only the ~30 coupling scalars stay live between phases.  No MFMA (there is no dense
- * contraction on this path), no inter-lane communication except the LDS transpose that turns the
- * wave's 64 x 22 observation block into coalesced row-major stores.  Plants are independent, so
- * blocks never share data and the block -> XCD placement cannot matter.
+ * Each phase's section struct reaches the registers through the LDS staging pipeline of npd_stage.h (LDS-DMA
+ * one phase ahead, because one wave per SIMD has nothing else to hide HBM latency behind), is updated in
+ * registers and stored back at the next phase boundary; only the ~30 coupling scalars stay live between
+ * phases.  No MFMA (there is no dense contraction on this path), no inter-lane communication except the
+ * turbine stage pass's ballot and the LDS transposes that turn the wave's 64 x 22 observation block into
+ * coalesced row-major stores.  Plants are independent, so blocks never share data and the block -> XCD
+ * placement cannot matter.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,10 +46,6 @@ extern "C" __attribute__((visibility("default"))) int npb_debug_set_stamp_buffer
 #include "npd_init.h"
 #include "npb_kernels.h"
 
-/* diagnostic builds only (-DNPB_ABLATE=mask): skip phases to attribute kernel time. 1 FW, 2 SG, 4 turbine, 8 condenser */
-#ifndef NPB_ABLATE
-#define NPB_ABLATE 0
-#endif
 #define NPB_OBS_PAD 23 /* LDS row stride in doubles: 22 + 1 keeps the transpose at <= 2-way bank conflicts */
 
 /* ---- section <-> SoA column movers.  A section struct is NF64 doubles followed by NI32 int32s
@@ -277,7 +275,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
 #pragma unroll 1
     for (int i = 0; i < NPB_NUM_PUMPS; i++) {
       NPD_STAMP(2 + i);
-      if (!(NPB_ABLATE & 1)) npd_fw_pump_step(&pm, &fw, &acc, i, n_prev_running, flow_per_pump, &sc, dt);
+      npd_fw_pump_step(&pm, &fw, &acc, i, n_prev_running, flow_per_pump, &sc, dt);
       /* boundary: pump i -> HBM, pump i+1 (staged during this pump's arithmetic) -> the same registers,
        * then stage pump i+2, or SG 0 once the last pump is on its way */
       NPD_DMA_WAIT();
@@ -334,7 +332,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       NPD_STAMP(8 + i);
       npd_sg_result_t r;
       r.heat_transfer_rate = 0.0; r.steam_flow_rate = 0.0; r.thermal_efficiency = 0.0;
-      if (!(NPB_ABLATE & 2)) npd_sg_update(&g, &P, c_inlet, c_outlet, c_flow, demand, fwflow, actual_feedwater_temp, dt * 60, &r);
+      npd_sg_update(&g, &P, c_inlet, c_outlet, c_flow, demand, fwflow, actual_feedwater_temp, dt * 60, &r);
       sg_total_thermal += r.heat_transfer_rate; sg_total_steam += r.steam_flow_rate;
       sg_ap += g.secondary_pressure; sg_at += g.secondary_temperature; sg_aq += g.steam_quality;
       if (i == 0) sg_pressures[0] = g.secondary_pressure;
@@ -378,7 +376,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     NPD_ST_LOAD(CHEM, npb_chem_t, ch, 1);
     NPD_ST_LOAD(CHEM, npb_chem_t, ch0, 0);
     NPD_ST_LOAD(PH, npb_ph_t, ph, 0);
-    if (!(NPB_ABLATE & 4)) npd_turbine_update(&t, st, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
+    npd_turbine_update(&t, st, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
                        load_demand, 0.007, dt / 60.0, &tr);
     NPD_STAMP(18);
     /* ================= phase 4: condenser (:591-621) ================= */
@@ -394,7 +392,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     npd_condenser_result_t cr;
     {
       NPD_ST_STORE(TURB, npb_turb_t, t, 0);
-      if (!(NPB_ABLATE & 8)) npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
+      npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
                            cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr);
       NPD_ST_STORE(COND, npb_cond_t, cd, 0);
       NPD_ST_STORE(CHEM, npb_chem_t, ch, 1);
