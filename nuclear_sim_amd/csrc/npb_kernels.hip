@@ -109,6 +109,71 @@ __device__ __forceinline__ void npd_st_load(S &s, const npd_stage_t &st, int fba
 #define NPD_ST_STORE(T, stype, s, inst) \
   npd_st_store<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
                                                       NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32)
+/* ---- unchanged-column elision.  Measured on the bench workload (and on a reactor-heat-source batch): about a
+ * quarter of the carried columns keep their exact bits over a step for every plant of a wave -- flags, status
+ * codes, protection timers at rest, pump pressures and cavitation state in normal operation, the spare pump,
+ * the kinetics block under the constant heat source.  A global store occupies the lone wave of a SIMD for its
+ * transfer time, a bitwise compare + wave ballot costs three instructions, so the
+ * members named in the masks below are stored only if some lane's bits changed.  Which members are listed is a
+ * performance choice only: the compare is on the bit patterns, so the arena always ends up with exactly the
+ * bits a plain store would have written.  "old" is the copy of the section as it was staged in. */
+template <int NF, int NI, typename S>
+__device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, const npd_stage_t &st, int fbase, int ibase,
+                                                   uint64_t fmask, uint32_t imask) {
+  const double *d = reinterpret_cast<const double *>(&s), *od = reinterpret_cast<const double *>(&old);
+#pragma unroll
+  for (int k = 0; k < NF; k++) {
+    if ((fmask >> k) & 1) {
+      if (__builtin_amdgcn_ballot_w64(__double_as_longlong(d[k]) != __double_as_longlong(od[k])) != 0)
+        *NPD_F64P(double, fbase + k, st.lane8) = d[k];
+    } else {
+      *NPD_F64P(double, fbase + k, st.lane8) = d[k];
+    }
+  }
+  const int32_t *q = reinterpret_cast<const int32_t *>(d + NF), *oq = reinterpret_cast<const int32_t *>(od + NF);
+#pragma unroll
+  for (int k = 0; k < NI; k++) {
+    if ((imask >> k) & 1) {
+      if (__builtin_amdgcn_ballot_w64(q[k] != oq[k]) != 0) *NPD_I32P(int32_t, ibase + k, st.lane4) = q[k];
+    } else {
+      *NPD_I32P(int32_t, ibase + k, st.lane4) = q[k];
+    }
+  }
+}
+#define NPD_ST_STORE_ELIDE(T, stype, s, old, inst) \
+  npd_st_store_elide<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, old, st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
+                                                            NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32, NPD_ELIDE_##T##_F, ~0u)
+#define NPD_FB(stype, m) (1ull << NPB_F64_SLOT(stype, m))
+#define NPD_FBN(stype, m, n) ((((1ull << (n)) - 1)) << NPB_F64_SLOT(stype, m))
+static constexpr uint64_t NPD_ELIDE_PRIM_F =
+    NPD_FB(npb_prim_t, neutron_flux) | NPD_FB(npb_prim_t, reactivity) | NPD_FBN(npb_prim_t, precursors, 6) |
+    NPD_FB(npb_prim_t, coolant_flow_rate) | NPD_FB(npb_prim_t, coolant_void_fraction) | NPD_FB(npb_prim_t, steam_pressure) |
+    NPD_FB(npb_prim_t, feedwater_flow_rate) | NPD_FB(npb_prim_t, control_rod_position) | NPD_FB(npb_prim_t, steam_valve_position) |
+    NPD_FB(npb_prim_t, boron_concentration) | NPD_FB(npb_prim_t, xenon_concentration) | NPD_FB(npb_prim_t, iodine_concentration) |
+    NPD_FB(npb_prim_t, samarium_concentration) | NPD_FB(npb_prim_t, burnable_poison_worth) | NPD_FB(npb_prim_t, fuel_burnup) |
+    NPD_FB(npb_prim_t, total_reactivity_pcm) | NPD_FB(npb_prim_t, hs_filtered_noise_mw);
+static constexpr uint64_t NPD_ELIDE_SG_F = NPD_FB(npb_sg_t, water_level);
+static constexpr uint64_t NPD_ELIDE_PUMP_F =
+    NPD_FB(npb_pump_t, suction_pressure) | NPD_FB(npb_pump_t, discharge_pressure) | NPD_FB(npb_pump_t, npsh_available) |
+    NPD_FB(npb_pump_t, differential_pressure) | NPD_FB(npb_pump_t, cavitation_intensity) | NPD_FB(npb_pump_t, cavitation_damage) |
+    NPD_FB(npb_pump_t, cavitation_time) | NPD_FB(npb_pump_t, head_degradation) | NPD_FB(npb_pump_t, seal_leakage_rate) |
+    /* the spare pump */ NPD_FB(npb_pump_t, speed_percent) | NPD_FB(npb_pump_t, speed_setpoint) | NPD_FB(npb_pump_t, flow_rate) |
+    NPD_FB(npb_pump_t, power_consumption) | NPD_FB(npb_pump_t, flow_demand);
+static constexpr uint64_t NPD_ELIDE_FW_F =
+    NPD_FBN(npb_fw_t, previous_level_errors, 3) | NPD_FB(npb_fw_t, cav_accumulated_damage) | NPD_FB(npb_fw_t, cav_time_in_cavitation) |
+    NPD_FB(npb_fw_t, npsh_low_low_timer) | NPD_FB(npb_fw_t, timer_low_flow) | NPD_FB(npb_fw_t, timer_high_flow) |
+    NPD_FB(npb_fw_t, timer_bearing_temp) | NPD_FB(npb_fw_t, timer_motor_temp) | NPD_FB(npb_fw_t, timer_vibration);
+static constexpr uint64_t NPD_ELIDE_TURB_F =
+    NPD_FB(npb_turb_t, rotor_speed) | NPD_FB(npb_turb_t, thermal_bow) | NPD_FBN(npb_turb_t, bearing_metal_temp, 4) |
+    NPD_FBN(npb_turb_t, bearing_wear_factor, 4) | NPD_FB(npb_turb_t, timer_overspeed) | NPD_FB(npb_turb_t, timer_vibration) |
+    NPD_FB(npb_turb_t, timer_bearing_temp) | NPD_FB(npb_turb_t, total_power_output) | NPD_FB(npb_turb_t, vibration_displacement);
+static constexpr uint64_t NPD_ELIDE_CHEM_F =
+    NPD_FB(npb_chem_t, dissolved_oxygen) | NPD_FB(npb_chem_t, corrosion_inhibitor_level) | NPD_FB(npb_chem_t, treatment_efficiency);
+static constexpr uint64_t NPD_ELIDE_PH_F = NPD_FB(npb_ph_t, morpholine_tank_level) | NPD_FB(npb_ph_t, pending_morpholine_dose);
+static constexpr uint64_t NPD_ELIDE_COND_F =
+    NPD_FB(npb_cond_t, vibration_damage) | NPD_FB(npb_cond_t, condenser_pressure) | NPD_FB(npb_cond_t, air_partial_pressure) |
+    NPD_FB(npb_cond_t, air_mass_in_condenser);
+
 #define NPD_ST_F64(T, stype, member, inst, k) \
   (*NPD_F64P(double, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64 + NPB_F64_SLOT(stype, member) + (k), st.lane8))
 #define NPD_ST_I32(T, stype, member, inst) \
@@ -190,6 +255,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   int has_prev;
   NPD_DMA_WAIT();
   NPD_CONSUME(PRIM, npb_prim_t, s, NPD_LS_PRIM);
+  const npb_prim_t s_old = s; /* for the unchanged-column elision; only the members named in its mask stay live */
   cooling_water_temperature = NPD_STAGED_F64(SEC, npb_sec_t, cooling_water_temperature, 0, NPD_LS_SEC);
   prev_feedwater_temp = NPD_STAGED_F64(SEC, npb_sec_t, previous_feedwater_temp, 0, NPD_LS_SEC);
   operating_hours = NPD_STAGED_F64(SEC, npb_sec_t, operating_hours, 0, NPD_LS_SEC);
@@ -246,7 +312,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   double fw_total_flow = 0.0, fw_total_power = 0.0;
   int fw_available = 1;
   uint32_t trip_flags = 0;
-  npb_sg_t g;
+  npb_sg_t g, g_old;
 
   NPD_STAMP(1);
   if (full) {
@@ -255,9 +321,11 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     npb_pump_t pm;
     /* boundary: fw + pump 0 are staged; store the primary section, stage pump 1 */
     NPD_DMA_WAIT();
-    NPD_ST_STORE(PRIM, npb_prim_t, s, 0);
+    NPD_ST_STORE_ELIDE(PRIM, npb_prim_t, s, s_old, 0);
     NPD_CONSUME(FW, npb_fw_t, fw, NPD_LS_FW);
     NPD_CONSUME(PUMP, npb_pump_t, pm, NPD_LS_PUMP0);
+    const npb_fw_t fw_old = fw;
+    npb_pump_t pm_old = pm;
     NPD_LDS_DRAIN();
     NPD_DMA(PUMP, 1, 0);
     double total_flow_demand = npd_fw_level_control(&fw, prev_levels, prev_flows, prev_quals, dt);
@@ -279,8 +347,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       /* boundary: pump i -> HBM, pump i+1 (staged during this pump's arithmetic) -> the same registers,
        * then stage pump i+2, or SG 0 once the last pump is on its way */
       NPD_DMA_WAIT();
-      NPD_ST_STORE(PUMP, npb_pump_t, pm, i);
-      if (i + 1 < NPB_NUM_PUMPS) NPD_CONSUME(PUMP, npb_pump_t, pm, 0);
+      NPD_ST_STORE_ELIDE(PUMP, npb_pump_t, pm, pm_old, i);
+      if (i + 1 < NPB_NUM_PUMPS) { NPD_CONSUME(PUMP, npb_pump_t, pm, 0); pm_old = pm; }
       NPD_LDS_DRAIN();
       if (i + 2 < NPB_NUM_PUMPS) NPD_DMA(PUMP, i + 2, 0);
       else if (i + 2 == NPB_NUM_PUMPS) NPD_DMA(SG, 0, 0);
@@ -293,15 +361,17 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     trip_flags |= (fwr.pump_trip_mask << 8) | (fw.system_trip_active ? NPB_TRIP_FW_SYSTEM : 0);
     /* boundary: SG 0 -> registers (its DMA ran during pump 3), fw -> HBM, stage SG 1 */
     NPD_DMA_WAIT();
-    NPD_ST_STORE(FW, npb_fw_t, fw, 0);
+    NPD_ST_STORE_ELIDE(FW, npb_fw_t, fw, fw_old, 0);
     NPD_CONSUME(SG, npb_sg_t, g, 0);
+    g_old = g;
     NPD_LDS_DRAIN();
     NPD_DMA(SG, 1, 0);
   } else {
     /* config-2 mode: no feedwater system; boundary straight to SG 0 */
     NPD_DMA_WAIT();
-    NPD_ST_STORE(PRIM, npb_prim_t, s, 0);
+    NPD_ST_STORE_ELIDE(PRIM, npb_prim_t, s, s_old, 0);
     NPD_CONSUME(SG, npb_sg_t, g, 0);
+    g_old = g;
     NPD_LDS_DRAIN();
     NPD_DMA(SG, 1, 0);
   }
@@ -341,11 +411,11 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       if (r.thermal_efficiency > 0.1) sg_effective++;
       /* boundary: SG i -> HBM, SG i+1 -> the same registers, stage SG i+2 / the turbine scalars */
       NPD_DMA_WAIT();
-      NPD_ST_STORE(SG, npb_sg_t, g, i);
+      NPD_ST_STORE_ELIDE(SG, npb_sg_t, g, g_old, i);
       NPD_ST_F64(SEC, npb_sec_t, prev_sg_levels, 0, i) = g.water_level;
       NPD_ST_F64(SEC, npb_sec_t, prev_sg_steam_flows, 0, i) = r.steam_flow_rate;
       NPD_ST_F64(SEC, npb_sec_t, prev_sg_qualities, 0, i) = g.steam_quality;
-      if (i + 1 < NPB_NUM_SG) NPD_CONSUME(SG, npb_sg_t, g, 0);
+      if (i + 1 < NPB_NUM_SG) { NPD_CONSUME(SG, npb_sg_t, g, 0); g_old = g; }
       NPD_LDS_DRAIN();
       if (i + 2 < NPB_NUM_SG) NPD_DMA(SG, i + 2, 0);
       else if (i + 2 == NPB_NUM_SG && full) NPD_DMA(TURB, 0, 0);
@@ -365,6 +435,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
      * land while the lubrication step and stage passes A / B run */
     NPD_DMA_WAIT();
     NPD_CONSUME(TURB, npb_turb_t, t, 0);
+    const npb_turb_t t_old = t;
     NPD_LDS_DRAIN();
     NPD_DMA(TSTG, 0, 0);
     /* the condenser, both WaterChemistry instances and the pH controller go to REGISTERS now, by plain loads
@@ -376,6 +447,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     NPD_ST_LOAD(CHEM, npb_chem_t, ch, 1);
     NPD_ST_LOAD(CHEM, npb_chem_t, ch0, 0);
     NPD_ST_LOAD(PH, npb_ph_t, ph, 0);
+    const npb_cond_t cd_old = cd; const npb_chem_t ch_old = ch, ch0_old = ch0; const npb_ph_t ph_old = ph;
     npd_turbine_update(&t, st, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
                        load_demand, 0.007, dt / 60.0, &tr);
     NPD_STAMP(18);
@@ -391,18 +463,18 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     }
     npd_condenser_result_t cr;
     {
-      NPD_ST_STORE(TURB, npb_turb_t, t, 0);
+      NPD_ST_STORE_ELIDE(TURB, npb_turb_t, t, t_old, 0);
       npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
                            cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr);
-      NPD_ST_STORE(COND, npb_cond_t, cd, 0);
-      NPD_ST_STORE(CHEM, npb_chem_t, ch, 1);
+      NPD_ST_STORE_ELIDE(COND, npb_cond_t, cd, cd_old, 0);
+      NPD_ST_STORE_ELIDE(CHEM, npb_chem_t, ch, ch_old, 1);
     }
     condenser_pressure = cr.condenser_pressure;
     NPD_STAMP(19);
     /* ================= chemistry sidecar: shared WaterChemistry + pH controller (:634-665) ========= */
     npd_chemistry_sidecar(&ch0, &ph, dt);
-    NPD_ST_STORE(CHEM, npb_chem_t, ch0, 0);
-    NPD_ST_STORE(PH, npb_ph_t, ph, 0);
+    NPD_ST_STORE_ELIDE(CHEM, npb_chem_t, ch0, ch0_old, 0);
+    NPD_ST_STORE_ELIDE(PH, npb_ph_t, ph, ph_old, 0);
     NPD_STAMP(20);
     /* ================= electrical-power gates (:750-932) ================= */
     double turbine_electrical_power = tr.electrical_power_net;
