@@ -158,22 +158,36 @@ static constexpr uint64_t NPD_ELIDE_PUMP_F =
     NPD_FB(npb_pump_t, differential_pressure) | NPD_FB(npb_pump_t, cavitation_intensity) | NPD_FB(npb_pump_t, cavitation_damage) |
     NPD_FB(npb_pump_t, cavitation_time) | NPD_FB(npb_pump_t, head_degradation) | NPD_FB(npb_pump_t, seal_leakage_rate) |
     /* the spare pump */ NPD_FB(npb_pump_t, speed_percent) | NPD_FB(npb_pump_t, speed_setpoint) | NPD_FB(npb_pump_t, flow_rate) |
-    NPD_FB(npb_pump_t, power_consumption) | NPD_FB(npb_pump_t, flow_demand);
+    NPD_FB(npb_pump_t, power_consumption) | NPD_FB(npb_pump_t, flow_demand) | NPD_FB(npb_pump_t, motor_temperature) |
+    NPD_FB(npb_pump_t, vibration_level) | NPD_FB(npb_pump_t, wear_motor_bearings) | NPD_FB(npb_pump_t, wear_pump_bearings) |
+    NPD_FB(npb_pump_t, wear_thrust_bearing) | NPD_FB(npb_pump_t, wear_coupling_system) | NPD_FB(npb_pump_t, flow_degradation) |
+    NPD_FB(npb_pump_t, vibration_increase);
 static constexpr uint64_t NPD_ELIDE_FW_F =
     NPD_FBN(npb_fw_t, previous_level_errors, 3) | NPD_FB(npb_fw_t, cav_accumulated_damage) | NPD_FB(npb_fw_t, cav_time_in_cavitation) |
     NPD_FB(npb_fw_t, npsh_low_low_timer) | NPD_FB(npb_fw_t, timer_low_flow) | NPD_FB(npb_fw_t, timer_high_flow) |
-    NPD_FB(npb_fw_t, timer_bearing_temp) | NPD_FB(npb_fw_t, timer_motor_temp) | NPD_FB(npb_fw_t, timer_vibration);
+    NPD_FB(npb_fw_t, timer_bearing_temp) | NPD_FB(npb_fw_t, timer_motor_temp) | NPD_FB(npb_fw_t, timer_vibration) |
+    NPD_FB(npb_fw_t, quality_integral_error);
 static constexpr uint64_t NPD_ELIDE_TURB_F =
     NPD_FB(npb_turb_t, rotor_speed) | NPD_FB(npb_turb_t, thermal_bow) | NPD_FBN(npb_turb_t, bearing_metal_temp, 4) |
     NPD_FBN(npb_turb_t, bearing_wear_factor, 4) | NPD_FB(npb_turb_t, timer_overspeed) | NPD_FB(npb_turb_t, timer_vibration) |
     NPD_FB(npb_turb_t, timer_bearing_temp) | NPD_FB(npb_turb_t, total_power_output) | NPD_FB(npb_turb_t, vibration_displacement);
 static constexpr uint64_t NPD_ELIDE_CHEM_F =
-    NPD_FB(npb_chem_t, dissolved_oxygen) | NPD_FB(npb_chem_t, corrosion_inhibitor_level) | NPD_FB(npb_chem_t, treatment_efficiency);
-static constexpr uint64_t NPD_ELIDE_PH_F = NPD_FB(npb_ph_t, morpholine_tank_level) | NPD_FB(npb_ph_t, pending_morpholine_dose);
+    NPD_FB(npb_chem_t, dissolved_oxygen) | NPD_FB(npb_chem_t, corrosion_inhibitor_level) | NPD_FB(npb_chem_t, treatment_efficiency) |
+    NPD_FB(npb_chem_t, chlorine_residual) | NPD_FB(npb_chem_t, antiscalant_concentration) | NPD_FB(npb_chem_t, water_aggressiveness);
+static constexpr uint64_t NPD_ELIDE_PH_F = NPD_FB(npb_ph_t, morpholine_tank_level) | NPD_FB(npb_ph_t, pending_morpholine_dose) |
+                                           NPD_FB(npb_ph_t, integral_sum);
 static constexpr uint64_t NPD_ELIDE_COND_F =
     NPD_FB(npb_cond_t, vibration_damage) | NPD_FB(npb_cond_t, condenser_pressure) | NPD_FB(npb_cond_t, air_partial_pressure) |
-    NPD_FB(npb_cond_t, air_mass_in_condenser);
+    NPD_FB(npb_cond_t, air_mass_in_condenser) | /* the idle ejector */ NPD_FBN(npb_cond_t, ej_nozzle_fouling, 2) |
+    NPD_FBN(npb_cond_t, ej_diffuser_fouling, 2) | NPD_FBN(npb_cond_t, ej_nozzle_erosion, 2);
 
+/* single column, same rule */
+#define NPD_ST_F64_ELIDE(T, stype, member, inst, k, newv, oldv) do { \
+    const double nv__ = (newv); \
+    if (__builtin_amdgcn_ballot_w64(__double_as_longlong(nv__) != __double_as_longlong(oldv)) != 0) NPD_ST_F64(T, stype, member, inst, k) = nv__; } while (0)
+#define NPD_ST_I32_ELIDE(T, stype, member, inst, newv, oldv) do { \
+    const int32_t nv__ = (newv); \
+    if (__builtin_amdgcn_ballot_w64(nv__ != (oldv)) != 0) NPD_ST_I32(T, stype, member, inst) = nv__; } while (0)
 #define NPD_ST_F64(T, stype, member, inst, k) \
   (*NPD_F64P(double, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64 + NPB_F64_SLOT(stype, member) + (k), st.lane8))
 #define NPD_ST_I32(T, stype, member, inst) \
@@ -260,9 +274,16 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   prev_feedwater_temp = NPD_STAGED_F64(SEC, npb_sec_t, previous_feedwater_temp, 0, NPD_LS_SEC);
   operating_hours = NPD_STAGED_F64(SEC, npb_sec_t, operating_hours, 0, NPD_LS_SEC);
   has_prev = NPD_STAGED_I32(SEC, npb_sec_t, has_previous_sg_conditions, NPD_LS_SEC);
+  /* staged values of the secondary-level columns that are usually rewritten unchanged (store elision) */
+  const double cw_old = cooling_water_temperature;
+  const double elec_old = NPD_STAGED_F64(SEC, npb_sec_t, electrical_power_output, 0, NPD_LS_SEC);
+  const double eff_old = NPD_STAGED_F64(SEC, npb_sec_t, thermal_efficiency, 0, NPD_LS_SEC);
+  const int sgavail_old = NPD_STAGED_I32(SEC, npb_sec_t, sg_system_availability, NPD_LS_SEC);
+  double pl_old[NPB_NUM_SG];
 #pragma unroll
   for (int i = 0; i < NPB_NUM_SG; i++) {
     prev_levels[i] = NPD_STAGED_F64(SEC, npb_sec_t, prev_sg_levels, i, NPD_LS_SEC);
+    pl_old[i] = prev_levels[i];
     prev_flows[i] = NPD_STAGED_F64(SEC, npb_sec_t, prev_sg_steam_flows, i, NPD_LS_SEC);
     prev_quals[i] = NPD_STAGED_F64(SEC, npb_sec_t, prev_sg_qualities, i, NPD_LS_SEC);
   }
@@ -412,7 +433,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
       /* boundary: SG i -> HBM, SG i+1 -> the same registers, stage SG i+2 / the turbine scalars */
       NPD_DMA_WAIT();
       NPD_ST_STORE_ELIDE(SG, npb_sg_t, g, g_old, i);
-      NPD_ST_F64(SEC, npb_sec_t, prev_sg_levels, 0, i) = g.water_level;
+      NPD_ST_F64_ELIDE(SEC, npb_sec_t, prev_sg_levels, 0, i, g.water_level, npd_sel3(i, pl_old[0], pl_old[1], pl_old[2]));
       NPD_ST_F64(SEC, npb_sec_t, prev_sg_steam_flows, 0, i) = r.steam_flow_rate;
       NPD_ST_F64(SEC, npb_sec_t, prev_sg_qualities, 0, i) = g.steam_quality;
       if (i + 1 < NPB_NUM_SG) { NPD_CONSUME(SG, npb_sg_t, g, 0); g_old = g; }
@@ -494,27 +515,27 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   }
 
   /* ================= secondary-level state write-back ================= */
-  NPD_ST_F64(SEC, npb_sec_t, previous_feedwater_temp, 0, 0) = actual_feedwater_temp;
-  NPD_ST_F64(SEC, npb_sec_t, electrical_power_output, 0, 0) = electrical_power;
-  NPD_ST_F64(SEC, npb_sec_t, thermal_efficiency, 0, 0) = thermal_efficiency;
+  NPD_ST_F64_ELIDE(SEC, npb_sec_t, previous_feedwater_temp, 0, 0, actual_feedwater_temp, prev_feedwater_temp);
+  NPD_ST_F64_ELIDE(SEC, npb_sec_t, electrical_power_output, 0, 0, electrical_power, elec_old);
+  NPD_ST_F64_ELIDE(SEC, npb_sec_t, thermal_efficiency, 0, 0, thermal_efficiency, eff_old);
   NPD_ST_F64(SEC, npb_sec_t, total_steam_flow, 0, 0) = sg_total_steam;
   NPD_ST_F64(SEC, npb_sec_t, total_heat_transfer, 0, 0) = sg_total_thermal;
   NPD_ST_F64(SEC, npb_sec_t, total_feedwater_flow, 0, 0) = fw_total_flow;
   NPD_ST_F64(SEC, npb_sec_t, load_demand, 0, 0) = load_demand;
-  NPD_ST_F64(SEC, npb_sec_t, cooling_water_temperature, 0, 0) = cooling_water_temperature;
+  NPD_ST_F64_ELIDE(SEC, npb_sec_t, cooling_water_temperature, 0, 0, cooling_water_temperature, cw_old);
   NPD_ST_F64(SEC, npb_sec_t, operating_hours, 0, 0) = operating_hours + dt / 3600.0;
   NPD_ST_F64(SEC, npb_sec_t, sg_avg_pressure, 0, 0) = sg_avg_pressure;
   NPD_ST_F64(SEC, npb_sec_t, sg_avg_temperature, 0, 0) = sg_avg_temperature;
   NPD_ST_F64(SEC, npb_sec_t, sg_avg_quality, 0, 0) = sg_avg_quality;
-  NPD_ST_I32(SEC, npb_sec_t, has_previous_sg_conditions, 0) = 1;
-  NPD_ST_I32(SEC, npb_sec_t, sg_system_availability, 0) = sg_system_availability;
+  NPD_ST_I32_ELIDE(SEC, npb_sec_t, has_previous_sg_conditions, 0, 1, has_prev);
+  NPD_ST_I32_ELIDE(SEC, npb_sec_t, sg_system_availability, 0, sg_system_availability, sgavail_old);
 
   /* ================= _apply_secondary_to_primary_feedback  sim.py:429-498 ================= */
   double heat_removal_factor = sg_total_steam / 1665.0;
   if (!fw_available) heat_removal_factor *= 0.5;
   NPD_ST_F64(PRIM, npb_prim_t, steam_flow_rate, 0, 0) = sg_total_steam;
   NPD_ST_F64(PRIM, npb_prim_t, last_heat_removal_factor, 0, 0) = heat_removal_factor;
-  NPD_ST_I32(PRIM, npb_prim_t, has_heat_removal_factor, 0) = 1;
+  NPD_ST_I32_ELIDE(PRIM, npb_prim_t, has_heat_removal_factor, 0, 1, s_old.has_heat_removal_factor);
 
   /* ================= observation / reward / done / flags / info ================= */
   obs[7] = sg_total_steam / 3000;
