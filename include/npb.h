@@ -66,7 +66,9 @@ NPB_API size_t npb_step_bytes_per_plant(void);
 NPB_API void npb_default_params(npb_params_t *p);
 
 /* NuclearPlantSimulator.__init__ (sim.py:30-87) for n_plants plants on HIP device `device`:
- * allocates the SoA arena and fills it with the construction-time state. */
+ * allocates the SoA arena and fills it with the construction-time state.  One handle carries at most
+ * 4 GiB of fp64 state (about one million plants: the step kernel's column offsets are 32-bit);
+ * larger batches use several handles (they are independent). */
 NPB_API int npb_create(const npb_params_t *params, int n_plants, int device, NpbHandle **out);
 NPB_API int npb_destroy(NpbHandle *h);
 NPB_API const char *npb_last_error(const NpbHandle *h); /* h may be NULL: last create error */
@@ -90,7 +92,10 @@ NPB_API int npb_state_arena(NpbHandle *h, double **f64, int32_t **i32, size_t *p
  * (NaN entries also mean unchanged; replaces heat_source.set_power_setpoint), noise_z -> 0
  * (standard-normal sample that ConstantHeatSource would draw, constant_heat_source.py:178),
  * cooling_water_temp -> unchanged.  Output columns (device) may be NULL:
- * obs [n,22] row-major, reward [n], done [n] u8, trip_flags [n] u32, info [n,10]. */
+ * obs [n,22] row-major, reward [n], done [n] u8, trip_flags [n] u32, info [n,10].
+ * With params.maint_enabled the automatic-maintenance rule for the feedwater pumps' oil_top_off action runs
+ * after the physics, in the reference's order (sim.py:208-223: AutoMaintenanceSystem.update, then the state
+ * manager's threshold scan); its state and counters are the maint.* columns of npb_fields.h. */
 NPB_API int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const double *power_setpoint,
              const double *noise_z, const double *cooling_water_temp, double *obs, double *reward, uint8_t *done,
              uint32_t *trip_flags, double *info, void *stream);
