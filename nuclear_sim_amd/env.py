@@ -257,6 +257,8 @@ class BatchedPlantEnv:
         info = {name: self._info[:, j] for j, name in enumerate(INFO_COLUMNS)}
         info["trip_flags"] = self._flags
         info["scram_activated"] = self._done
+        if self.params.maint_enabled:  # bit-exact counterpart of AutoMaintenanceSystem.maintenance_actions_performed
+            info["maintenance_event_count"] = self.get_field("maint.maintenance_actions_performed")
         return self._obs, self._reward, self._done, info
 
 

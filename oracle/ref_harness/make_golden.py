@@ -66,6 +66,12 @@ def scenarios():
                   runner=dict(action="oil_top_off", duration_hours=4.0, feedwater_ic={"pump_oil_levels": [58.3, 58.1, 98.0, 57.0]})))
     S.append(dict(name="m2_oil_top_off_simultaneous", steps=48, dt=5.0, noise=True, noise_seed=42, every=1,
                   runner=dict(action="oil_top_off", duration_hours=4.0, feedwater_ic={"pump_oil_levels": [57.0, 57.5, 56.0, 57.2]})))
+    # M3a-c: the same runner-built simulator with the composer's per-seed randomised initial
+    # conditions (randomization_utils.py:799-842), 120 steps = 10 h: one seed per catalog scenario
+    # (low oil level -> triggers, moderate loss -> triggers late, stable -> never)
+    for tag, seed in (("a", 4), ("b", 5), ("c", 2)):
+        S.append(dict(name="m3%s_oil_top_off_seed%d" % (tag, seed), steps=120, dt=5.0, noise=True, noise_seed=42, every=4,
+                      runner=dict(action="oil_top_off", duration_hours=10.0, randomization_seed=seed)))
     return S
 
 

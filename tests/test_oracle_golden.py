@@ -69,3 +69,4 @@ def test_known_answers_from_reference_tests(oracle_lib):
     assert done[0] == 1 and o2.get("prim.control_rod_position") == 0.0 and o2.get("prim.scram_status") == 1
     obs, rew, done, flags, info = o2.step()
     assert done[0] == 0  # one-shot: True only on the firing step
+
