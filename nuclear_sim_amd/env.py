@@ -262,34 +262,131 @@ class BatchedPlantEnv:
         return self._obs, self._reward, self._done, info
 
 
-class NuclearPlantSimulator:
-    """Single-plant facade with the reference's scalar signatures (sim.py:27-258)."""
+class ConstantHeatSource:
+    """systems/primary/reactor/heat_sources/constant_heat_source.py:29-102 (constructor and setpoint surface)."""
 
-    def __init__(self, dt: float = 1.0, heat_source: str = "constant", enable_secondary: bool = True,
-                 noise_enabled: bool = False, noise_std_percent: float = 0.1, noise_seed: Optional[int] = None,
-                 device: int = 0):
+    def __init__(self, rated_power_mw: float = 3000.0, noise_enabled: bool = False, noise_std_percent: float = 5.0,
+                 noise_seed: Optional[int] = None, noise_filter_time_constant: float = 30.0):
+        self.rated_power_mw = rated_power_mw
+        self.noise_enabled = noise_enabled
+        self.noise_std_percent = noise_std_percent
+        self.noise_seed = noise_seed
+        self.noise_filter_time_constant = noise_filter_time_constant
+        self.power_setpoint_percent = 100.0
+        self._pending = None
+
+    def set_power_setpoint(self, power_percent: float) -> None:
+        self.power_setpoint_percent = float(np.clip(power_percent, 0.0, 150.0))
+        self._pending = float(power_percent)
+
+
+class ReactorHeatSource:
+    """systems/primary/reactor/heat_sources/reactor_heat_source.py (point-kinetics heat source)."""
+
+    def __init__(self, rated_power_mw: float = 3000.0):
+        self.rated_power_mw = rated_power_mw
+        self._pending = None
+
+
+class _Namespace:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class NuclearPlantSimulator:
+    """Single-plant facade with the reference's signatures (simulator/core/sim.py:27-258), so that loops written
+    against the reference -- ``sim.primary_physics.heat_source.set_power_setpoint(p); sim.step(action=...)``
+    (maintenance_scenario_runner.py:383-411, 651-671) -- run unchanged on one lane of the HIP stepper.
+
+    Differences, all explicit: ``enable_state_management=True`` turns on what the path needs of it (the automatic
+    oil_top_off maintenance rule), not the pandas state log; ``secondary_config`` is honoured for the
+    initial-condition keys nuclear_sim_amd.scenarios can map (others are listed in ``ignored_initial_conditions``);
+    ``reset()`` returns to the construction-time state (the data-gen runner's episode start), not to the
+    reference's partial reset."""
+
+    def __init__(self, dt: float = 1.0, heat_source=None, enable_secondary: bool = True,
+                 enable_state_management: bool = False, max_state_rows: int = 100000, secondary_config=None,
+                 secondary_config_file: Optional[str] = None, device: int = 0):
         if not enable_secondary:
             raise NotImplementedError("the HIP stepper always runs the secondary side")
+        if secondary_config_file is not None:
+            raise NotImplementedError("pass secondary_config as a dict (YAML loading is out of scope)")
+        if heat_source is None or heat_source == "reactor":
+            heat_source = ReactorHeatSource()            # sim.py:41-44: the default heat source is the reactor model
+        elif heat_source == "constant":
+            heat_source = ConstantHeatSource(noise_std_percent=0.1)
+        constant = isinstance(heat_source, ConstantHeatSource)
         self.dt = dt
-        self._env = BatchedPlantEnv(1, dt=dt, heat_source=heat_source, noise_enabled=noise_enabled,
-                                    noise_std_percent=noise_std_percent,
-                                    noise_seeds=None if noise_seed is None else [noise_seed], device=device)
-        self._setpoint = None
+        self.enable_secondary = True
+        self.enable_state_management = enable_state_management
+        params = {"rated_power_mw": float(heat_source.rated_power_mw)}
+        if constant:
+            params["hs_noise_filter_tau"] = float(heat_source.noise_filter_time_constant)
+        self._env = BatchedPlantEnv(1, dt=dt, heat_source="constant" if constant else "reactor",
+                                    noise_enabled=bool(constant and heat_source.noise_enabled),
+                                    noise_std_percent=float(heat_source.noise_std_percent) if constant else 0.1,
+                                    noise_seeds=[heat_source.noise_seed] if (constant and heat_source.noise_enabled and
+                                                                             heat_source.noise_seed is not None) else None,
+                                    device=device, maintenance=enable_state_management, params=params)
+        self.primary_physics = _Namespace(heat_source=heat_source, rated_power_mw=heat_source.rated_power_mw)
+        self.ignored_initial_conditions = []
+        if secondary_config is not None:
+            self._apply_secondary_config(secondary_config)
+        self.load_demand = 100.0
+        self.cooling_water_temp = 25.0
+
+    def _apply_secondary_config(self, cfg: dict) -> None:
+        """initial_conditions of the composed configuration -> state columns (nuclear_sim_amd.scenarios)"""
+        from . import scenarios
+        sec = cfg.get("secondary_system", cfg)
+        fields = {}
+        fw_ic = dict(sec.get("feedwater", {}).get("initial_conditions", {}) or {})
+        known = set(scenarios.FEEDWATER_IC_DEFAULTS)
+        self.ignored_initial_conditions += ["feedwater." + k for k in fw_ic if k not in known]
+        if fw_ic:
+            eff = float(self._env.get_field("pump.lubrication_effectiveness")[0].item())
+            fields.update(scenarios.feedwater_fields({k: v for k, v in fw_ic.items() if k in known}, 1, eff))
+        sg_ic = sec.get("steam_generator", {}).get("initial_conditions", {}) or {}
+        if "sg_steam_flows" in sg_ic:
+            for k in range(scenarios.NUM_SG):
+                fields[("sg.steam_flow_rate", k)] = np.array([float(sg_ic["sg_steam_flows"][k])])
+        self.ignored_initial_conditions += ["steam_generator." + k for k in sg_ic if k != "sg_steam_flows"]
+        tb_ic = sec.get("turbine", {}).get("initial_conditions", {}) or {}
+        if "rotor_temperature" in tb_ic:
+            fields["turb.rotor_temperature"] = np.array([float(tb_ic["rotor_temperature"])])
+        if "bearing_temperatures" in tb_ic:
+            for k in range(4):
+                fields[("turb.bearing_metal_temp", 0, k)] = np.array([float(tb_ic["bearing_temperatures"][k])])
+        self.ignored_initial_conditions += ["turbine." + k for k in tb_ic if k not in ("rotor_temperature", "bearing_temperatures")]
+        self.ignored_initial_conditions += ["condenser." + k for k in (sec.get("condenser", {}).get("initial_conditions", {}) or {})]
+        self._env.set_fields(fields)
+
+    @property
+    def state(self):
+        """ReactorState view of the primary columns (sim.state, sim.py:85,151): attribute name -> current value"""
+        out = {}
+        for sec, f in (SCHEMA.by_name[k] for k in SCHEMA.by_name if k.startswith("prim.")):
+            if f.count == 1 and f.path.startswith("primary_physics.state."):
+                out[f.path[len("primary_physics.state."):]] = self._env.get_field("prim." + f.name)[0].item()
+        return _Namespace(**out)
 
     def set_power_setpoint(self, power_percent: float) -> None:
         """heat_source.set_power_setpoint  constant_heat_source.py:93-102 (applied at the next step)."""
-        self._setpoint = float(power_percent)
+        self.primary_physics.heat_source._pending = float(power_percent)
 
     def step(self, action: Optional[ControlAction] = None, magnitude: float = 1.0, load_demand: float = None,
              cooling_water_temp: float = None) -> Dict:
         a = ControlAction.NO_ACTION.value if action is None else (action.value if isinstance(action, ControlAction) else int(action))
+        hs = self.primary_physics.heat_source
+        sp, hs._pending = hs._pending, None
         obs, rew, done, info = self._env.step(action=[a], magnitude=[magnitude],
-                                              power_setpoint=None if self._setpoint is None else [self._setpoint],
+                                              power_setpoint=None if sp is None else [sp],
                                               cooling_water_temp=None if cooling_water_temp is None else [cooling_water_temp])
-        self._setpoint = None
         o = obs[0].cpu().numpy().copy()
         inf = {k: (v[0].item()) for k, v in info.items()}
         inf["scram_activated"] = bool(inf["scram_activated"])
+        inf["datetime"] = None
+        inf["secondary_system"] = {"feedwater_total_flow": inf["feedwater_flow"]}
         return {"observation": o, "reward": float(rew[0].item()), "done": bool(done[0].item()), "info": inf}
 
     def reset(self, start_at_steady_state: bool = True):
@@ -306,6 +403,9 @@ class NuclearPlantEnv:
         self.sim = NuclearPlantSimulator(**kw)
         self.action_space_size = len(ControlAction)
         self.observation_space_size = 22
+
+    def render(self):
+        return None
 
     def reset(self):
         return self.sim.reset()

@@ -264,6 +264,36 @@ def test_config4_randomized_oil_top_off_scenario(oracle_lib):
     assert created.max() >= 1 and created.min() == 0, "the scenario mix has plants that trigger within 2 h and plants that do not"
 
 
+def test_single_plant_facade_runs_the_data_gen_loop():
+    """Drop-in check: the reference-style loop of MaintenanceScenarioRunner.run_scenario
+    (maintenance_scenario_runner.py:383-411: ramped set_power_setpoint on the heat source, then
+    sim.step(action=NO_ACTION)) on nuclear_sim_amd's NuclearPlantSimulator, constructed the way the runner
+    constructs the reference's (:210-244) with the initial conditions of fixture m1; observations, rewards and the
+    maintenance event count must be the reference's."""
+    from nuclear_sim_amd.env import NuclearPlantSimulator, ConstantHeatSource, ControlAction
+    from nuclear_sim_amd import scenarios
+    g = Golden("m1_oil_top_off_staggered")
+    ic = dict(scenarios.ACTION_TEST_TEMPLATE["feedwater"]); ic.update(scenarios.OIL_TOP_OFF_CONDITIONS)
+    ic["pump_oil_levels"] = [58.3, 58.1, 98.0, 57.0]
+    cfg = {"secondary_system": {"feedwater": {"initial_conditions": ic},
+                                "steam_generator": {"initial_conditions": scenarios.ACTION_TEST_TEMPLATE["steam_generator"]},
+                                "turbine": {"initial_conditions": scenarios.ACTION_TEST_TEMPLATE["turbine"]}}}
+    hs = ConstantHeatSource(rated_power_mw=3000.0, noise_enabled=True, noise_std_percent=0.1, noise_seed=42)
+    sim = NuclearPlantSimulator(heat_source=hs, dt=5.0, enable_secondary=True, enable_state_management=True, secondary_config=cfg)
+    assert not sim.ignored_initial_conditions
+    events = 0
+    for t in range(g.T):
+        sim.primary_physics.heat_source.set_power_setpoint(float(g.setpoint[t]))
+        r = sim.step(action=ControlAction.NO_ACTION)
+        np.testing.assert_allclose(r["observation"], g.obs[t], rtol=RTOL, atol=1e-12, err_msg="obs step %d" % t)
+        np.testing.assert_allclose(r["reward"], g.reward[t], rtol=RTOL, atol=1e-9)
+        assert r["done"] == bool(g.done[t])
+        events = r["info"]["maintenance_event_count"]
+    lab = [c[2] for c in g.cols]
+    assert events == int(g.state[-1, lab.index("maint.maintenance_actions_performed")]) == 3
+    assert abs(sim.state.power_level - g.state[-1, lab.index("prim.power_level")]) <= RTOL * 100
+
+
 def env_cols():
     from nuclear_sim_amd.schema import SCHEMA
     return SCHEMA.columns()
