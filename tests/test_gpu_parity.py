@@ -294,6 +294,46 @@ def test_single_plant_facade_runs_the_data_gen_loop():
     assert abs(sim.state.power_level - g.state[-1, lab.index("prim.power_level")]) <= RTOL * 100
 
 
+def test_lane_independence_and_determinism():
+    """Plants are independent: perturbing one plant's state and inputs must leave every other plant's state and
+    outputs bit-identical (also across the wave-level decisions: store elision ballots, the turbine stage pass's
+    fast-path ballot), and two identical runs must agree bit for bit."""
+    n, T = 200, 25
+    rng = np.random.default_rng(77)
+    z = rng.standard_normal((T, n)); sp = rng.uniform(60, 100, (T, n))
+    acts = rng.choice([0, 1, 3, 8, 8, 8], size=(T, n)).astype(np.int32)
+
+    def run(perturb):
+        env = _env(n=n, heat_source="reactor", noise_enabled=False)
+        from nuclear_sim_amd.env import equilibrium_state
+        env.set_fields(equilibrium_state())
+        zz, ss, aa = z.copy(), sp.copy(), acts.copy()
+        if perturb:
+            for victim in (5, 70, 199):   # one per wave, incl. the ragged last wave
+                lv = np.full(n, 100.0); lv[victim] = 9.0                      # trips that plant's pump 0
+                env.set_field("pump.oil_level", lv, instance=0)
+                fl = env.get_field("prim.coolant_flow_rate").cpu().numpy(); fl[victim] = 4000.0   # scrams it
+                env.set_field("prim.coolant_flow_rate", fl)
+                aa[:, victim] = 3
+        outs = []
+        for t in range(T):
+            obs, rew, done, info = env.step(action=aa[t], magnitude=np.ones(n), power_setpoint=ss[t], noise_z=zz[t])
+            outs.append((obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), info["trip_flags"].cpu().numpy().copy()))
+        f, i = _host_state(env)
+        return outs, f, i
+
+    o1, f1, i1 = run(False)
+    o2, f2, i2 = run(False)
+    assert np.array_equal(f1, f2, equal_nan=True) and np.array_equal(i1, i2)
+    o3, f3, i3 = run(True)
+    keep = np.ones(n, dtype=bool); keep[[5, 70, 199]] = False
+    assert np.array_equal(f1[:, :n][:, keep], f3[:, :n][:, keep], equal_nan=True)
+    assert np.array_equal(i1[:, :n][:, keep], i3[:, :n][:, keep])
+    for (a, b, c), (d, e, g_) in zip(o1, o3):
+        assert np.array_equal(a[keep], d[keep]) and np.array_equal(b[keep], e[keep]) and np.array_equal(c[keep], g_[keep])
+    assert not np.array_equal(f1[:, 5], f3[:, 5])
+
+
 def env_cols():
     from nuclear_sim_amd.schema import SCHEMA
     return SCHEMA.columns()
