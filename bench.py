@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--maintenance", action="store_true",
                     help="also run the automatic oil_top_off maintenance kernel after every step (not the headline workload)")
+    ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
+                    help="element type of the carried state in HBM (f32 = BASELINE config 5; the headline is f64)")
     args = ap.parse_args()
 
     import torch
@@ -100,7 +102,7 @@ def main():
     K, W = args.steps, args.warmup
 
     env = BatchedPlantEnv(n, dt=1.0, heat_source="constant", noise_enabled=True, noise_std_percent=0.1, device=local_rank,
-                          maintenance=args.maintenance)
+                          maintenance=args.maintenance, storage=args.storage)
     # synthetic inputs, resident in HBM before the timed region: per-plant load-following setpoint
     # trace (90 % + 10 % sin, period 600 + 60*(i mod 16) steps) and N(0,1) noise samples
     gid = torch.arange(lo, lo + n, device=dev, dtype=torch.float64)
@@ -158,20 +160,21 @@ def main():
     elapsed = float(el.item()); kernel_ms = float(km.item())
 
     if rank == 0:
-        bytes_per_plant = BatchedPlantEnv.step_bytes_per_plant()
+        bytes_per_plant = env.handle_step_bytes_per_plant()
         achieved = bytes_per_plant * n / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "plant-env-steps/s", "value": n_global * K / elapsed, "unit": "plant-env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",   # arithmetic is fp64 in both storage modes
             "config": {"workload": "BASELINE config 3: %d plants per GPU (%d total), full secondary "
                                    "(primary + feedwater + 3 SG + turbine + condenser), ConstantHeatSource 0.1%% noise, "
                                    "load-following setpoints, dt=1.0, obs+reward+done+trip_flags+info written every step" % (n, n_global),
                        "plants_per_gpu": n, "global_plants": n_global, "parallelism": "plants sharded contiguously, no data-path collective",
                        "state_bytes_per_plant": BatchedPlantEnv.state_bytes_per_plant(),
-                       "algorithmic_bytes_per_plant_step": bytes_per_plant, "maintenance_kernel": bool(args.maintenance)},
+                       "algorithmic_bytes_per_plant_step": bytes_per_plant, "maintenance_kernel": bool(args.maintenance),
+                       "state_storage": args.storage},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n) if args.storage == "f64" else None,
                          "algorithmic_bytes_per_launch": bytes_per_plant * n,
                          "kernel": "npb_step_kernel", "kernel_ms": kernel_ms},
         }

@@ -62,6 +62,8 @@ NPB_API size_t npb_state_bytes(void);
  * + per-step inputs (action 4 + magnitude/setpoint/noise/cooling 4*8) + outputs (obs 22*8 + reward 8
  * + done 1 + trip_flags 4 + info 10*8) */
 NPB_API size_t npb_step_bytes_per_plant(void);
+/* the same for one handle: with fp32 storage every real-valued column moves 4 bytes instead of 8 */
+NPB_API size_t npb_handle_step_bytes_per_plant(const NpbHandle *h);
 
 NPB_API void npb_default_params(npb_params_t *p);
 
@@ -70,6 +72,17 @@ NPB_API void npb_default_params(npb_params_t *p);
  * 4 GiB of fp64 state (about one million plants: the step kernel's column offsets are 32-bit);
  * larger batches use several handles (they are independent). */
 NPB_API int npb_create(const npb_params_t *params, int n_plants, int device, NpbHandle **out);
+/* The same with the element type of the real-valued state columns chosen (BASELINE config 5, "fp32-mixed"):
+ * NPB_STORAGE_F32 keeps the carried state as float in HBM and in the LDS staging -- half the traffic of
+ * the HBM-bound step kernel -- while every expression is still evaluated in fp64 exactly as in the fp64
+ * build; values are rounded to float once per step, when they are stored.  Flags, counters and enums are
+ * int32 columns either way and stay bit-exact as long as no rounded value sits within 1e-7 relative of a
+ * trip threshold.  Inputs, observations, rewards and info stay fp64; npb_get_field / npb_set_field convert.
+ * The reference has no counterpart (it is fp64 throughout); parity for this mode is 1e-4 relative on
+ * observations (tests/test_gpu_parity.py). */
+enum { NPB_STORAGE_F64 = 0, NPB_STORAGE_F32 = 1 };
+NPB_API int npb_create_storage(const npb_params_t *params, int n_plants, int device, int storage, NpbHandle **out);
+NPB_API int npb_storage(const NpbHandle *h);
 NPB_API int npb_destroy(NpbHandle *h);
 NPB_API const char *npb_last_error(const NpbHandle *h); /* h may be NULL: last create error */
 NPB_API int npb_num_plants(const NpbHandle *h);
@@ -85,7 +98,9 @@ NPB_API int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream);
 NPB_API int npb_get_field(NpbHandle *h, int kind, int slot, void *buf, int buf_is_device, void *stream);
 NPB_API int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int buf_is_device, void *stream);
 /* raw arena: f64[slot * pitch + plant], i32[slot * pitch + plant] */
-NPB_API int npb_state_arena(NpbHandle *h, double **f64, int32_t **i32, size_t *pitch);
+NPB_API int npb_state_arena(NpbHandle *h, double **f64, int32_t **i32, size_t *pitch); /* fp64-storage handles */
+/* any handle: real[slot * pitch + plant] is double or float according to *storage */
+NPB_API int npb_state_arena_raw(NpbHandle *h, void **real, int32_t **i32, size_t *pitch, int *storage);
 
 /* NuclearPlantSimulator.step (sim.py:130-258) for every plant.  Input columns (device, n_plants each)
  * may be NULL: action -> NO_ACTION(8), magnitude -> 1.0, power_setpoint -> unchanged

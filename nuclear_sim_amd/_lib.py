@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("NPB_LIB", os.path.join(_HERE, "libnpb.so"))
 
 NPB_KIND_F64, NPB_KIND_I32 = 0, 1
 HEAT_CONSTANT, HEAT_REACTOR = 0, 1
+STORAGE_F64, STORAGE_F32 = 0, 1
 MODE_FULL, MODE_PRIMARY_SG = 0, 1
 
 
@@ -55,6 +56,11 @@ def load():
     L.npb_step_bytes_per_plant.restype = ctypes.c_size_t
     L.npb_default_params.argtypes = [ctypes.POINTER(NpbParams)]
     L.npb_create.argtypes = [ctypes.POINTER(NpbParams), ci, ci, ctypes.POINTER(vp)]
+    L.npb_create_storage.argtypes = [ctypes.POINTER(NpbParams), ci, ci, ci, ctypes.POINTER(vp)]
+    L.npb_storage.argtypes = [vp]
+    L.npb_handle_step_bytes_per_plant.argtypes = [vp]
+    L.npb_handle_step_bytes_per_plant.restype = ctypes.c_size_t
+    L.npb_state_arena_raw.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ci)]
     L.npb_destroy.argtypes = [vp]
     L.npb_last_error.argtypes = [vp]
     L.npb_last_error.restype = ctypes.c_char_p

@@ -25,6 +25,10 @@
 /* diagnostic build only (-DNPB_STAMPS, tools/phase_stamps.py): lane 0 of every wave records s_memtime
  * at phase boundaries so the kernel's time can be attributed to phases on the GPU */
 #ifdef NPB_STAMPS
+#ifdef NPB_BUILD_F32
+#define npb_stamp_buf npb32_stamp_buf
+#define npb_debug_set_stamp_buffer npb32_debug_set_stamp_buffer
+#endif
 __device__ unsigned long long *npb_stamp_buf;
 #define NPD_STAMP(k) do { if (threadIdx.x == 0 && npb_stamp_buf) npb_stamp_buf[(size_t)blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
 extern "C" __attribute__((visibility("default"))) int npb_debug_set_stamp_buffer(unsigned long long *dev) {
@@ -51,21 +55,21 @@ extern "C" __attribute__((visibility("default"))) int npb_debug_set_stamp_buffer
 /* ---- section <-> SoA column movers.  A section struct is NF64 doubles followed by NI32 int32s
  * (include/npb_fields.h), so a fully unrolled constant-index copy is all that is needed. */
 template <int NF, int NI, typename S>
-__device__ __forceinline__ void npd_load(S &s, const double *__restrict__ f64, const int32_t *__restrict__ i32,
+__device__ __forceinline__ void npd_load(S &s, const npd_real_t *__restrict__ f64, const int32_t *__restrict__ i32,
                                          size_t N, size_t p, int fbase, int ibase) {
   double *d = reinterpret_cast<double *>(&s);
 #pragma unroll
-  for (int k = 0; k < NF; k++) d[k] = f64[(size_t)(fbase + k) * N + p];
+  for (int k = 0; k < NF; k++) d[k] = (double)f64[(size_t)(fbase + k) * N + p];
   int32_t *q = reinterpret_cast<int32_t *>(d + NF);
 #pragma unroll
   for (int k = 0; k < NI; k++) q[k] = i32[(size_t)(ibase + k) * N + p];
 }
 template <int NF, int NI, typename S>
-__device__ __forceinline__ void npd_store(const S &s, double *__restrict__ f64, int32_t *__restrict__ i32,
+__device__ __forceinline__ void npd_store(const S &s, npd_real_t *__restrict__ f64, int32_t *__restrict__ i32,
                                           size_t N, size_t p, int fbase, int ibase) {
   const double *d = reinterpret_cast<const double *>(&s);
 #pragma unroll
-  for (int k = 0; k < NF; k++) f64[(size_t)(fbase + k) * N + p] = d[k];
+  for (int k = 0; k < NF; k++) f64[(size_t)(fbase + k) * N + p] = (npd_real_t)d[k];
   const int32_t *q = reinterpret_cast<const int32_t *>(d + NF);
 #pragma unroll
   for (int k = 0; k < NI; k++) i32[(size_t)(ibase + k) * N + p] = q[k];
@@ -89,7 +93,7 @@ template <int NF, int NI, typename S>
 __device__ __forceinline__ void npd_st_store(const S &s, const npd_stage_t &st, int fbase, int ibase) {
   const double *d = reinterpret_cast<const double *>(&s);
 #pragma unroll
-  for (int k = 0; k < NF; k++) *NPD_F64P(double, fbase + k, st.lane8) = d[k];
+  for (int k = 0; k < NF; k++) *NPD_RP(fbase + k) = (npd_real_t)d[k];
   const int32_t *q = reinterpret_cast<const int32_t *>(d + NF);
 #pragma unroll
   for (int k = 0; k < NI; k++) *NPD_I32P(int32_t, ibase + k, st.lane4) = q[k];
@@ -98,7 +102,7 @@ template <int NF, int NI, typename S>
 __device__ __forceinline__ void npd_st_load(S &s, const npd_stage_t &st, int fbase, int ibase) {
   double *d = reinterpret_cast<double *>(&s);
 #pragma unroll
-  for (int k = 0; k < NF; k++) d[k] = *NPD_F64P(const double, fbase + k, st.lane8);
+  for (int k = 0; k < NF; k++) d[k] = (double)*NPD_RP(fbase + k);
   int32_t *q = reinterpret_cast<int32_t *>(d + NF);
 #pragma unroll
   for (int k = 0; k < NI; k++) q[k] = *NPD_I32P(const int32_t, ibase + k, st.lane4);
@@ -117,6 +121,14 @@ __device__ __forceinline__ void npd_st_load(S &s, const npd_stage_t &st, int fba
  * members named in the masks below are stored only if some lane's bits changed.  Which members are listed is a
  * performance choice only: the compare is on the bit patterns, so the arena always ends up with exactly the
  * bits a plain store would have written.  "old" is the copy of the section as it was staged in. */
+/* bit pattern of a value as it is stored (fp32 storage: after rounding to fp32) */
+__device__ __forceinline__ long long npd_real_bits(double v) {
+#ifdef NPB_BUILD_F32
+  return (long long)__float_as_int((float)v);
+#else
+  return __double_as_longlong(v);
+#endif
+}
 template <int NF, int NI, typename S>
 __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, const npd_stage_t &st, int fbase, int ibase,
                                                    uint64_t fmask, uint32_t imask) {
@@ -124,10 +136,9 @@ __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, con
 #pragma unroll
   for (int k = 0; k < NF; k++) {
     if ((fmask >> k) & 1) {
-      if (__builtin_amdgcn_ballot_w64(__double_as_longlong(d[k]) != __double_as_longlong(od[k])) != 0)
-        *NPD_F64P(double, fbase + k, st.lane8) = d[k];
+      if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) *NPD_RP(fbase + k) = (npd_real_t)d[k];
     } else {
-      *NPD_F64P(double, fbase + k, st.lane8) = d[k];
+      *NPD_RP(fbase + k) = (npd_real_t)d[k];
     }
   }
   const int32_t *q = reinterpret_cast<const int32_t *>(d + NF), *oq = reinterpret_cast<const int32_t *>(od + NF);
@@ -184,12 +195,12 @@ static constexpr uint64_t NPD_ELIDE_COND_F =
 /* single column, same rule */
 #define NPD_ST_F64_ELIDE(T, stype, member, inst, k, newv, oldv) do { \
     const double nv__ = (newv); \
-    if (__builtin_amdgcn_ballot_w64(__double_as_longlong(nv__) != __double_as_longlong(oldv)) != 0) NPD_ST_F64(T, stype, member, inst, k) = nv__; } while (0)
+    if (__builtin_amdgcn_ballot_w64(npd_real_bits(nv__) != npd_real_bits(oldv)) != 0) NPD_ST_F64(T, stype, member, inst, k) = (npd_real_t)nv__; } while (0)
 #define NPD_ST_I32_ELIDE(T, stype, member, inst, newv, oldv) do { \
     const int32_t nv__ = (newv); \
     if (__builtin_amdgcn_ballot_w64(nv__ != (oldv)) != 0) NPD_ST_I32(T, stype, member, inst) = nv__; } while (0)
 #define NPD_ST_F64(T, stype, member, inst, k) \
-  (*NPD_F64P(double, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64 + NPB_F64_SLOT(stype, member) + (k), st.lane8))
+  (*NPD_RP(NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64 + NPB_F64_SLOT(stype, member) + (k)))
 #define NPD_ST_I32(T, stype, member, inst) \
   (*NPD_I32P(int32_t, NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32 + NPB_I32_SLOT(stype, T, member), st.lane4))
 
@@ -229,13 +240,13 @@ __device__ __forceinline__ void npd_obs_primary(const npb_prim_t &s, double *obs
 }
 
 __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
-    npb_params_t P, int n_plants, size_t N, double *__restrict__ f64, int32_t *__restrict__ i32,
+    npb_params_t P, int n_plants, size_t N, npd_real_t *__restrict__ f64, int32_t *__restrict__ i32,
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
     const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,
     double *__restrict__ reward_out, uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out,
     double *__restrict__ info_out) {
   /* staging region of the LDS-DMA pipeline (npd_stage.h); the obs / info transposes at the very end reuse it */
-  __shared__ __attribute__((aligned(16))) double lds[NPB_STAGE_SLOTS * NPB_WAVE];
+  __shared__ __attribute__((aligned(16))) double lds[NPB_STAGE_BYTES / 8];
   static_assert(NPB_STAGE_SLOTS >= NPB_OBS_PAD, "the transposes alias the staging region");
   const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
   const size_t p = block_base + threadIdx.x; /* always < N (arena is padded to a multiple of 64) */
@@ -588,10 +599,10 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
 }
 
 /* get_observation() without stepping (after reset / set_field): sim.py:290-333 */
-__global__ __launch_bounds__(NPB_WAVE) void npb_observe_kernel(int mode, int n_plants, size_t N, const double *__restrict__ f64c,
+__global__ __launch_bounds__(NPB_WAVE) void npb_observe_kernel(int mode, int n_plants, size_t N, const npd_real_t *__restrict__ f64c,
                                                                const int32_t *__restrict__ i32c, double *__restrict__ obs_out) {
   __shared__ double lds[NPB_WAVE * NPB_OBS_PAD];
-  double *f64 = const_cast<double *>(f64c);
+  npd_real_t *f64 = const_cast<npd_real_t *>(f64c);
   int32_t *i32 = const_cast<int32_t *>(i32c);
   const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
   const size_t p = block_base + threadIdx.x;
@@ -621,7 +632,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_observe_kernel(int mode, int n_p
 
 /* construction-time state for every plant selected by mask (NULL = all): the state the reference's
  * constructors leave behind with the default SecondarySystemConfig (npd_init.h) */
-__global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size_t N, double *__restrict__ f64,
+__global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size_t N, npd_real_t *__restrict__ f64,
                                                             int32_t *__restrict__ i32, const uint8_t *__restrict__ mask,
                                                             int n_plants) {
   const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
@@ -647,7 +658,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size
  * state manager's threshold scan (npd_maintenance.h).  HBM-bound and small: per plant it reads
  * sim_time, the maint section and four oil levels (184 B); it writes only what changed -- the
  * maint section when a check ran or a violation was recorded, one pump record when a top-off ran. */
-__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, size_t N, double *__restrict__ f64,
+__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, size_t N, npd_real_t *__restrict__ f64,
                                                              int32_t *__restrict__ i32) {
   const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
   const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
@@ -670,6 +681,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, siz
   if (dirty) NPD_STORE(MAINT, npb_maint_t, m, 0);
 }
 
+#ifndef NPB_BUILD_F32
 /* calibration aid for the HBM traffic counters: reads every state column and writes it back unchanged,
  * with exactly the access shape of the step kernel (8 B per lane, one 512-B line per wave and column),
  * so that FETCH_SIZE / WRITE_SIZE can be scaled against a known byte count (2 * state_bytes * pitch) */
@@ -680,31 +692,53 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_touch_kernel(size_t N, double *_
 #pragma unroll 8
   for (int k = 0; k < NPB_TOTAL_I32; k++) { int32_t v = i32[(size_t)k * N + p]; i32[(size_t)k * N + p] = v; }
 }
-
-/* ---- host-side launchers (called from npb_api.hip) */
 extern "C" void npb_launch_touch(size_t npad, double *f64, int32_t *i32, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
   hipLaunchKernelGGL(npb_touch_kernel, grid, block, 0, stream, npad, f64, i32);
 }
-extern "C" void npb_launch_step(const npb_params_t *P, int n_plants, size_t npad, double *f64, int32_t *i32,
+#else
+/* fp32 storage: the C ABI's field access speaks fp64, so one column is converted on the way in and out */
+__global__ void npb_col_to_f64_kernel(const float *__restrict__ col, double *__restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)col[i];
+}
+__global__ void npb_col_from_f64_kernel(float *__restrict__ col, const double *__restrict__ in, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) col[i] = (float)in[i];
+}
+extern "C" void npb32_launch_col_to_f64(const float *col, double *out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(npb_col_to_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, col, out, n);
+}
+extern "C" void npb32_launch_col_from_f64(float *col, const double *in, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(npb_col_from_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, col, in, n);
+}
+#endif
+
+/* ---- host-side launchers (called from npb_api.hip); one set per storage type */
+#ifdef NPB_BUILD_F32
+#define NPB_LAUNCHER(name) npb32_launch_##name
+#else
+#define NPB_LAUNCHER(name) npb_launch_##name
+#endif
+extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad, void *f64, int32_t *i32,
                                 const int32_t *action, const double *magnitude, const double *setpoint,
                                 const double *noise_z, const double *cw_temp, double *obs, double *reward, uint8_t *done,
                                 uint32_t *trip_flags, double *info, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, f64, i32, action, magnitude, setpoint,
+  hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)f64, i32, action, magnitude, setpoint,
                      noise_z, cw_temp, obs, reward, done, trip_flags, info);
 }
-extern "C" void npb_launch_maint(const npb_params_t *P, size_t npad, double *f64, int32_t *i32, hipStream_t stream) {
+extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, size_t npad, void *f64, int32_t *i32, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_maint_kernel, grid, block, 0, stream, *P, npad, f64, i32);
+  hipLaunchKernelGGL(npb_maint_kernel, grid, block, 0, stream, *P, npad, (npd_real_t *)f64, i32);
 }
-extern "C" void npb_launch_observe(int mode, int n_plants, size_t npad, const double *f64, const int32_t *i32, double *obs,
+extern "C" void NPB_LAUNCHER(observe)(int mode, int n_plants, size_t npad, const void *f64, const int32_t *i32, double *obs,
                                    hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_observe_kernel, grid, block, 0, stream, mode, n_plants, npad, f64, i32, obs);
+  hipLaunchKernelGGL(npb_observe_kernel, grid, block, 0, stream, mode, n_plants, npad, (const npd_real_t *)f64, i32, obs);
 }
-extern "C" void npb_launch_init(const npb_params_t *P, int n_plants, size_t npad, double *f64, int32_t *i32,
+extern "C" void NPB_LAUNCHER(init)(const npb_params_t *P, int n_plants, size_t npad, void *f64, int32_t *i32,
                                 const uint8_t *mask, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_init_kernel, grid, block, 0, stream, *P, npad, f64, i32, mask, n_plants);
+  hipLaunchKernelGGL(npb_init_kernel, grid, block, 0, stream, *P, npad, (npd_real_t *)f64, i32, mask, n_plants);
 }

@@ -16,8 +16,8 @@
  *                                to wait for freshly issued stores
  *     issue DMA(j+2)             into the same LDS region, lands while phase j+1 computes
  *
- * One staging region of NPB_STAGE_SLOTS column slots (512 B = 64 lanes x 8 B) per wave; an int32 column
- * takes half a slot.  36 KB per wave, 4 waves per CU = 144 KB of the CU's 160 KB.
+ * One staging region of 36 KB per wave (4 waves per CU = 144 KB of the CU's 160 KB), addressed in column slots
+ * of 64 lanes x sizeof(stored real); an int32 column takes 256 B.
  *
  * hipcc (ROCm 7.2) does not insert the vmcnt wait between an LDS-DMA and a later ds_read of the same
  * bytes, so the waits here are explicit and carry a "memory" clobber so nothing moves across them.
@@ -26,8 +26,21 @@
 #define NPD_STAGE_H
 #include "npd_common.h"
 
-#define NPB_STAGE_SLOTS 72
 #define NPB_WAVE 64
+
+/* Storage type of the fp64 state columns in HBM.  The arithmetic is fp64 either way; a build with
+ * -DNPB_BUILD_F32 keeps the arena in fp32 (BASELINE config 5, "fp32 mixed precision"): half the bytes, state
+ * rounded to fp32 at every store.  npb_kernels.hip is compiled once per storage type (Makefile). */
+#ifdef NPB_BUILD_F32
+typedef float npd_real_t;
+#else
+typedef double npd_real_t;
+#endif
+#define NPD_RB ((int)sizeof(npd_real_t))            /* bytes of a stored real */
+#define NPD_SLOTB (NPB_WAVE * NPD_RB)               /* bytes of one staged real column (one wave) */
+#define NPD_GROUP (16 / NPD_RB)                     /* real columns one dwordx4 LDS-DMA moves: 2 (fp64) or 4 (fp32) */
+#define NPB_STAGE_BYTES 36864                       /* staging region per wave; 4 waves per CU = 144 KB of 160 */
+#define NPB_STAGE_SLOTS (NPB_STAGE_BYTES / NPD_SLOTB)
 
 typedef __attribute__((address_space(1))) const void npd_gptr_t;
 typedef __attribute__((address_space(3))) void npd_lptr_t;
@@ -40,29 +53,31 @@ typedef __attribute__((address_space(3))) void npd_lptr_t;
  * arena at 4 GiB per kind; npb_create enforces it (about one million plants per handle). */
 typedef __attribute__((address_space(1))) char npd_gchar_t;
 typedef struct npd_stage_t {
-  double *lds;            /* staging region base (wave-uniform) */
+  char *lds;              /* staging region base (wave-uniform) */
   npd_gchar_t *f64b;      /* SoA arenas, offset to this wave's first plant (wave-uniform) */
   npd_gchar_t *i32b;
-  uint32_t n8, n4;        /* column pitch in bytes: fp64 and int32 arena */
-  uint32_t lane8, lane4;  /* lane * 8, lane * 4: this lane's plant within a column */
-  uint32_t pair16;        /* two-column LDS-DMA: lanes 0-31 carry column c (2 plants = 16 B each), lanes 32-63
-                           * column c + 1:  (lane >> 5) * n8 + (lane & 31) * 16 */
+  uint32_t nr, n4;        /* column pitch in bytes: real and int32 arena */
+  uint32_t laner, lane4;  /* lane * sizeof(real), lane * 4: this lane's plant within a column */
+  uint32_t grp16;         /* grouped LDS-DMA: 64 / NPD_GROUP consecutive lanes carry one column, 16 B
+                           * (2 fp64 or 4 fp32 plants) each:  (lane / lanes_per_col) * nr + (lane % lanes_per_col) * 16 */
 } npd_stage_t;
 
-__device__ __forceinline__ void npd_stage_init(npd_stage_t &st, double *lds, double *f64, int32_t *i32, size_t N, size_t block_base) {
-  const uint32_t lane = threadIdx.x;
-  st.lds = lds;
+__device__ __forceinline__ void npd_stage_init(npd_stage_t &st, void *lds, npd_real_t *f64, int32_t *i32, size_t N, size_t block_base) {
+  const uint32_t lane = threadIdx.x, lpc = NPB_WAVE / NPD_GROUP;
+  st.lds = (char *)lds;
   st.f64b = (npd_gchar_t *)(f64 + block_base); st.i32b = (npd_gchar_t *)(i32 + block_base);
-  st.n8 = (uint32_t)(N * 8); st.n4 = (uint32_t)(N * 4);
-  st.lane8 = lane * 8u; st.lane4 = lane * 4u;
-  st.pair16 = (lane >> 5) * st.n8 + (lane & 31u) * 16u;
+  st.nr = (uint32_t)(N * NPD_RB); st.n4 = (uint32_t)(N * 4);
+  st.laner = lane * NPD_RB; st.lane4 = lane * 4u;
+  st.grp16 = (lane / lpc) * st.nr + (lane % lpc) * 16u;
 }
 __device__ __forceinline__ uint32_t npd_voff(uint32_t col, uint32_t pitch, uint32_t lane_off) {
   uint32_t v, t;
   asm volatile("s_mul_i32 %1, %2, %3\n\tv_add_u32 %0, %1, %4" : "=v"(v), "=&s"(t) : "s"(col), "s"(pitch), "v"(lane_off));
   return v;
 }
-#define NPD_F64P(type, col, off) ((__attribute__((address_space(1))) type *)(st.f64b + npd_voff((uint32_t)(col), st.n8, (off))))
+/* this lane's element of real column `col` / int32 column `col`; NPD_RPO: column base + explicit lane offset */
+#define NPD_RPO(type, col, off) ((__attribute__((address_space(1))) type *)(st.f64b + npd_voff((uint32_t)(col), st.nr, (off))))
+#define NPD_RP(col) NPD_RPO(npd_real_t, col, st.laner)
 #define NPD_I32P(type, col, off) ((__attribute__((address_space(1))) type *)(st.i32b + npd_voff((uint32_t)(col), st.n4, (off))))
 
 #ifdef NPB_STAMPS
@@ -77,55 +92,55 @@ __shared__ unsigned long long npd_wait_acc_s;
 #endif
 #define NPD_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-/* slots a section occupies in the staging region */
-#define NPD_SLOTS(T) (NPB_##T##_NF64 + (NPB_##T##_NI32 + 1) / 2)
+/* real-column slots a section occupies in the staging region (an int32 column is 256 B) */
+#define NPD_SLOTS(T) (NPB_##T##_NF64 + (NPB_##T##_NI32 * 256 + NPD_SLOTB - 1) / NPD_SLOTB)
 
-/* issue the LDS-DMA of NF fp64 columns starting at arena column fslot and NI int32 columns starting at
- * islot into staging slot ls: fp64 column c -> slot ls + c; int32 column k -> the k-th 256-B half slot
- * after the fp64 slots.  One dwordx4 instruction moves two fp64 columns: lanes 0-31 carry column c
- * (16 B = 2 plants each), lanes 32-63 column c + 1, and the LDS image (base + lane * 16) is the two
- * columns back to back. */
+/* issue the LDS-DMA of NF real columns starting at arena column fslot and NI int32 columns starting at
+ * islot into staging slot ls: real column c -> slot ls + c; int32 column k -> the k-th 256 B after the real
+ * slots.  One dwordx4 instruction moves NPD_GROUP columns: the LDS image (base + lane * 16) is those columns
+ * back to back.  Left-over columns go as 256-B dword pieces. */
 template <int NF, int NI>
 __device__ __forceinline__ void npd_dma(const npd_stage_t &st, int fslot, int islot, int ls) {
-  double *l = st.lds + ls * NPB_WAVE;
+  char *l = st.lds + ls * NPD_SLOTB;
 #pragma unroll
-  for (int c = 0; c + 1 < NF; c += 2)
-    __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_F64P(double, fslot + c, st.pair16), (npd_lptr_t *)(l + c * NPB_WAVE), 16, 0, 0);
-  if (NF & 1) { /* odd last column: two dword pieces of 256 B */
-    const __attribute__((address_space(1))) uint32_t *g4 = NPD_F64P(const uint32_t, fslot + NF - 1, st.lane4);
-    uint32_t *l4 = (uint32_t *)(l + (NF - 1) * NPB_WAVE);
-    __builtin_amdgcn_global_load_lds((npd_gptr_t *)g4, (npd_lptr_t *)l4, 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((npd_gptr_t *)(g4 + NPB_WAVE), (npd_lptr_t *)(l4 + NPB_WAVE), 4, 0, 0);
-  }
+  for (int c = 0; c + NPD_GROUP <= NF; c += NPD_GROUP)
+    __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_RPO(char, fslot + c, st.grp16), (npd_lptr_t *)(l + c * NPD_SLOTB), 16, 0, 0);
+#pragma unroll
+  for (int c = NF / NPD_GROUP * NPD_GROUP; c < NF; c++)
+#pragma unroll
+    for (int piece = 0; piece < NPD_RB / 4; piece++)
+      __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_RPO(char, fslot + c, st.lane4 + piece * 256),
+                                       (npd_lptr_t *)(l + c * NPD_SLOTB + piece * 256), 4, 0, 0);
   if (NI > 0) {
-    int32_t *li = (int32_t *)(l + NF * NPB_WAVE);
+    char *li = l + NF * NPD_SLOTB;
 #pragma unroll
     for (int k = 0; k < NI; k++)
-      __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_I32P(int32_t, islot + k, st.lane4), (npd_lptr_t *)(li + k * NPB_WAVE), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_I32P(int32_t, islot + k, st.lane4), (npd_lptr_t *)(li + k * 256), 4, 0, 0);
   }
 }
 #define NPD_DMA(T, inst, ls) \
   npd_dma<NPB_##T##_NF64, NPB_##T##_NI32>(st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
                                           NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32, ls)
 
+/* staged real k of the image at slot ls / staged int k behind NF real slots, for this lane */
+#define NPD_LDS_REAL(ls, k) ((double)((const npd_real_t *)(st.lds + (ls) * NPD_SLOTB))[(k) * NPB_WAVE + threadIdx.x])
+#define NPD_LDS_INT(ls, nf, k) (((const int32_t *)(st.lds + ((ls) + (nf)) * NPD_SLOTB))[(k) * NPB_WAVE + threadIdx.x])
+
 /* staging slot ls -> register struct (all fp64 members first, then the int32 members) */
 template <int NF, int NI, typename S>
-__device__ __forceinline__ void npd_consume(S &s, const double *lds, int ls) {
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void npd_consume(S &s, const npd_stage_t &st, int ls) {
   double *d = reinterpret_cast<double *>(&s);
 #pragma unroll
-  for (int k = 0; k < NF; k++) d[k] = lds[(ls + k) * NPB_WAVE + lane];
-  const int32_t *li = (const int32_t *)(lds + (ls + NF) * NPB_WAVE);
+  for (int k = 0; k < NF; k++) d[k] = NPD_LDS_REAL(ls, k);
   int32_t *q = reinterpret_cast<int32_t *>(d + NF);
 #pragma unroll
-  for (int k = 0; k < NI; k++) q[k] = li[k * NPB_WAVE + lane];
+  for (int k = 0; k < NI; k++) q[k] = NPD_LDS_INT(ls, NF, k);
 }
-#define NPD_CONSUME(T, stype, s, ls) npd_consume<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, st.lds, ls)
+#define NPD_CONSUME(T, stype, s, ls) npd_consume<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, st, ls)
 
 /* single staged members */
-#define NPD_STAGED_F64(T, stype, member, k, ls) st.lds[((ls) + NPB_F64_SLOT(stype, member) + (k)) * NPB_WAVE + threadIdx.x]
-#define NPD_STAGED_I32(T, stype, member, ls) \
-  ((const int32_t *)(st.lds + ((ls) + NPB_##T##_NF64) * NPB_WAVE))[NPB_I32_SLOT(stype, T, member) * NPB_WAVE + threadIdx.x]
+#define NPD_STAGED_F64(T, stype, member, k, ls) NPD_LDS_REAL(ls, NPB_F64_SLOT(stype, member) + (k))
+#define NPD_STAGED_I32(T, stype, member, ls) NPD_LDS_INT(ls, NPB_##T##_NF64, NPB_I32_SLOT(stype, T, member))
 
 /* fixed slot plan (see the kernel): groups that are staged together */
 #define NPD_LS_PRIM 0

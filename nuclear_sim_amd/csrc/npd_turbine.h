@@ -172,8 +172,8 @@ typedef struct npd_stagesys_out_t {
  * tstg section is LDS-DMA'd there while the lubrication step and passes A/B run, npd_stage.h) and each
  * updated value is written straight to its SoA column; every column is read before it is written and
  * never re-read within a step, so the staged copy does not need the update */
-#define NPD_TSTG_RD(member, k) stg[(NPB_F64_SLOT(npb_tstg_t, member) + (k)) * NPB_WAVE]
-#define NPD_TSTG_WR(member, k, v) *NPD_F64P(double, NPB_TSTG_F64_BASE + NPB_F64_SLOT(npb_tstg_t, member) + (k), st.lane8) = (v)
+#define NPD_TSTG_RD(member, k) NPD_LDS_REAL(0, NPB_F64_SLOT(npb_tstg_t, member) + (k))
+#define NPD_TSTG_WR(member, k, v) *NPD_RP(NPB_TSTG_F64_BASE + NPB_F64_SLOT(npb_tstg_t, member) + (k)) = (npd_real_t)(v)
 
 /* one stage's share of TurbineStage.update_degradation (stage_system.py:294-339) and of
  * MetalTemperatureTracker.update_temperatures (enhanced_physics.py:73-166, time constant 1 h, ambient 25 C);
@@ -475,7 +475,7 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
   t->load_demand = load_demand;
   double pressure_stability_factor = npd_pressure_stability_factor(sg_pressures);
   npd_stagesys_out_t ss;
-  npd_stage_system_update(st, st.lds + threadIdx.x, steam_pressure, steam_temperature, steam_flow, load_demand,
+  npd_stage_system_update(st, (const double *)0, steam_pressure, steam_temperature, steam_flow, load_demand,
                           pressure_stability_factor, dt, &ss);
   NPD_STAMP(15);
   double stage_power_mw = ss.total_power;

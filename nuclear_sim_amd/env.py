@@ -107,7 +107,8 @@ class BatchedPlantEnv:
 
     def __init__(self, n_envs: int, dt: float = 1.0, heat_source: str = "constant", noise_enabled: bool = False,
                  noise_std_percent: float = 0.1, noise_seeds: Optional[Sequence[int]] = None,
-                 mode: str = "full", device: int = 0, params: Optional[dict] = None, maintenance: bool = False):
+                 mode: str = "full", device: int = 0, params: Optional[dict] = None, maintenance: bool = False,
+                 storage: str = "f64"):
         if not torch.cuda.is_available():
             raise _lib.NpbError("BatchedPlantEnv needs a HIP device (torch.cuda.is_available() is False); "
                                 "there is no CPU fallback")
@@ -128,7 +129,10 @@ class BatchedPlantEnv:
         self.params = p
         self.dt = float(dt)
         self._h = ctypes.c_void_p()
-        _lib.check(self.L.npb_create(ctypes.byref(p), self.n, device, ctypes.byref(self._h)))
+        # storage="f32": carried state kept as float in HBM, arithmetic still fp64 (BASELINE config 5; include/npb.h)
+        self.storage = storage
+        kind = {"f64": _lib.STORAGE_F64, "f32": _lib.STORAGE_F32}[storage]
+        _lib.check(self.L.npb_create_storage(ctypes.byref(p), self.n, device, kind, ctypes.byref(self._h)))
         with torch.cuda.device(self.device):
             self._obs = torch.zeros((self.n, 22), dtype=torch.float64, device=self.device)
             self._reward = torch.zeros(self.n, dtype=torch.float64, device=self.device)
@@ -230,6 +234,10 @@ class BatchedPlantEnv:
     @staticmethod
     def step_bytes_per_plant() -> int:
         return int(_lib.load().npb_step_bytes_per_plant())
+
+    def handle_step_bytes_per_plant(self) -> int:
+        """Algorithmic bytes of one plant-step for this handle's storage type."""
+        return int(self.L.npb_handle_step_bytes_per_plant(self._h))
 
     # ------------------------------------------------------------------ reference API
     def reset(self, mask=None) -> torch.Tensor:

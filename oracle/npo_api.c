@@ -28,6 +28,13 @@ NPO_API void npo_get_all(npo_plant_t *plants, int plant, double *f64, int32_t *i
   for (int s = 0; s < NPB_TOTAL_F64; s++) f64[s] = *npo_f64_slot(&plants[plant], s);
   for (int s = 0; s < NPB_TOTAL_I32; s++) i32[s] = *npo_i32_slot(&plants[plant], s);
 }
+/* checker for the product's fp32-storage mode (include/npb.h, NPB_STORAGE_F32): that mode computes in fp64 and
+ * rounds every real-valued state column to float when it is stored, once per step -- which is what this does
+ * to the oracle's state between steps */
+NPO_API void npo_round_state_f32(npo_plant_t *plants, int n) {
+  for (int i = 0; i < n; i++)
+    for (int s = 0; s < NPB_TOTAL_F64; s++) { double *v = npo_f64_slot(&plants[i], s); *v = (double)(float)*v; }
+}
 
 /* One step for n plants. Per-plant input columns may be NULL (defaults: NO_ACTION,
  * magnitude 1, setpoint/cooling unchanged, z = 0). Outputs may be NULL. */

@@ -91,3 +91,19 @@ def test_create_rejects_arena_beyond_32bit_offsets():
     assert rc != 0 and not h.value
     L.npb_last_error.restype = ctypes.c_char_p
     assert b"4 GiB" in L.npb_last_error(None)
+
+
+def test_create_storage_validates_its_argument():
+    """npb_create_storage: unknown storage kinds are refused before any device call; fp32 storage doubles
+    the number of plants one handle may carry (4 GiB of 4-byte columns)."""
+    import ctypes
+    from nuclear_sim_amd import _lib
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    assert L.npb_create_storage(None, 64, 0, 7, ctypes.byref(h)) != 0 and not h.value
+    L.npb_last_error.restype = ctypes.c_char_p
+    assert b"storage" in L.npb_last_error(None)
+    assert L.npb_create_storage(None, 2_200_000, 0, _lib.STORAGE_F32, ctypes.byref(h)) != 0 and not h.value
+    assert b"4 GiB" in L.npb_last_error(None)
+    L.npb_handle_step_bytes_per_plant.restype = ctypes.c_size_t
+    assert L.npb_handle_step_bytes_per_plant(None) == L.npb_step_bytes_per_plant()

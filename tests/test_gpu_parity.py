@@ -377,3 +377,121 @@ def test_full_size_properties():
     assert np.array_equal(r1.cpu().numpy()[perm], r2.cpu().numpy())
     sf = env.get_field("sec.total_steam_flow").cpu().numpy()
     np.testing.assert_allclose(o1[:, 14], sf / 1665, rtol=1e-14, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp32 state storage (BASELINE config 5): fp64 arithmetic, columns kept as float in HBM
+F32_EMU_RTOL = 2e-5     # against the oracle with its state rounded to float every step (same algorithm)
+F32_OBS_RTOL = 1e-4     # against the plain fp64 oracle (BASELINE config 5's bar, on observations)
+
+
+def _f32_pair(oracle_lib, n, **kw):
+    env = _env(n=n, storage="f32", **kw)
+    P = oracle_lib.Params()
+    P.dt = kw.get("dt", 1.0)
+    P.heat_source = 1 if kw.get("heat_source") == "reactor" else 0
+    P.hs_noise_enabled = 1 if kw.get("noise_enabled") else 0
+    P.maint_enabled = 1 if kw.get("maintenance") else 0
+    return env, P
+
+
+@pytest.mark.parametrize("heat_source", ["constant", "reactor"])
+def test_fp32_storage_matches_rounding_oracle(oracle_lib, heat_source):
+    """The fp32-storage build computes in fp64 and rounds the carried state to float once per step.  The oracle
+    with its state rounded to float between steps is that same algorithm, so the two must agree far inside the
+    mode's 1e-4 budget: integer columns and trip flags exactly, real columns to a few float ulps; and the
+    observations must stay within 1e-4 of the plain fp64 oracle."""
+    n, T = 200, 150
+    rng = np.random.default_rng(515)
+    env, P = _f32_pair(oracle_lib, n, heat_source=heat_source, noise_enabled=True)
+    assert env.handle_step_bytes_per_plant() < env.step_bytes_per_plant()
+    emu = oracle_lib.OraclePlants(n, P)
+    ref = oracle_lib.OraclePlants(n, P)
+    ics = {"prim.coolant_flow_rate": rng.uniform(15000, 25000, n), "prim.control_rod_position": rng.uniform(85, 100, n),
+           "prim.fuel_temperature": rng.uniform(450, 600, n)}
+    for name, v in ics.items():
+        env.set_field(name, v); emu.set(name, v); ref.set(name, v)
+    for k in range(4):
+        v = rng.uniform(40.0, 100.0, n)
+        env.set_field("pump.oil_level", v, instance=k); emu.set("pump.oil_level", v, instance=k); ref.set("pump.oil_level", v, instance=k)
+    emu.round_state_f32()
+    acts = rng.choice([0, 1, 4, 5, 8, 9, 10], size=(T, n)).astype(np.int32)
+    mags = rng.uniform(0, 1, size=(T, n))
+    z = rng.standard_normal((T, n))
+    sp = 90.0 + 10.0 * np.sin(np.arange(T)[:, None] / 15.0 + np.arange(n)[None, :])
+    worst = 0.0
+    for t in range(T):
+        e_obs, e_rew, e_done, e_flags, _ = emu.step(action=acts[t], magnitude=mags[t], setpoint=sp[t], noise_z=z[t])
+        emu.round_state_f32()
+        r_obs, _r, _d, _f, _ = ref.step(action=acts[t], magnitude=mags[t], setpoint=sp[t], noise_z=z[t])
+        obs, rew, done, info = env.step(action=acts[t], magnitude=mags[t], power_setpoint=sp[t], noise_z=z[t])
+        obs = obs.cpu().numpy()
+        np.testing.assert_allclose(obs, e_obs, rtol=F32_EMU_RTOL, atol=1e-9, err_msg="obs vs rounding oracle, step %d" % t)
+        np.testing.assert_allclose(rew.cpu().numpy(), e_rew, rtol=F32_EMU_RTOL, atol=1e-7, err_msg="reward step %d" % t)
+        assert np.array_equal(done.cpu().numpy(), e_done), "done step %d" % t
+        assert np.array_equal(info["trip_flags"].cpu().numpy().astype(np.uint32), e_flags), "trip flags step %d" % t
+        np.testing.assert_allclose(obs, r_obs, rtol=F32_OBS_RTOL, atol=1e-7, err_msg="obs vs fp64 oracle, step %d" % t)
+        worst = max(worst, float(np.max(np.abs(obs - r_obs) / np.maximum(np.abs(r_obs), 1e-3))))
+    f, i = _host_state(env)
+    of, oi = emu.state_all()
+    for kind, slot, label, _p in env_cols():
+        if kind == "i32":
+            assert np.array_equal(i[slot, :n], oi[:, slot]), label
+        else:
+            np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=F32_EMU_RTOL, atol=1e-7, err_msg=label)
+    print("fp32 storage: worst observation deviation from the fp64 oracle %.2e" % worst)
+
+
+def test_fp32_storage_field_roundtrip_and_maintenance(oracle_lib):
+    """get/set_field convert between the fp64 ABI and the float columns; the maintenance rule (its own kernel,
+    same storage type) still matches the rounding oracle, counters bit-exact."""
+    import torch
+    n, T = 130, 40
+    rng = np.random.default_rng(61)
+    env, P = _f32_pair(oracle_lib, n, dt=5.0, noise_enabled=True, maintenance=True)
+    v = torch.tensor(rng.uniform(20, 90, n), dtype=torch.float64, device=env.device)
+    env.set_field("pump.oil_level", v, instance=2)
+    back = env.get_field("pump.oil_level", instance=2)
+    assert torch.equal(back, v.float().double())          # rounded to float exactly once
+    host = env.get_field("pump.oil_level", instance=2).cpu().numpy()
+    env.set_field("pump.oil_level", host, instance=2)     # host buffers go through the conversion column
+    assert torch.equal(env.get_field("pump.oil_level", instance=2), back)
+    emu = oracle_lib.OraclePlants(n, P)
+    for k in range(4):
+        lv = rng.uniform(57.0, 59.5, n)
+        env.set_field("pump.oil_level", lv, instance=k); emu.set("pump.oil_level", lv, instance=k)
+    emu.round_state_f32()
+    z = rng.standard_normal((T, n))
+    cols = [c for c in env_cols() if c[2].startswith(("maint", "pump"))]
+    for t in range(T):
+        emu.step(setpoint=np.full(n, 90.0), noise_z=z[t]); emu.round_state_f32()
+        env.step(power_setpoint=np.full(n, 90.0), noise_z=z[t])
+    f, i = _host_state(env)
+    of, oi = emu.state_all()
+    for kind, slot, label, _p in cols:
+        if kind == "i32":
+            assert np.array_equal(i[slot, :n], oi[:, slot]), label
+        else:
+            np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=F32_EMU_RTOL, atol=1e-7, err_msg=label)
+    assert env.get_field("maint.maintenance_actions_performed").max().item() >= 1
+
+
+def test_fp32_storage_replays_golden_within_1e4():
+    """The reference's own trajectories (fixtures) replayed with fp32 storage: observations within 1e-4."""
+    for name in ("s1_constant_steady", "s2_reactor_actions", "s5_load_following", "m1_oil_top_off_staggered"):
+        g = Golden(name)
+        n = 64
+        env = _env(g, n=n, storage="f32")
+        f0, i0 = _host_state(env)
+        f, i, fm, im = g.split_state(g.state[0])
+        f0[fm, :] = f[fm, None]; i0[im, :] = i[im, None]
+        env.load_state_arrays(f0, i0)
+        if g.pokes:
+            continue
+        for t in range(g.T):
+            sp = None if np.isnan(g.setpoint[t]) else g.setpoint[t]
+            cw = None if np.isnan(g.cooling[t]) else g.cooling[t]
+            obs, rew, done, info = env.step(action=int(g.action[t]), magnitude=float(g.magnitude[t]), power_setpoint=sp,
+                                            cooling_water_temp=cw, noise_z=float(g.noise_z[t]))
+            np.testing.assert_allclose(obs[0].cpu().numpy(), g.obs[t], rtol=F32_OBS_RTOL, atol=1e-7, err_msg="%s step %d" % (name, t))
+            assert int(done[0].item()) == int(g.done[t])
