@@ -30,7 +30,7 @@ def lib():
         L.npo_get_i32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.npo_set_i32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.npo_init.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-        L.npo_round_state_f32.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.npo_round_state_f32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.npo_get_all.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.npo_step_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 10
         L.npo_observe_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
@@ -132,9 +132,11 @@ class OraclePlants:
             self.L.npo_get_all(_ptr(self._buf), pl, _ptr(F[pl]), _ptr(I[pl]))
         return F, I
 
-    def round_state_f32(self):
-        """Round every real-valued state column to float (emulates the product's fp32-storage mode)."""
-        self.L.npo_round_state_f32(_ptr(self._buf), self.n)
+    def round_state_f32(self, keep_f64=None):
+        """Round the real-valued state columns to float (emulates the product's fp32-storage mode);
+        keep_f64: uint8[total_f64], 1 = column stays fp64."""
+        k = None if keep_f64 is None else np.ascontiguousarray(keep_f64, dtype=np.uint8)
+        self.L.npo_round_state_f32(_ptr(self._buf), self.n, None if k is None else _ptr(k))
 
     def set_state(self, f64, i32, plant=0):
         for s, v in enumerate(f64):

@@ -31,9 +31,12 @@ NPO_API void npo_get_all(npo_plant_t *plants, int plant, double *f64, int32_t *i
 /* checker for the product's fp32-storage mode (include/npb.h, NPB_STORAGE_F32): that mode computes in fp64 and
  * rounds every real-valued state column to float when it is stored, once per step -- which is what this does
  * to the oracle's state between steps */
-NPO_API void npo_round_state_f32(npo_plant_t *plants, int n) {
+NPO_API void npo_round_state_f32(npo_plant_t *plants, int n, const uint8_t *keep_f64) {
   for (int i = 0; i < n; i++)
-    for (int s = 0; s < NPB_TOTAL_F64; s++) { double *v = npo_f64_slot(&plants[i], s); *v = (double)(float)*v; }
+    for (int s = 0; s < NPB_TOTAL_F64; s++) {
+      if (keep_f64 && keep_f64[s]) continue;   /* columns the mode keeps in fp64 (slow integrators) */
+      double *v = npo_f64_slot(&plants[i], s); *v = (double)(float)*v;
+    }
 }
 
 /* One step for n plants. Per-plant input columns may be NULL (defaults: NO_ACTION,

@@ -495,3 +495,69 @@ def test_fp32_storage_replays_golden_within_1e4():
                                             cooling_water_temp=cw, noise_z=float(g.noise_z[t]))
             np.testing.assert_allclose(obs[0].cpu().numpy(), g.obs[t], rtol=F32_OBS_RTOL, atol=1e-7, err_msg="%s step %d" % (name, t))
             assert int(done[0].item()) == int(g.done[t])
+
+
+def _config5_scripts(n, T):
+    """transient script per plant chosen by i mod 4, interleaved so that every wave diverges:
+    (0) none, (1) DECREASE_COOLANT_FLOW from step 100 on, (2) CONTROL_ROD_WITHDRAW alternating with DILUTE_BORON,
+    (3) state pokes: fuel_temperature = 1300 at step 150, oil level of pump 0 = 9 % at step 200.
+    In the reference's clipped physics (1) ends at the 5 000 kg/s floor, just above the low-flow scram, and (2)
+    saturates at rods 100 % / boron 0 without an excursion, so neither scrams by itself; (2) therefore also gets
+    the S4a poke (neutron_flux = 1.3e13, overpower scram) at step 250."""
+    kind = np.arange(n) % 4
+    acts = np.full((T, n), 8, dtype=np.int32)
+    acts[100:, kind == 1] = 3
+    acts[50::2, kind == 2] = 1
+    acts[51::2, kind == 2] = 9
+    return kind, acts
+
+
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_config5_transients(oracle_lib, storage):
+    """BASELINE config 5 / SURVEY 8d C5 on 2048 interleaved plants, ReactorHeatSource, 600 steps, against the fp64
+    oracle: fp64 storage to 1e-6, fp32 storage to 1e-4 on the observations; the step at which each plant scrams
+    and the step at which each trip flag first rises must be the oracle's exactly in both."""
+    from nuclear_sim_amd.env import equilibrium_state
+    n, T = 2048, 600
+    env = _env(n=n, heat_source="reactor", storage=storage)
+    P = oracle_lib.Params(); P.heat_source = 1
+    ora = oracle_lib.OraclePlants(n, P)
+    env.set_fields(equilibrium_state())
+    for key, v in equilibrium_state().items():
+        name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
+        ora.set(name, v, instance=inst, k=k)
+    kind, acts = _config5_scripts(n, T)
+    rtol = RTOL if storage == "f64" else F32_OBS_RTOL
+    first_done = np.full(n, -1); o_first_done = np.full(n, -1)
+    first_flag = {}; o_first_flag = {}
+    worst = 0.0
+    for t in range(T):
+        if t == 150:
+            v = np.where(kind == 3, 1300.0, env.get_field("prim.fuel_temperature").cpu().numpy())
+            ov = np.where(kind == 3, 1300.0, np.array([ora.get("prim.fuel_temperature", plant=p) for p in range(n)]))
+            env.set_field("prim.fuel_temperature", v); ora.set("prim.fuel_temperature", ov)
+        if t == 250:
+            v = np.where(kind == 2, 1.3e13, env.get_field("prim.neutron_flux").cpu().numpy())
+            ov = np.where(kind == 2, 1.3e13, np.array([ora.get("prim.neutron_flux", plant=p) for p in range(n)]))
+            env.set_field("prim.neutron_flux", v); ora.set("prim.neutron_flux", ov)
+        if t == 200:
+            v = np.where(kind == 3, 9.0, env.get_field("pump.oil_level").cpu().numpy())
+            ov = np.where(kind == 3, 9.0, np.array([ora.get("pump.oil_level", plant=p) for p in range(n)]))
+            env.set_field("pump.oil_level", v); ora.set("pump.oil_level", ov)
+        o_obs, _r, o_done, o_flags, _i = ora.step(action=acts[t])
+        obs, _rew, done, info = env.step(action=acts[t])
+        obs = obs.cpu().numpy(); done = done.cpu().numpy(); flags = info["trip_flags"].cpu().numpy().astype(np.uint32)
+        np.testing.assert_allclose(obs, o_obs, rtol=rtol, atol=1e-7 if storage == "f32" else 1e-12, err_msg="obs step %d" % t)
+        worst = max(worst, float(np.max(np.abs(obs - o_obs) / np.maximum(np.abs(o_obs), 1e-3))))
+        first_done = np.where((first_done < 0) & (done != 0), t, first_done)
+        o_first_done = np.where((o_first_done < 0) & (o_done != 0), t, o_first_done)
+        for bit in range(12):
+            m = (flags >> bit) & 1; om = (o_flags >> bit) & 1
+            a = first_flag.setdefault(bit, np.full(n, -1)); b = o_first_flag.setdefault(bit, np.full(n, -1))
+            first_flag[bit] = np.where((a < 0) & (m != 0), t, a); o_first_flag[bit] = np.where((b < 0) & (om != 0), t, b)
+    assert np.array_equal(first_done, o_first_done), "scram step indices"
+    for bit in range(12):
+        assert np.array_equal(first_flag[bit], o_first_flag[bit]), "first step of trip flag bit %d" % bit
+    assert (first_done[kind == 3] == 150).all() and (first_done[kind == 2] >= 250).all() and (first_done[kind < 2] < 0).all()
+    assert (first_flag[8][kind == 3] >= 200).all(), "pump 0 trips on low oil level after the poke at step 200"
+    print("config 5 (%s storage): worst observation deviation %.2e, scrams %d of %d" % (storage, worst, int((first_done >= 0).sum()), n))
