@@ -77,12 +77,18 @@ NPD_FN double npd_log10(double x) { return npd_log(x) * 4.34294481903251827651e-
 NPD_FN double npd_powc(double x, double c) { return npd_exp(c * npd_log(x)); }
 
 NPD_FN double npd_sq(double x) { return x * x; }
+/* np.clip / Python max / min on doubles.  A compare + select on fp64 costs a lone wave ~20 cycles (v_cmp_f64 to VCC,
+ * the VCC hazard nop, one v_cndmask_b32 per register half) against ~5 for v_max_f64 / v_min_f64, and the path has
+ * several hundred of them per plant-step (tools/membench/clipcost.hip, cmpsel.hip).  The hardware min / max return
+ * the non-NaN operand, while np.clip and Python's max(a, b) / min(a, b) give NaN when x / a is NaN; the
+ * fma(x, 0.0, r) restores exactly that (0 * NaN = NaN, 0 * finite = +-0 and r + +-0 = r).  The one difference left:
+ * an INFINITE x / a comes out as NaN instead of the bound / itself -- nothing on the path produces infinities from
+ * finite state, and NaN is the value the reference's own check_for_nan_values looks for. */
 NPD_FN double npd_clip(double x, double lo, double hi) { /* np.minimum(np.maximum(x, lo), hi): NaN propagates, lo > hi gives hi */
-  double t = (x < lo) ? lo : x;
-  return (t > hi) ? hi : t;
+  return __builtin_fma(x, 0.0, __builtin_fmin(__builtin_fmax(x, lo), hi));
 }
-NPD_FN double npd_pymax(double a, double b) { return (b > a) ? b : a; }
-NPD_FN double npd_pymin(double a, double b) { return (b < a) ? b : a; }
+NPD_FN double npd_pymax(double a, double b) { return __builtin_fma(a, 0.0, __builtin_fmax(a, b)); } /* (b > a) ? b : a */
+NPD_FN double npd_pymin(double a, double b) { return __builtin_fma(a, 0.0, __builtin_fmin(a, b)); } /* (b < a) ? b : a */
 
 /* per-step inputs of one plant (what step() receives, sim.py:130-133, plus the
  * pre-drawn standard-normal sample that replaces ConstantHeatSource's MT19937 draw) */

@@ -561,3 +561,40 @@ def test_config5_transients(oracle_lib, storage):
     assert (first_done[kind == 3] == 150).all() and (first_done[kind == 2] >= 250).all() and (first_done[kind < 2] < 0).all()
     assert (first_flag[8][kind == 3] >= 200).all(), "pump 0 trips on low oil level after the poke at step 200"
     print("config 5 (%s storage): worst observation deviation %.2e, scrams %d of %d" % (storage, worst, int((first_done >= 0).sum()), n))
+
+
+def test_nan_state_propagates_like_the_reference(oracle_lib):
+    """np.clip and Python's max / min pass a NaN first operand through; the device code clips with the hardware
+    min / max (which drop NaN) plus a term that restores exactly that (npd_common.h).  Poke NaN into secondary-side
+    columns of some plants and require the same NaN pattern and the same finite values as the oracle, which clips
+    by compare-and-select; the primary's check_for_nan_values reset (primary/__init__.py:247-270) is part of it."""
+    n, T = 192, 6
+    rng = np.random.default_rng(77)
+    env = _env(n=n, noise_enabled=True)
+    P = oracle_lib.Params(); P.hs_noise_enabled = 1
+    ora = oracle_lib.OraclePlants(n, P)
+    pokes = [("sg.water_level", 1), ("pump.oil_level", 0), ("turb.rotor_speed", 0), ("cond.condenser_pressure", 0),
+             ("prim.fuel_temperature", 0), ("fw.total_flow_rate", 0), ("pump.motor_temperature", 2), ("sg.secondary_pressure", 2)]
+    for j, (name, inst) in enumerate(pokes):
+        v = env.get_field(name, instance=inst).cpu().numpy().copy()
+        v[j::len(pokes) * 2] = np.nan            # every 16th plant, a different column each; plants 8..15 mod 16 stay clean
+        env.set_field(name, v, instance=inst); ora.set(name, v, instance=inst)
+    for t in range(T):
+        z = rng.standard_normal(n)
+        o_obs, o_rew, o_done, o_flags, _ = ora.step(noise_z=z)
+        obs, rew, done, info = env.step(noise_z=z)
+        obs = obs.cpu().numpy()
+        assert np.array_equal(np.isnan(obs), np.isnan(o_obs)), "NaN pattern of the observations, step %d" % t
+        np.testing.assert_allclose(obs, o_obs, rtol=RTOL, atol=1e-12, equal_nan=True, err_msg="obs step %d" % t)
+        assert np.array_equal(done.cpu().numpy(), o_done)
+        assert np.array_equal(info["trip_flags"].cpu().numpy().astype(np.uint32), o_flags), "trip flags step %d" % t
+    f, i = _host_state(env)
+    of, oi = ora.state_all()
+    for kind, slot, label, _p in env_cols():
+        if kind == "i32":
+            assert np.array_equal(i[slot, :n], oi[:, slot]), label
+        else:
+            assert np.array_equal(np.isnan(f[slot, :n]), np.isnan(of[:, slot])), "NaN pattern of " + label
+            np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, equal_nan=True, err_msg=label)
+    clean = (np.arange(n) % 16) >= 8
+    assert np.isnan(of[~clean]).any() and not np.isnan(of[clean]).any()

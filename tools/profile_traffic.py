@@ -75,8 +75,26 @@ def summarize(out):
     print(json.dumps(res, indent=1))
 
 
+def summarize_sq(out):
+    """Per-launch averages of every counter found under OUT (one sub-directory per --pmc pass), for
+    npb_step_kernel; SQ counters are summed over the chip, so they are also shown per wave (1 024 waves)."""
+    waves = N // 64
+    res = {}
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if not row["Kernel_Name"].startswith("npb_step_kernel"):
+                continue
+            res.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    print("%-28s %16s %14s" % ("counter", "per launch", "per wave"))
+    for k in sorted(res):
+        v = sum(res[k]) / len(res[k])
+        print("%-28s %16.0f %14.1f" % (k, v, v / waves))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[1] == "--summarize":
+    if len(sys.argv) > 2 and sys.argv[1] == "--summarize-sq":
+        summarize_sq(sys.argv[2])
+    elif len(sys.argv) > 2 and sys.argv[1] == "--summarize":
         summarize(sys.argv[2])
     else:
         run()
