@@ -55,12 +55,12 @@ NPB_API int npb_version(void);
 /* schema sizes (must equal NPB_TOTAL_F64 / NPB_TOTAL_I32 the caller was compiled against) */
 NPB_API int npb_num_f64(void);
 NPB_API int npb_num_i32(void);
-/* carried bytes per plant = 8 * num_f64 + 4 * num_i32: S_carry of the roofline accounting */
+/* arena bytes per plant (fp64 storage): 8 * (carried fp64 members + ceil(narrow members / 2) per section instance) */
 NPB_API size_t npb_state_bytes(void);
-/* algorithmic HBM bytes of one plant-step: 2 * state_bytes (read + write every carried column the
- * step kernel owns, i.e. all but the maint.* section, which only the maintenance kernel touches)
- * + per-step inputs (action 4 + magnitude/setpoint/noise/cooling 4*8) + outputs (obs 22*8 + reward 8
- * + done 1 + trip_flags 4 + info 10*8) */
+/* algorithmic HBM bytes of one plant-step: carried fp64 members read and written (16 B), int32 members read and
+ * written (8 B), output members written as float (4 B) -- all but the maint.* section, which only the
+ * maintenance kernel touches -- + per-step inputs (action 4 + magnitude/setpoint/noise/cooling 4*8) + outputs
+ * (obs 22*8 + reward 8 + done 1 + trip_flags 4 + info 10*8) */
 NPB_API size_t npb_step_bytes_per_plant(void);
 /* the same for one handle: with fp32 storage every real-valued column moves 4 bytes instead of 8 */
 NPB_API size_t npb_handle_step_bytes_per_plant(const NpbHandle *h);
@@ -97,10 +97,13 @@ NPB_API int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream);
  * npb_fields.h; buf holds n_plants elements (double or int32_t) on the device or the host. */
 NPB_API int npb_get_field(NpbHandle *h, int kind, int slot, void *buf, int buf_is_device, void *stream);
 NPB_API int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int buf_is_device, void *stream);
-/* raw arena: f64[slot * pitch + plant], i32[slot * pitch + plant] */
-NPB_API int npb_state_arena(NpbHandle *h, double **f64, int32_t **i32, size_t *pitch); /* fp64-storage handles */
-/* any handle: real[slot * pitch + plant] is double or float according to *storage */
-NPB_API int npb_state_arena_raw(NpbHandle *h, void **real, int32_t **i32, size_t *pitch, int *storage);
+/* raw arena (checkpointing, external kernels): one allocation of equally wide columns, column-major with `pitch`
+ * plants per column; the members of the schema are mapped onto columns as include/npb_fields.h describes */
+NPB_API int npb_state_arena(NpbHandle *h, void **arena, size_t *pitch, int *storage);
+/* where a field lives: arena column, position of a narrow member inside the column (0/1), and how it is stored
+ * (0 = carried real of the column width, 1 = output real stored as float, 2 = int32); element address =
+ * arena + (column * pitch + plant) * width + sub * 4, width = 8 (NPB_STORAGE_F64) or 4 (NPB_STORAGE_F32) */
+NPB_API int npb_locate_field(const NpbHandle *h, int kind, int slot, int *column, int *sub, int *access);
 
 /* NuclearPlantSimulator.step (sim.py:130-258) for every plant.  Input columns (device, n_plants each)
  * may be NULL: action -> NO_ACTION(8), magnitude -> 1.0, power_setpoint -> unchanged

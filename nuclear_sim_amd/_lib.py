@@ -60,7 +60,6 @@ def load():
     L.npb_storage.argtypes = [vp]
     L.npb_handle_step_bytes_per_plant.argtypes = [vp]
     L.npb_handle_step_bytes_per_plant.restype = ctypes.c_size_t
-    L.npb_state_arena_raw.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ci)]
     L.npb_destroy.argtypes = [vp]
     L.npb_last_error.argtypes = [vp]
     L.npb_last_error.restype = ctypes.c_char_p
@@ -69,7 +68,8 @@ def load():
     L.npb_reset.argtypes = [vp, vp, vp]
     L.npb_get_field.argtypes = [vp, ci, ci, vp, ci, vp]
     L.npb_set_field.argtypes = [vp, ci, ci, vp, ci, vp]
-    L.npb_state_arena.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    L.npb_state_arena.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ci)]
+    L.npb_locate_field.argtypes = [vp, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.npb_step.argtypes = [vp] + [vp] * 11
     L.npb_observe.argtypes = [vp, vp, vp]
     L.npb_debug_touch.argtypes = [vp, vp]

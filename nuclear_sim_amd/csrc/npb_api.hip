@@ -17,9 +17,8 @@ struct NpbHandle {
   size_t pitch;        /* n_plants rounded up to a multiple of the wave size */
   int storage;         /* NPB_STORAGE_F64 | NPB_STORAGE_F32: element type of the real-valued columns */
   size_t real_bytes;   /* 8 | 4 */
-  void *f64;           /* [NPB_TOTAL_F64][pitch] of double (or float) */
-  int32_t *i32;        /* [NPB_TOTAL_I32][pitch] */
-  double *convert;     /* fp32 storage only: one fp64 column used by get/set_field with host buffers */
+  void *f64;           /* the arena: [NPB_TOTAL_COL64][pitch] 8-byte columns, or [NPB_TOTAL_COL32][pitch] 4-byte ones */
+  double *convert;     /* one staging column (pitch doubles) used by get/set_field with host buffers */
   std::string error;
 };
 
@@ -33,20 +32,51 @@ static int fail(NpbHandle *h, int code, const char *what, hipError_t e = hipSucc
 }
 #define NPB_HIP(h, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(h, NPB_EHIP, #call, e__); } while (0)
 
+/* where the members of the schema live in the arena (include/npb_fields.h: carried fp64 members one per column,
+ * then the narrow members -- outputs as float, int32 -- two per 8-byte column or one per 4-byte column) */
+struct SectionInfo { int f64_base, nf64, nout, i32_base, ni32, count, col64_base, ncol64, col32_base, ncol32; };
+static const SectionInfo g_sections[] = {
+#define NPB__INFO(member, T, stype, count) \
+  {NPB_##T##_F64_BASE, NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_I32_BASE, NPB_##T##_NI32, (count), \
+   NPB_##T##_COL64_BASE, NPB_##T##_NCOL64, NPB_##T##_COL32_BASE, NPB_##T##_NCOL32},
+  NPB_SECTIONS(NPB__INFO)
+#undef NPB__INFO
+};
+/* kind: NPB_KIND_F64 / NPB_KIND_I32 and the global slot -> arena column, narrow position, access kind of the field kernels */
+static bool locate(int storage, int kind, int slot, int *col, int *sub, int *akind) {
+  const int npc = storage == NPB_STORAGE_F32 ? 1 : 2;
+  for (const SectionInfo &s : g_sections) {
+    const int base = kind == NPB_KIND_F64 ? s.f64_base : s.i32_base, per = kind == NPB_KIND_F64 ? s.nf64 : s.ni32;
+    if (per == 0 || slot < base || slot >= base + per * s.count) continue;
+    const int inst = (slot - base) / per, k = (slot - base) % per, ncarry = s.nf64 - s.nout;
+    const int col0 = (storage == NPB_STORAGE_F32 ? s.col32_base + inst * s.ncol32 : s.col64_base + inst * s.ncol64);
+    if (kind == NPB_KIND_F64 && k < ncarry) { *col = col0 + k; *sub = 0; *akind = 0; return true; }
+    const int j = kind == NPB_KIND_F64 ? k - ncarry : s.nout + k;
+    *col = col0 + ncarry + j / npc; *sub = j % npc; *akind = kind == NPB_KIND_F64 ? 1 : 2;
+    return true;
+  }
+  return false;
+}
+static size_t arena_columns(int storage) { return storage == NPB_STORAGE_F32 ? (size_t)NPB_TOTAL_COL32 : (size_t)NPB_TOTAL_COL64; }
+
 extern "C" {
 
 int npb_version(void) { return NPB_VERSION; }
 int npb_num_f64(void) { return NPB_TOTAL_F64; }
 int npb_num_i32(void) { return NPB_TOTAL_I32; }
-size_t npb_state_bytes(void) { return (size_t)NPB_TOTAL_F64 * 8 + (size_t)NPB_TOTAL_I32 * 4; }
-size_t npb_step_bytes_per_plant(void) {
-  const size_t maint = (size_t)NPB_MAINT_NF64 * 8 + (size_t)NPB_MAINT_NI32 * 4; /* not touched by the step kernel */
-  return 2 * (npb_state_bytes() - maint) + (4 + 4 * 8) + (NPB_OBS_DIM * 8 + 8 + 1 + 4 + NPB_INFO_DIM * 8);
+size_t npb_state_bytes(void) { return (size_t)NPB_TOTAL_COL64 * 8; }
+/* carried fp64 members are read and written, int32 members too, output members are only written (as float);
+ * the maint.* section belongs to the maintenance kernel */
+static size_t step_bytes(size_t real_bytes) {
+  size_t carried = 0, outputs = 0, ints = 0;
+  for (const SectionInfo &s : g_sections) {
+    if (s.f64_base == NPB_MAINT_F64_BASE) continue;
+    carried += (size_t)(s.nf64 - s.nout) * s.count; outputs += (size_t)s.nout * s.count; ints += (size_t)s.ni32 * s.count;
+  }
+  return 2 * carried * real_bytes + 2 * ints * 4 + outputs * 4 + (4 + 4 * 8) + (NPB_OBS_DIM * 8 + 8 + 1 + 4 + NPB_INFO_DIM * 8);
 }
-size_t npb_handle_step_bytes_per_plant(const NpbHandle *h) {
-  if (!h || h->storage == NPB_STORAGE_F64) return npb_step_bytes_per_plant();
-  return npb_step_bytes_per_plant() - 2 * (size_t)(NPB_TOTAL_F64 - NPB_MAINT_NF64) * 4;
-}
+size_t npb_step_bytes_per_plant(void) { return step_bytes(8); }
+size_t npb_handle_step_bytes_per_plant(const NpbHandle *h) { return step_bytes(h && h->storage == NPB_STORAGE_F32 ? 4 : 8); }
 void npb_default_params(npb_params_t *p) { npb_params_default(p); }
 
 const char *npb_last_error(const NpbHandle *h) { return h ? h->error.c_str() : g_create_error.c_str(); }
@@ -64,7 +94,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   if (storage != NPB_STORAGE_F64 && storage != NPB_STORAGE_F32) return fail(nullptr, NPB_EINVAL, "npb_create: storage must be NPB_STORAGE_F64 or NPB_STORAGE_F32");
   const size_t real_bytes = storage == NPB_STORAGE_F32 ? sizeof(float) : sizeof(double);
   /* the step kernel addresses a column as (one 64-bit base) + (32-bit byte offset), nuclear_sim_amd/csrc/npd_stage.h */
-  if ((((size_t)n_plants + 63) / 64 * 64) * NPB_TOTAL_F64 * real_bytes >= ((size_t)1 << 32))
+  if ((((size_t)n_plants + 63) / 64 * 64) * arena_columns(storage) * real_bytes >= ((size_t)1 << 32))
     return fail(nullptr, NPB_EINVAL, "npb_create: more than 4 GiB of real-valued state per handle (about one million fp64 plants); use several handles");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
@@ -76,20 +106,18 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   h->n_plants = n_plants; h->device = device;
   h->pitch = ((size_t)n_plants + 63) / 64 * 64;
   h->storage = storage; h->real_bytes = real_bytes;
-  h->f64 = nullptr; h->i32 = nullptr; h->convert = nullptr;
-  e = hipMalloc(&h->f64, (size_t)NPB_TOTAL_F64 * h->pitch * real_bytes);
-  if (e == hipSuccess) e = hipMalloc((void **)&h->i32, (size_t)NPB_TOTAL_I32 * h->pitch * sizeof(int32_t));
-  if (e == hipSuccess && storage == NPB_STORAGE_F32) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double));
+  h->f64 = nullptr; h->convert = nullptr;
+  e = hipMalloc(&h->f64, arena_columns(storage) * h->pitch * real_bytes);
+  if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double));
   if (e != hipSuccess) {
     if (h->f64) (void)hipFree(h->f64);
-    if (h->i32) (void)hipFree(h->i32);
     delete h;
     return fail(nullptr, NPB_ENOMEM, "npb_create: hipMalloc of the state arena failed", e);
   }
-  (storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, n_plants, h->pitch, h->f64, h->i32, nullptr, nullptr);
+  (storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, n_plants, h->pitch, h->f64, nullptr, nullptr);
   e = hipDeviceSynchronize();
   if (e != hipSuccess) {
-    (void)hipFree(h->f64); (void)hipFree(h->i32); if (h->convert) (void)hipFree(h->convert);
+    (void)hipFree(h->f64); if (h->convert) (void)hipFree(h->convert);
     delete h; return fail(nullptr, NPB_EHIP, "npb_create: init kernel failed", e);
   }
   *out = h;
@@ -99,7 +127,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
 int npb_destroy(NpbHandle *h) {
   if (!h) return NPB_OK;
   (void)hipSetDevice(h->device);
-  (void)hipFree(h->f64); (void)hipFree(h->i32);
+  (void)hipFree(h->f64);
   if (h->convert) (void)hipFree(h->convert);
   delete h;
   return NPB_OK;
@@ -114,79 +142,68 @@ int npb_set_params(NpbHandle *h, const npb_params_t *params) {
 int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream) {
   if (!h) return NPB_EINVAL;
   NPB_HIP(h, hipSetDevice(h->device));
-  (h->storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, h->pitch, h->f64, h->i32, mask, (hipStream_t)stream);
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, h->pitch, h->f64, mask, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
   return NPB_OK;
 }
 
-static int field_ptr(NpbHandle *h, int kind, int slot, void **col, size_t *bytes) {
-  if (kind == NPB_KIND_F64) {
-    if (slot < 0 || slot >= NPB_TOTAL_F64) return fail(h, NPB_EINVAL, "field slot out of range");
-    *col = (char *)h->f64 + (size_t)slot * h->pitch * h->real_bytes; *bytes = (size_t)h->n_plants * sizeof(double);
-  } else if (kind == NPB_KIND_I32) {
-    if (slot < 0 || slot >= NPB_TOTAL_I32) return fail(h, NPB_EINVAL, "field slot out of range");
-    *col = h->i32 + (size_t)slot * h->pitch; *bytes = (size_t)h->n_plants * sizeof(int32_t);
-  } else {
-    return fail(h, NPB_EINVAL, "field kind must be NPB_KIND_F64 or NPB_KIND_I32");
-  }
+/* one member of every plant <-> a contiguous buffer: a small gather / scatter kernel (members share columns and
+ * outputs are stored as float, so this is never a plain copy); host buffers go through the staging column */
+static int field_args(NpbHandle *h, int kind, int slot, int *col, int *sub, int *akind, size_t *bytes) {
+  if (kind != NPB_KIND_F64 && kind != NPB_KIND_I32) return fail(h, NPB_EINVAL, "field kind must be NPB_KIND_F64 or NPB_KIND_I32");
+  if (!locate(h->storage, kind, slot, col, sub, akind)) return fail(h, NPB_EINVAL, "field slot out of range");
+  *bytes = (size_t)h->n_plants * (kind == NPB_KIND_F64 ? sizeof(double) : sizeof(int32_t));
   return NPB_OK;
 }
 
 int npb_get_field(NpbHandle *h, int kind, int slot, void *buf, int buf_is_device, void *stream) {
   if (!h || !buf) return NPB_EINVAL;
-  void *col; size_t bytes;
-  int rc = field_ptr(h, kind, slot, &col, &bytes);
+  int col, sub, akind; size_t bytes;
+  int rc = field_args(h, kind, slot, &col, &sub, &akind, &bytes);
   if (rc) return rc;
   NPB_HIP(h, hipSetDevice(h->device));
-  if (kind == NPB_KIND_F64 && h->storage == NPB_STORAGE_F32) { /* the ABI speaks fp64: widen the column on the device */
-    double *wide = buf_is_device ? (double *)buf : h->convert;
-    npb32_launch_col_to_f64((const float *)col, wide, h->n_plants, (hipStream_t)stream);
-    NPB_HIP(h, hipGetLastError());
-    if (buf_is_device) return NPB_OK;
-    col = wide;
+  void *dst = buf_is_device ? buf : (void *)h->convert;
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_field_get : npb_launch_field_get)(h->f64, h->pitch, col, sub, akind, dst, h->n_plants, (hipStream_t)stream);
+  NPB_HIP(h, hipGetLastError());
+  if (!buf_is_device) {
+    NPB_HIP(h, hipMemcpyAsync(buf, dst, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    NPB_HIP(h, hipStreamSynchronize((hipStream_t)stream));
   }
-  NPB_HIP(h, hipMemcpyAsync(buf, col, bytes, buf_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, (hipStream_t)stream));
-  if (!buf_is_device) NPB_HIP(h, hipStreamSynchronize((hipStream_t)stream));
   return NPB_OK;
 }
 
 int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int buf_is_device, void *stream) {
   if (!h || !buf) return NPB_EINVAL;
-  void *col; size_t bytes;
-  int rc = field_ptr(h, kind, slot, &col, &bytes);
+  int col, sub, akind; size_t bytes;
+  int rc = field_args(h, kind, slot, &col, &sub, &akind, &bytes);
   if (rc) return rc;
   NPB_HIP(h, hipSetDevice(h->device));
-  if (kind == NPB_KIND_F64 && h->storage == NPB_STORAGE_F32) { /* round the fp64 values to the stored type on the device */
-    const double *wide = (const double *)buf;
-    if (!buf_is_device) {
-      NPB_HIP(h, hipMemcpyAsync(h->convert, buf, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
-      wide = h->convert;
-    }
-    npb32_launch_col_from_f64((float *)col, wide, h->n_plants, (hipStream_t)stream);
-    NPB_HIP(h, hipGetLastError());
-    if (!buf_is_device) NPB_HIP(h, hipStreamSynchronize((hipStream_t)stream));
-    return NPB_OK;
+  const void *src = buf;
+  if (!buf_is_device) {
+    NPB_HIP(h, hipMemcpyAsync(h->convert, buf, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    src = h->convert;
   }
-  NPB_HIP(h, hipMemcpyAsync(col, buf, bytes, buf_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, (hipStream_t)stream));
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_field_set : npb_launch_field_set)(h->f64, h->pitch, col, sub, akind, src, h->n_plants, (hipStream_t)stream);
+  NPB_HIP(h, hipGetLastError());
   if (!buf_is_device) NPB_HIP(h, hipStreamSynchronize((hipStream_t)stream));
   return NPB_OK;
 }
 
-int npb_state_arena(NpbHandle *h, double **f64, int32_t **i32, size_t *pitch) {
+int npb_state_arena(NpbHandle *h, void **arena, size_t *pitch, int *storage) {
   if (!h) return NPB_EINVAL;
-  if (h->storage != NPB_STORAGE_F64) return fail(h, NPB_EINVAL, "npb_state_arena: fp32-storage handle; use npb_state_arena_raw");
-  if (f64) *f64 = (double *)h->f64;
-  if (i32) *i32 = h->i32;
+  if (arena) *arena = h->f64;
   if (pitch) *pitch = h->pitch;
+  if (storage) *storage = h->storage;
   return NPB_OK;
 }
 
-int npb_state_arena_raw(NpbHandle *h, void **real, int32_t **i32, size_t *pitch, int *storage) {
+int npb_locate_field(const NpbHandle *h, int kind, int slot, int *column, int *sub, int *access) {
   if (!h) return NPB_EINVAL;
-  if (real) *real = h->f64;
-  if (i32) *i32 = h->i32;
-  if (pitch) *pitch = h->pitch;
-  if (storage) *storage = h->storage;
+  int c, s2, a;
+  if ((kind != NPB_KIND_F64 && kind != NPB_KIND_I32) || !locate(h->storage, kind, slot, &c, &s2, &a)) return NPB_EINVAL;
+  if (column) *column = c;
+  if (sub) *sub = s2;
+  if (access) *access = a;
   return NPB_OK;
 }
 
@@ -195,9 +212,9 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
              uint32_t *trip_flags, double *info, void *stream) {
   if (!h) return NPB_EINVAL;
   const bool narrow = h->storage == NPB_STORAGE_F32;
-  (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, h->i32, action, magnitude, power_setpoint,
+  (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, action, magnitude, power_setpoint,
                                                  noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, (hipStream_t)stream);
-  if (h->params.maint_enabled) (narrow ? npb32_launch_maint : npb_launch_maint)(&h->params, h->pitch, h->f64, h->i32, (hipStream_t)stream);
+  if (h->params.maint_enabled) (narrow ? npb32_launch_maint : npb_launch_maint)(&h->params, h->pitch, h->f64, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_step: kernel launch failed", e);
   return NPB_OK;
@@ -206,7 +223,7 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
 int npb_debug_touch(NpbHandle *h, void *stream) {
   if (!h) return NPB_EINVAL;
   if (h->storage != NPB_STORAGE_F64) return fail(h, NPB_EINVAL, "npb_debug_touch: fp64-storage handles only");
-  npb_launch_touch(h->pitch, (double *)h->f64, h->i32, (hipStream_t)stream);
+  npb_launch_touch(h->pitch, (double *)h->f64, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_debug_touch: kernel launch failed", e);
   return NPB_OK;
@@ -214,7 +231,7 @@ int npb_debug_touch(NpbHandle *h, void *stream) {
 
 int npb_observe(NpbHandle *h, double *obs, void *stream) {
   if (!h || !obs) return NPB_EINVAL;
-  (h->storage == NPB_STORAGE_F32 ? npb32_launch_observe : npb_launch_observe)(h->params.mode, h->n_plants, h->pitch, h->f64, h->i32, obs, (hipStream_t)stream);
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_observe : npb_launch_observe)(h->params.mode, h->n_plants, h->pitch, h->f64, obs, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_observe: kernel launch failed", e);
   return NPB_OK;

@@ -1,6 +1,6 @@
 /* npb_kernels.h -- host-callable launchers of the device kernels (internal to libnpb.so).
- * npb_kernels.hip is compiled twice: fp64 storage (npb_launch_*) and fp32 storage (npb32_launch_*, -DNPB_BUILD_F32);
- * the arena pointer is void* here and typed inside each translation unit. */
+ * npb_kernels.hip is compiled twice: 8-byte arena columns (npb_launch_*) and 4-byte columns for fp32 storage
+ * (npb32_launch_*, -DNPB_BUILD_F32); the arena pointer is void* here and typed inside each translation unit. */
 #ifndef NPB_KERNELS_H
 #define NPB_KERNELS_H
 #include <hip/hip_runtime.h>
@@ -10,18 +10,19 @@
 extern "C" {
 #endif
 #define NPB__DECL(prefix) \
-  void prefix##step(const npb_params_t *P, int n_plants, size_t npad, void *f64, int32_t *i32, const int32_t *action, \
+  void prefix##step(const npb_params_t *P, int n_plants, size_t npad, void *arena, const int32_t *action, \
                     const double *magnitude, const double *setpoint, const double *noise_z, const double *cw_temp, \
                     double *obs, double *reward, uint8_t *done, uint32_t *trip_flags, double *info, hipStream_t stream); \
-  void prefix##maint(const npb_params_t *P, size_t npad, void *f64, int32_t *i32, hipStream_t stream); \
-  void prefix##observe(int mode, int n_plants, size_t npad, const void *f64, const int32_t *i32, double *obs, hipStream_t stream); \
-  void prefix##init(const npb_params_t *P, int n_plants, size_t npad, void *f64, int32_t *i32, const uint8_t *mask, hipStream_t stream);
+  void prefix##maint(const npb_params_t *P, size_t npad, void *arena, hipStream_t stream); \
+  void prefix##observe(int mode, int n_plants, size_t npad, const void *arena, double *obs, hipStream_t stream); \
+  void prefix##init(const npb_params_t *P, int n_plants, size_t npad, void *arena, const uint8_t *mask, hipStream_t stream); \
+  /* kind: 0 carried real, 1 output real (float), 2 int32; buffers: double for reals, int32 for ints */ \
+  void prefix##field_get(const void *arena, size_t npad, int col, int sub, int kind, void *out, int n, hipStream_t stream); \
+  void prefix##field_set(void *arena, size_t npad, int col, int sub, int kind, const void *in, int n, hipStream_t stream);
 NPB__DECL(npb_launch_)
 NPB__DECL(npb32_launch_)
 #undef NPB__DECL
-void npb_launch_touch(size_t npad, double *f64, int32_t *i32, hipStream_t stream);
-void npb32_launch_col_to_f64(const float *col, double *out, int n, hipStream_t stream);
-void npb32_launch_col_from_f64(float *col, const double *in, int n, hipStream_t stream);
+void npb_launch_touch(size_t npad, double *arena, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

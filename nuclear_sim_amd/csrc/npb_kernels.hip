@@ -52,67 +52,110 @@ extern "C" __attribute__((visibility("default"))) int npb_debug_set_stamp_buffer
 
 #define NPB_OBS_PAD 23 /* LDS row stride in doubles: 22 + 1 keeps the transpose at <= 2-way bank conflicts */
 
-/* ---- section <-> SoA column movers.  A section struct is NF64 doubles followed by NI32 int32s
- * (include/npb_fields.h), so a fully unrolled constant-index copy is all that is needed. */
-template <int NF, int NI, typename S>
-__device__ __forceinline__ void npd_load(S &s, const npd_real_t *__restrict__ f64, const int32_t *__restrict__ i32,
-                                         size_t N, size_t p, int fbase, int ibase) {
+/* ---- section <-> arena movers outside the step kernel (init, observe, maintenance): plain global accesses.
+ * A section struct is NF doubles (the last NO of them outputs) followed by NI int32s (include/npb_fields.h); in the
+ * arena the NF - NO carried doubles take one column each and the narrow members share columns (npd_stage.h). */
+__device__ __forceinline__ char *npd_gaddr(npd_real_t *arena, size_t N, size_t p, int col) {
+  return (char *)(arena + (size_t)col * N + p);
+}
+template <int NF, int NO, int NI, typename S>
+__device__ __forceinline__ void npd_load(S &s, const npd_real_t *__restrict__ arena, size_t N, size_t p, int col0) {
   double *d = reinterpret_cast<double *>(&s);
+  constexpr int NC = NF - NO;
+  npd_real_t *a = const_cast<npd_real_t *>(arena);
 #pragma unroll
-  for (int k = 0; k < NF; k++) d[k] = (double)f64[(size_t)(fbase + k) * N + p];
+  for (int k = 0; k < NC; k++) d[k] = (double)*(const npd_real_t *)npd_gaddr(a, N, p, col0 + k);
+#pragma unroll
+  for (int j = 0; j < NO; j++) d[NC + j] = (double)*(const float *)(npd_gaddr(a, N, p, col0 + NC + j / NPD_NPC) + (j % NPD_NPC) * 4);
   int32_t *q = reinterpret_cast<int32_t *>(d + NF);
 #pragma unroll
-  for (int k = 0; k < NI; k++) q[k] = i32[(size_t)(ibase + k) * N + p];
+  for (int k = 0; k < NI; k++) q[k] = *(const int32_t *)(npd_gaddr(a, N, p, col0 + NC + (NO + k) / NPD_NPC) + ((NO + k) % NPD_NPC) * 4);
 }
-template <int NF, int NI, typename S>
-__device__ __forceinline__ void npd_store(const S &s, npd_real_t *__restrict__ f64, int32_t *__restrict__ i32,
-                                          size_t N, size_t p, int fbase, int ibase) {
+template <int NF, int NO, int NI, typename S>
+__device__ __forceinline__ void npd_store(const S &s, npd_real_t *__restrict__ arena, size_t N, size_t p, int col0) {
   const double *d = reinterpret_cast<const double *>(&s);
+  constexpr int NC = NF - NO;
 #pragma unroll
-  for (int k = 0; k < NF; k++) f64[(size_t)(fbase + k) * N + p] = (npd_real_t)d[k];
+  for (int k = 0; k < NC; k++) *(npd_real_t *)npd_gaddr(arena, N, p, col0 + k) = (npd_real_t)d[k];
+#pragma unroll
+  for (int j = 0; j < NO; j++) *(float *)(npd_gaddr(arena, N, p, col0 + NC + j / NPD_NPC) + (j % NPD_NPC) * 4) = (float)d[NC + j];
   const int32_t *q = reinterpret_cast<const int32_t *>(d + NF);
 #pragma unroll
-  for (int k = 0; k < NI; k++) i32[(size_t)(ibase + k) * N + p] = q[k];
+  for (int k = 0; k < NI; k++) *(int32_t *)(npd_gaddr(arena, N, p, col0 + NC + (NO + k) / NPD_NPC) + ((NO + k) % NPD_NPC) * 4) = q[k];
+  if ((NO + NI) % NPD_NPC) *(int32_t *)(npd_gaddr(arena, N, p, col0 + NC + (NO + NI) / NPD_NPC) + 4) = 0; /* unused half of the last column */
 }
-#define NPD_LOAD(T, stype, s, inst) \
-  npd_load<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, f64, i32, N, p, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
-                                                  NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32)
-#define NPD_STORE(T, stype, s, inst) \
-  npd_store<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, f64, i32, N, p, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
-                                                   NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32)
-/* single-column access */
-#define NPD_F64_COL(T, stype, member, inst) \
-  f64[(size_t)(NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64 + NPB_F64_SLOT(stype, member)) * N + p]
-#define NPD_F64_COLK(T, stype, member, inst, k) \
-  f64[(size_t)(NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64 + NPB_F64_SLOT(stype, member) + (k)) * N + p]
+#define NPD_LOAD(T, stype, s, inst) npd_load<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype>(s, f64, N, p, NPD_SEC_COL(T, inst))
+#define NPD_STORE(T, stype, s, inst) npd_store<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype>(s, f64, N, p, NPD_SEC_COL(T, inst))
+/* single member reads: fp64 member (carried or output) / int32 member */
+template <int NC> __device__ __forceinline__ double npd_gread_real(const npd_real_t *arena, size_t N, size_t p, int col0, int idx) {
+  npd_real_t *a = const_cast<npd_real_t *>(arena);
+  if (idx < NC) return (double)*(const npd_real_t *)npd_gaddr(a, N, p, col0 + idx);
+  const int j = idx - NC;
+  return (double)*(const float *)(npd_gaddr(a, N, p, col0 + NC + j / NPD_NPC) + (j % NPD_NPC) * 4);
+}
+#define NPD_F64_COL(T, stype, member, inst) npd_gread_real<NPB_##T##_NCARRY>(f64, N, p, NPD_SEC_COL(T, inst), NPB_F64_SLOT(stype, member))
+#define NPD_F64_COLK(T, stype, member, inst, k) npd_gread_real<NPB_##T##_NCARRY>(f64, N, p, NPD_SEC_COL(T, inst), NPB_F64_SLOT(stype, member) + (k))
 #define NPD_I32_COL(T, stype, member, inst) \
-  i32[(size_t)(NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32 + NPB_I32_SLOT(stype, T, member)) * N + p]
+  (*(const int32_t *)(npd_gaddr(const_cast<npd_real_t *>(f64), N, p, NPD_SEC_COL(T, inst) + NPB_##T##_NCARRY + (NPB_##T##_NOUT + NPB_I32_SLOT(stype, T, member)) / NPD_NPC) + \
+                      ((NPB_##T##_NOUT + NPB_I32_SLOT(stype, T, member)) % NPD_NPC) * 4))
 
-/* step kernel: section / column stores through the pinned 32-bit-offset addressing of npd_stage.h */
-template <int NF, int NI, typename S>
-__device__ __forceinline__ void npd_st_store(const S &s, const npd_stage_t &st, int fbase, int ibase) {
+/* ---- step kernel: section stores through the pinned 32-bit-offset addressing of npd_stage.h.
+ * bits of narrow member j of a section struct: outputs as float, then the int32 members */
+template <int NF, int NO, int NI, typename S>
+__device__ __forceinline__ uint32_t npd_narrow_bits(const S &s, int j) {
   const double *d = reinterpret_cast<const double *>(&s);
-#pragma unroll
-  for (int k = 0; k < NF; k++) *NPD_RP(fbase + k) = (npd_real_t)d[k];
   const int32_t *q = reinterpret_cast<const int32_t *>(d + NF);
-#pragma unroll
-  for (int k = 0; k < NI; k++) *NPD_I32P(int32_t, ibase + k, st.lane4) = q[k];
+  if (j < NO) return __float_as_uint((float)d[NF - NO + j]);
+  if (j < NO + NI) return (uint32_t)q[j - NO];
+  return 0u;
 }
-template <int NF, int NI, typename S>
-__device__ __forceinline__ void npd_st_load(S &s, const npd_stage_t &st, int fbase, int ibase) {
-  double *d = reinterpret_cast<double *>(&s);
+/* store the narrow column c of a section instance (col = its arena column) from NPD_NPC 32-bit words */
+__device__ __forceinline__ void npd_st_store_narrow(const npd_stage_t &st, int col, uint32_t w0, uint32_t w1) {
+#ifdef NPB_BUILD_F32
+  *NPD_NP(uint32_t, col, 0) = w0;
+#else
+  typedef uint32_t npd_u32x2 __attribute__((ext_vector_type(2)));
+  npd_u32x2 v; v.x = w0; v.y = w1;
+  *NPD_RPO(npd_u32x2, col, st.laner) = v;
+#endif
+}
+template <int NF, int NO, int NI, typename S>
+__device__ __forceinline__ void npd_st_store(const S &s, const npd_stage_t &st, int col0) {
+  const double *d = reinterpret_cast<const double *>(&s);
+  constexpr int NC = NF - NO, NNC = (NO + NI + NPD_NPC - 1) / NPD_NPC;
 #pragma unroll
-  for (int k = 0; k < NF; k++) d[k] = (double)*NPD_RP(fbase + k);
+  for (int k = 0; k < NC; k++) *NPD_RP(col0 + k) = (npd_real_t)d[k];
+#pragma unroll
+  for (int c = 0; c < NNC; c++)
+    npd_st_store_narrow(st, col0 + NC + c, npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1));
+}
+template <int NF, int NO, int NI, int SID, typename S>
+__device__ __forceinline__ void npd_st_load(S &s, const npd_stage_t &st, int col0) {
+  double *d = reinterpret_cast<double *>(&s);
+  constexpr int NC = NF - NO;
+#pragma unroll
+  for (int k = 0; k < NC; k++) d[k] = (double)*NPD_RP(col0 + k);
+#pragma unroll
+  for (int j = 0; j < NO; j++) d[NC + j] = (double)*NPD_NP(const float, col0 + NC + j / NPD_NPC, j % NPD_NPC);
   int32_t *q = reinterpret_cast<int32_t *>(d + NF);
 #pragma unroll
-  for (int k = 0; k < NI; k++) q[k] = *NPD_I32P(const int32_t, ibase + k, st.lane4);
+  for (int k = 0; k < NI; k++) q[k] = *NPD_NP(const int32_t, col0 + NC + (NO + k) / NPD_NPC, (NO + k) % NPD_NPC);
+  NPD_PROBE_STRUCT(SID, NF, NI, d, q);
 }
 #define NPD_ST_LOAD(T, stype, s, inst) \
-  npd_st_load<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
-                                                     NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32)
+  npd_st_load<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, NPB_##T##_F64_BASE, stype>(s, st, NPD_SEC_COL(T, inst))
 #define NPD_ST_STORE(T, stype, s, inst) \
-  npd_st_store<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
-                                                      NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32)
+  npd_st_store<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype>(s, st, NPD_SEC_COL(T, inst))
+/* only the narrow columns of a section (its outputs and int32 members) */
+template <int NF, int NO, int NI, typename S>
+__device__ __forceinline__ void npd_st_store_narrow_cols(const S &s, const npd_stage_t &st, int col0) {
+  constexpr int NC = NF - NO, NNC = (NO + NI + NPD_NPC - 1) / NPD_NPC;
+#pragma unroll
+  for (int c = 0; c < NNC; c++)
+    npd_st_store_narrow(st, col0 + NC + c, npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1));
+}
+#define NPD_ST_STORE_NARROW(T, stype, s, inst) \
+  npd_st_store_narrow_cols<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype>(s, st, NPD_SEC_COL(T, inst))
 /* ---- unchanged-column elision.  Measured on the bench workload (and on a reactor-heat-source batch): about a
  * quarter of the carried columns keep their exact bits over a step for every plant of a wave -- flags, status
  * codes, protection timers at rest, pump pressures and cavitation state in normal operation, the spare pump,
@@ -129,31 +172,35 @@ __device__ __forceinline__ long long npd_real_bits(double v) {
   return __double_as_longlong(v);
 #endif
 }
-template <int NF, int NI, typename S>
-__device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, const npd_stage_t &st, int fbase, int ibase,
-                                                   uint64_t fmask, uint32_t imask) {
+template <int NF, int NO, int NI, typename S>
+__device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, const npd_stage_t &st, int col0, uint64_t fmask) {
   const double *d = reinterpret_cast<const double *>(&s), *od = reinterpret_cast<const double *>(&old);
+  constexpr int NC = NF - NO, NNC = (NO + NI + NPD_NPC - 1) / NPD_NPC;
+#ifdef NPB_PROBE
+  fmask = 0; /* the liveness probe looks at the physics only, not at the elision's old copies */
+#endif
 #pragma unroll
-  for (int k = 0; k < NF; k++) {
+  for (int k = 0; k < NC; k++) {
     if ((fmask >> k) & 1) {
-      if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) *NPD_RP(fbase + k) = (npd_real_t)d[k];
+      if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) *NPD_RP(col0 + k) = (npd_real_t)d[k];
     } else {
-      *NPD_RP(fbase + k) = (npd_real_t)d[k];
+      *NPD_RP(col0 + k) = (npd_real_t)d[k];
     }
   }
-  const int32_t *q = reinterpret_cast<const int32_t *>(d + NF), *oq = reinterpret_cast<const int32_t *>(od + NF);
+  /* narrow columns (outputs as float, flags, status codes, counters): always compared */
 #pragma unroll
-  for (int k = 0; k < NI; k++) {
-    if ((imask >> k) & 1) {
-      if (__builtin_amdgcn_ballot_w64(q[k] != oq[k]) != 0) *NPD_I32P(int32_t, ibase + k, st.lane4) = q[k];
-    } else {
-      *NPD_I32P(int32_t, ibase + k, st.lane4) = q[k];
-    }
+  for (int c = 0; c < NNC; c++) {
+    const uint32_t w0 = npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), w1 = npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1);
+#ifdef NPB_PROBE
+    npd_st_store_narrow(st, col0 + NC + c, w0, w1);
+#else
+    const uint32_t o0 = npd_narrow_bits<NF, NO, NI>(old, c * NPD_NPC), o1 = npd_narrow_bits<NF, NO, NI>(old, c * NPD_NPC + 1);
+    if (__builtin_amdgcn_ballot_w64(NPD_NPC == 2 ? ((w0 != o0) | (w1 != o1)) : (w0 != o0)) != 0) npd_st_store_narrow(st, col0 + NC + c, w0, w1);
+#endif
   }
 }
 #define NPD_ST_STORE_ELIDE(T, stype, s, old, inst) \
-  npd_st_store_elide<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, old, st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
-                                                            NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32, NPD_ELIDE_##T##_F, ~0u)
+  npd_st_store_elide<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype>(s, old, st, NPD_SEC_COL(T, inst), NPD_ELIDE_##T##_F)
 #define NPD_FB(stype, m) (1ull << NPB_F64_SLOT(stype, m))
 #define NPD_FBN(stype, m, n) ((((1ull << (n)) - 1)) << NPB_F64_SLOT(stype, m))
 static constexpr uint64_t NPD_ELIDE_PRIM_F =
@@ -192,17 +239,13 @@ static constexpr uint64_t NPD_ELIDE_COND_F =
     NPD_FB(npb_cond_t, air_mass_in_condenser) | /* the idle ejector */ NPD_FBN(npb_cond_t, ej_nozzle_fouling, 2) |
     NPD_FBN(npb_cond_t, ej_diffuser_fouling, 2) | NPD_FBN(npb_cond_t, ej_nozzle_erosion, 2);
 
-/* single column, same rule */
+/* single carried column, same rule (output / int32 members are stored as whole narrow columns, see the tail) */
 #define NPD_ST_F64_ELIDE(T, stype, member, inst, k, newv, oldv) do { \
     const double nv__ = (newv); \
     if (__builtin_amdgcn_ballot_w64(npd_real_bits(nv__) != npd_real_bits(oldv)) != 0) NPD_ST_F64(T, stype, member, inst, k) = (npd_real_t)nv__; } while (0)
-#define NPD_ST_I32_ELIDE(T, stype, member, inst, newv, oldv) do { \
-    const int32_t nv__ = (newv); \
-    if (__builtin_amdgcn_ballot_w64(nv__ != (oldv)) != 0) NPD_ST_I32(T, stype, member, inst) = nv__; } while (0)
 #define NPD_ST_F64(T, stype, member, inst, k) \
-  (*NPD_RP(NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64 + NPB_F64_SLOT(stype, member) + (k)))
-#define NPD_ST_I32(T, stype, member, inst) \
-  (*NPD_I32P(int32_t, NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32 + NPB_I32_SLOT(stype, T, member), st.lane4))
+  (*NPD_RP(NPD_SEC_COL(T, inst) + npd_carried_slot<NPB_##T##_NCARRY>(NPB_F64_SLOT(stype, member) + (k))))
+template <int NC> __device__ __forceinline__ constexpr int npd_carried_slot(int idx) { return idx; }
 
 /* wave-cooperative store of a [64][W] block held one row per lane into row-major global memory */
 template <int W>
@@ -240,7 +283,7 @@ __device__ __forceinline__ void npd_obs_primary(const npb_prim_t &s, double *obs
 }
 
 __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
-    npb_params_t P, int n_plants, size_t N, npd_real_t *__restrict__ f64, int32_t *__restrict__ i32,
+    npb_params_t P, int n_plants, size_t N, npd_real_t *__restrict__ f64,
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
     const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,
     double *__restrict__ reward_out, uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out,
@@ -254,7 +297,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   const double dt = P.dt;
   const bool full = P.mode == NPB_MODE_FULL;
   npd_stage_t st;
-  npd_stage_init(st, lds, f64, i32, N, block_base);
+  npd_stage_init(st, lds, f64, N, block_base);
 
   /* per-step inputs first (plain loads), then the first staged group: primary + secondary-level scalars */
   npd_inputs_t in;
@@ -353,6 +396,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     npb_pump_t pm;
     /* boundary: fw + pump 0 are staged; store the primary section, stage pump 1 */
     NPD_DMA_WAIT();
+    s.has_heat_removal_factor = 1; /* consumed by phase 0; the feedback below always leaves a factor behind (sim.py:495) */
     NPD_ST_STORE_ELIDE(PRIM, npb_prim_t, s, s_old, 0);
     NPD_CONSUME(FW, npb_fw_t, fw, NPD_LS_FW);
     NPD_CONSUME(PUMP, npb_pump_t, pm, NPD_LS_PUMP0);
@@ -401,6 +445,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   } else {
     /* config-2 mode: no feedwater system; boundary straight to SG 0 */
     NPD_DMA_WAIT();
+    s.has_heat_removal_factor = 1; /* consumed by phase 0; the feedback below always leaves a factor behind (sim.py:495) */
     NPD_ST_STORE_ELIDE(PRIM, npb_prim_t, s, s_old, 0);
     NPD_CONSUME(SG, npb_sg_t, g, 0);
     g_old = g;
@@ -527,26 +572,22 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
 
   /* ================= secondary-level state write-back ================= */
   NPD_ST_F64_ELIDE(SEC, npb_sec_t, previous_feedwater_temp, 0, 0, actual_feedwater_temp, prev_feedwater_temp);
-  NPD_ST_F64_ELIDE(SEC, npb_sec_t, electrical_power_output, 0, 0, electrical_power, elec_old);
-  NPD_ST_F64_ELIDE(SEC, npb_sec_t, thermal_efficiency, 0, 0, thermal_efficiency, eff_old);
-  NPD_ST_F64(SEC, npb_sec_t, total_steam_flow, 0, 0) = sg_total_steam;
-  NPD_ST_F64(SEC, npb_sec_t, total_heat_transfer, 0, 0) = sg_total_thermal;
-  NPD_ST_F64(SEC, npb_sec_t, total_feedwater_flow, 0, 0) = fw_total_flow;
-  NPD_ST_F64(SEC, npb_sec_t, load_demand, 0, 0) = load_demand;
   NPD_ST_F64_ELIDE(SEC, npb_sec_t, cooling_water_temperature, 0, 0, cooling_water_temperature, cw_old);
   NPD_ST_F64(SEC, npb_sec_t, operating_hours, 0, 0) = operating_hours + dt / 3600.0;
-  NPD_ST_F64(SEC, npb_sec_t, sg_avg_pressure, 0, 0) = sg_avg_pressure;
-  NPD_ST_F64(SEC, npb_sec_t, sg_avg_temperature, 0, 0) = sg_avg_temperature;
-  NPD_ST_F64(SEC, npb_sec_t, sg_avg_quality, 0, 0) = sg_avg_quality;
-  NPD_ST_I32_ELIDE(SEC, npb_sec_t, has_previous_sg_conditions, 0, 1, has_prev);
-  NPD_ST_I32_ELIDE(SEC, npb_sec_t, sg_system_availability, 0, sg_system_availability, sgavail_old);
+  { /* the section's outputs and flags: narrow members, stored as whole columns */
+    npb_sec_t so;
+    so.electrical_power_output = electrical_power; so.thermal_efficiency = thermal_efficiency;
+    so.total_steam_flow = sg_total_steam; so.total_heat_transfer = sg_total_thermal; so.total_feedwater_flow = fw_total_flow;
+    so.load_demand = load_demand; so.sg_avg_pressure = sg_avg_pressure; so.sg_avg_temperature = sg_avg_temperature;
+    so.sg_avg_quality = sg_avg_quality; so.has_previous_sg_conditions = 1; so.sg_system_availability = sg_system_availability;
+    NPD_ST_STORE_NARROW(SEC, npb_sec_t, so, 0);
+  }
 
   /* ================= _apply_secondary_to_primary_feedback  sim.py:429-498 ================= */
   double heat_removal_factor = sg_total_steam / 1665.0;
   if (!fw_available) heat_removal_factor *= 0.5;
   NPD_ST_F64(PRIM, npb_prim_t, steam_flow_rate, 0, 0) = sg_total_steam;
   NPD_ST_F64(PRIM, npb_prim_t, last_heat_removal_factor, 0, 0) = heat_removal_factor;
-  NPD_ST_I32_ELIDE(PRIM, npb_prim_t, has_heat_removal_factor, 0, 1, s_old.has_heat_removal_factor);
 
   /* ================= observation / reward / done / flags / info ================= */
   obs[7] = sg_total_steam / 3000;
@@ -600,10 +641,9 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
 
 /* get_observation() without stepping (after reset / set_field): sim.py:290-333 */
 __global__ __launch_bounds__(NPB_WAVE) void npb_observe_kernel(int mode, int n_plants, size_t N, const npd_real_t *__restrict__ f64c,
-                                                               const int32_t *__restrict__ i32c, double *__restrict__ obs_out) {
+                                                               double *__restrict__ obs_out) {
   __shared__ double lds[NPB_WAVE * NPB_OBS_PAD];
   npd_real_t *f64 = const_cast<npd_real_t *>(f64c);
-  int32_t *i32 = const_cast<int32_t *>(i32c);
   const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
   const size_t p = block_base + threadIdx.x;
   double obs[NPB_OBS_DIM];
@@ -633,7 +673,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_observe_kernel(int mode, int n_p
 /* construction-time state for every plant selected by mask (NULL = all): the state the reference's
  * constructors leave behind with the default SecondarySystemConfig (npd_init.h) */
 __global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size_t N, npd_real_t *__restrict__ f64,
-                                                            int32_t *__restrict__ i32, const uint8_t *__restrict__ mask,
+                                                            const uint8_t *__restrict__ mask,
                                                             int n_plants) {
   const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
   if (mask && p < (size_t)n_plants && !mask[p]) return;
@@ -658,8 +698,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size
  * state manager's threshold scan (npd_maintenance.h).  HBM-bound and small: per plant it reads
  * sim_time, the maint section and four oil levels (184 B); it writes only what changed -- the
  * maint section when a check ran or a violation was recorded, one pump record when a top-off ran. */
-__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, size_t N, npd_real_t *__restrict__ f64,
-                                                             int32_t *__restrict__ i32) {
+__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, size_t N, npd_real_t *__restrict__ f64) {
   const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
   const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
   npb_maint_t m;
@@ -682,35 +721,17 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, siz
 }
 
 #ifndef NPB_BUILD_F32
-/* calibration aid for the HBM traffic counters: reads every state column and writes it back unchanged,
+/* calibration aid for the HBM traffic counters: reads every arena column and writes it back unchanged,
  * with exactly the access shape of the step kernel (8 B per lane, one 512-B line per wave and column),
  * so that FETCH_SIZE / WRITE_SIZE can be scaled against a known byte count (2 * state_bytes * pitch) */
-__global__ __launch_bounds__(NPB_WAVE) void npb_touch_kernel(size_t N, double *__restrict__ f64, int32_t *__restrict__ i32) {
+__global__ __launch_bounds__(NPB_WAVE) void npb_touch_kernel(size_t N, double *__restrict__ f64) {
   const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
 #pragma unroll 8
-  for (int k = 0; k < NPB_TOTAL_F64; k++) { double v = f64[(size_t)k * N + p]; f64[(size_t)k * N + p] = v + 0.0; }
-#pragma unroll 8
-  for (int k = 0; k < NPB_TOTAL_I32; k++) { int32_t v = i32[(size_t)k * N + p]; i32[(size_t)k * N + p] = v; }
+  for (int k = 0; k < NPB_TOTAL_COL64; k++) { double v = f64[(size_t)k * N + p]; f64[(size_t)k * N + p] = v + 0.0; }
 }
-extern "C" void npb_launch_touch(size_t npad, double *f64, int32_t *i32, hipStream_t stream) {
+extern "C" void npb_launch_touch(size_t npad, double *f64, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_touch_kernel, grid, block, 0, stream, npad, f64, i32);
-}
-#else
-/* fp32 storage: the C ABI's field access speaks fp64, so one column is converted on the way in and out */
-__global__ void npb_col_to_f64_kernel(const float *__restrict__ col, double *__restrict__ out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (double)col[i];
-}
-__global__ void npb_col_from_f64_kernel(float *__restrict__ col, const double *__restrict__ in, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) col[i] = (float)in[i];
-}
-extern "C" void npb32_launch_col_to_f64(const float *col, double *out, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(npb_col_to_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, col, out, n);
-}
-extern "C" void npb32_launch_col_from_f64(float *col, const double *in, int n, hipStream_t stream) {
-  hipLaunchKernelGGL(npb_col_from_f64_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, col, in, n);
+  hipLaunchKernelGGL(npb_touch_kernel, grid, block, 0, stream, npad, f64);
 }
 #endif
 
@@ -720,25 +741,49 @@ extern "C" void npb32_launch_col_from_f64(float *col, const double *in, int n, h
 #else
 #define NPB_LAUNCHER(name) npb_launch_##name
 #endif
-extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad, void *f64, int32_t *i32,
+
+/* field access of the C ABI: one member of every plant <-> a contiguous buffer of double (real members) or
+ * int32 (int members).  where = arena column, sub = narrow position inside the column, kind: 0 carried real,
+ * 1 output real (stored as float), 2 int32 */
+__global__ void npb_field_get_kernel(const npd_real_t *__restrict__ arena, size_t N, int col, int sub, int kind, void *__restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const char *e = (const char *)(arena + (size_t)col * N + i);
+  if (kind == 0) ((double *)out)[i] = (double)*(const npd_real_t *)e;
+  else if (kind == 1) ((double *)out)[i] = (double)*(const float *)(e + sub * 4);
+  else ((int32_t *)out)[i] = *(const int32_t *)(e + sub * 4);
+}
+__global__ void npb_field_set_kernel(npd_real_t *__restrict__ arena, size_t N, int col, int sub, int kind, const void *__restrict__ in, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  char *e = (char *)(arena + (size_t)col * N + i);
+  if (kind == 0) *(npd_real_t *)e = (npd_real_t)((const double *)in)[i];
+  else if (kind == 1) *(float *)(e + sub * 4) = (float)((const double *)in)[i];
+  else *(int32_t *)(e + sub * 4) = ((const int32_t *)in)[i];
+}
+extern "C" void NPB_LAUNCHER(field_get)(const void *arena, size_t npad, int col, int sub, int kind, void *out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(npb_field_get_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const npd_real_t *)arena, npad, col, sub, kind, out, n);
+}
+extern "C" void NPB_LAUNCHER(field_set)(void *arena, size_t npad, int col, int sub, int kind, const void *in, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(npb_field_set_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (npd_real_t *)arena, npad, col, sub, kind, in, n);
+}
+extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad, void *arena,
                                 const int32_t *action, const double *magnitude, const double *setpoint,
                                 const double *noise_z, const double *cw_temp, double *obs, double *reward, uint8_t *done,
                                 uint32_t *trip_flags, double *info, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)f64, i32, action, magnitude, setpoint,
+  hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                      noise_z, cw_temp, obs, reward, done, trip_flags, info);
 }
-extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, size_t npad, void *f64, int32_t *i32, hipStream_t stream) {
+extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, size_t npad, void *arena, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_maint_kernel, grid, block, 0, stream, *P, npad, (npd_real_t *)f64, i32);
+  hipLaunchKernelGGL(npb_maint_kernel, grid, block, 0, stream, *P, npad, (npd_real_t *)arena);
 }
-extern "C" void NPB_LAUNCHER(observe)(int mode, int n_plants, size_t npad, const void *f64, const int32_t *i32, double *obs,
-                                   hipStream_t stream) {
+extern "C" void NPB_LAUNCHER(observe)(int mode, int n_plants, size_t npad, const void *arena, double *obs, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_observe_kernel, grid, block, 0, stream, mode, n_plants, npad, (const npd_real_t *)f64, i32, obs);
+  hipLaunchKernelGGL(npb_observe_kernel, grid, block, 0, stream, mode, n_plants, npad, (const npd_real_t *)arena, obs);
 }
-extern "C" void NPB_LAUNCHER(init)(const npb_params_t *P, int n_plants, size_t npad, void *f64, int32_t *i32,
-                                const uint8_t *mask, hipStream_t stream) {
+extern "C" void NPB_LAUNCHER(init)(const npb_params_t *P, int n_plants, size_t npad, void *arena, const uint8_t *mask, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_init_kernel, grid, block, 0, stream, *P, npad, (npd_real_t *)f64, i32, mask, n_plants);
+  hipLaunchKernelGGL(npb_init_kernel, grid, block, 0, stream, *P, npad, (npd_real_t *)arena, mask, n_plants);
 }

@@ -17,7 +17,11 @@
  *     issue DMA(j+2)             into the same LDS region, lands while phase j+1 computes
  *
  * One staging region of 36 KB per wave (4 waves per CU = 144 KB of the CU's 160 KB), addressed in column slots
- * of 64 lanes x sizeof(stored real); an int32 column takes 256 B.
+ * of 64 lanes x the arena's column width.
+ *
+ * Arena columns (include/npb_fields.h): a section instance is NCARRY carried reals, one per column, followed by its
+ * "narrow" 4-byte members -- the step's output reals as float, then the int32 members -- packed NPD_NPC to a column
+ * (two per 8-byte column; one per column under fp32 storage, where every column is 4 bytes wide).
  *
  * hipcc (ROCm 7.2) does not insert the vmcnt wait between an LDS-DMA and a later ds_read of the same
  * bytes, so the waits here are explicit and carry a "memory" clobber so nothing moves across them.
@@ -42,6 +46,16 @@ typedef double npd_real_t;
 #define NPB_STAGE_BYTES 36864                       /* staging region per wave; 4 waves per CU = 144 KB of 160 */
 #define NPB_STAGE_SLOTS (NPB_STAGE_BYTES / NPD_SLOTB)
 
+#define NPD_NPC (NPD_RB / 4)                        /* narrow (4-byte) members per arena column */
+#ifdef NPB_BUILD_F32
+#define NPD_COL_BASE(T) NPB_##T##_COL32_BASE
+#define NPD_NCOL(T) NPB_##T##_NCOL32
+#else
+#define NPD_COL_BASE(T) NPB_##T##_COL64_BASE
+#define NPD_NCOL(T) NPB_##T##_NCOL64
+#endif
+#define NPD_SEC_COL(T, inst) (NPD_COL_BASE(T) + (inst) * NPD_NCOL(T))   /* first arena column of a section instance */
+
 typedef __attribute__((address_space(1))) const void npd_gptr_t;
 typedef __attribute__((address_space(3))) void npd_lptr_t;
 
@@ -50,24 +64,23 @@ typedef __attribute__((address_space(3))) void npd_lptr_t;
  * One s_mul + one v_add per access instead of 64-bit per-lane arithmetic and an address register pair per
  * column.  The offsets are computed by a volatile asm where they are used: as plain C the optimiser hoists
  * these one-instruction values out of the phases and keeps hundreds of them live.  32-bit offsets bound an
- * arena at 4 GiB per kind; npb_create enforces it (about one million plants per handle). */
+ * arena at 4 GiB; npb_create enforces it (about one million plants per handle). */
 typedef __attribute__((address_space(1))) char npd_gchar_t;
 typedef struct npd_stage_t {
   char *lds;              /* staging region base (wave-uniform) */
-  npd_gchar_t *f64b;      /* SoA arenas, offset to this wave's first plant (wave-uniform) */
-  npd_gchar_t *i32b;
-  uint32_t nr, n4;        /* column pitch in bytes: real and int32 arena */
-  uint32_t laner, lane4;  /* lane * sizeof(real), lane * 4: this lane's plant within a column */
-  uint32_t grp16;         /* grouped LDS-DMA: 64 / NPD_GROUP consecutive lanes carry one column, 16 B
-                           * (2 fp64 or 4 fp32 plants) each:  (lane / lanes_per_col) * nr + (lane % lanes_per_col) * 16 */
+  npd_gchar_t *f64b;      /* the arena, offset to this wave's first plant (wave-uniform) */
+  uint32_t nr;            /* column pitch in bytes */
+  uint32_t laner;         /* lane * column width: this lane's plant within a column */
+  uint32_t grp16;         /* grouped LDS-DMA: 64 / NPD_GROUP consecutive lanes carry one column, 16 B each:
+                           * (lane / lanes_per_col) * nr + (lane % lanes_per_col) * 16 */
 } npd_stage_t;
 
-__device__ __forceinline__ void npd_stage_init(npd_stage_t &st, void *lds, npd_real_t *f64, int32_t *i32, size_t N, size_t block_base) {
+__device__ __forceinline__ void npd_stage_init(npd_stage_t &st, void *lds, npd_real_t *arena, size_t N, size_t block_base) {
   const uint32_t lane = threadIdx.x, lpc = NPB_WAVE / NPD_GROUP;
   st.lds = (char *)lds;
-  st.f64b = (npd_gchar_t *)(f64 + block_base); st.i32b = (npd_gchar_t *)(i32 + block_base);
-  st.nr = (uint32_t)(N * NPD_RB); st.n4 = (uint32_t)(N * 4);
-  st.laner = lane * NPD_RB; st.lane4 = lane * 4u;
+  st.f64b = (npd_gchar_t *)(arena + block_base);
+  st.nr = (uint32_t)(N * NPD_RB);
+  st.laner = lane * NPD_RB;
   st.grp16 = (lane / lpc) * st.nr + (lane % lpc) * 16u;
 }
 __device__ __forceinline__ uint32_t npd_voff(uint32_t col, uint32_t pitch, uint32_t lane_off) {
@@ -75,10 +88,11 @@ __device__ __forceinline__ uint32_t npd_voff(uint32_t col, uint32_t pitch, uint3
   asm volatile("s_mul_i32 %1, %2, %3\n\tv_add_u32 %0, %1, %4" : "=v"(v), "=&s"(t) : "s"(col), "s"(pitch), "v"(lane_off));
   return v;
 }
-/* this lane's element of real column `col` / int32 column `col`; NPD_RPO: column base + explicit lane offset */
+/* this lane's element of arena column `col`; NPD_RPO: column base + explicit byte offset; NPD_NP: the narrow
+ * member `sub` (0 .. NPD_NPC-1) of this lane's element */
 #define NPD_RPO(type, col, off) ((__attribute__((address_space(1))) type *)(st.f64b + npd_voff((uint32_t)(col), st.nr, (off))))
 #define NPD_RP(col) NPD_RPO(npd_real_t, col, st.laner)
-#define NPD_I32P(type, col, off) ((__attribute__((address_space(1))) type *)(st.i32b + npd_voff((uint32_t)(col), st.n4, (off))))
+#define NPD_NP(type, col, sub) NPD_RPO(type, col, st.laner + (uint32_t)(sub) * 4u)
 
 #ifdef NPB_STAMPS
 /* diagnostic build: ticks this wave spent inside the staging pipeline's waits (lane 0 keeps the sum in LDS) */
@@ -92,55 +106,72 @@ __shared__ unsigned long long npd_wait_acc_s;
 #endif
 #define NPD_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-/* real-column slots a section occupies in the staging region (an int32 column is 256 B) */
-#define NPD_SLOTS(T) (NPB_##T##_NF64 + (NPB_##T##_NI32 * 256 + NPD_SLOTB - 1) / NPD_SLOTB)
+/* staging slots a section occupies = its arena columns */
+#define NPD_SLOTS(T) NPD_NCOL(T)
 
-/* issue the LDS-DMA of NF real columns starting at arena column fslot and NI int32 columns starting at
- * islot into staging slot ls: real column c -> slot ls + c; int32 column k -> the k-th 256 B after the real
- * slots.  One dwordx4 instruction moves NPD_GROUP columns: the LDS image (base + lane * 16) is those columns
- * back to back.  Left-over columns go as 256-B dword pieces. */
-template <int NF, int NI>
-__device__ __forceinline__ void npd_dma(const npd_stage_t &st, int fslot, int islot, int ls) {
+/* issue the LDS-DMA of NCOL arena columns starting at column col0 into staging slots ls ...: one dwordx4 instruction
+ * moves NPD_GROUP columns (the LDS image, base + lane * 16, is those columns back to back); left-over columns go as
+ * 256-B dword pieces. */
+template <int NCOL>
+__device__ __forceinline__ void npd_dma(const npd_stage_t &st, int col0, int ls) {
   char *l = st.lds + ls * NPD_SLOTB;
 #pragma unroll
-  for (int c = 0; c + NPD_GROUP <= NF; c += NPD_GROUP)
-    __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_RPO(char, fslot + c, st.grp16), (npd_lptr_t *)(l + c * NPD_SLOTB), 16, 0, 0);
+  for (int c = 0; c + NPD_GROUP <= NCOL; c += NPD_GROUP)
+    __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_RPO(char, col0 + c, st.grp16), (npd_lptr_t *)(l + c * NPD_SLOTB), 16, 0, 0);
 #pragma unroll
-  for (int c = NF / NPD_GROUP * NPD_GROUP; c < NF; c++)
+  for (int c = NCOL / NPD_GROUP * NPD_GROUP; c < NCOL; c++)
 #pragma unroll
     for (int piece = 0; piece < NPD_RB / 4; piece++)
-      __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_RPO(char, fslot + c, st.lane4 + piece * 256),
+      __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_RPO(char, col0 + c, threadIdx.x * 4u + piece * 256),
                                        (npd_lptr_t *)(l + c * NPD_SLOTB + piece * 256), 4, 0, 0);
-  if (NI > 0) {
-    char *li = l + NF * NPD_SLOTB;
-#pragma unroll
-    for (int k = 0; k < NI; k++)
-      __builtin_amdgcn_global_load_lds((npd_gptr_t *)NPD_I32P(int32_t, islot + k, st.lane4), (npd_lptr_t *)(li + k * 256), 4, 0, 0);
-  }
 }
-#define NPD_DMA(T, inst, ls) \
-  npd_dma<NPB_##T##_NF64, NPB_##T##_NI32>(st, NPB_##T##_F64_BASE + (inst) * NPB_##T##_NF64, \
-                                          NPB_##T##_I32_BASE + (inst) * NPB_##T##_NI32, ls)
+#define NPD_DMA(T, inst, ls) npd_dma<NPD_NCOL(T)>(st, NPD_SEC_COL(T, inst), ls)
 
-/* staged real k of the image at slot ls / staged int k behind NF real slots, for this lane */
+/* staged carried real k / narrow member j (raw 32 bits) of the section image at slot ls, for this lane */
 #define NPD_LDS_REAL(ls, k) ((double)((const npd_real_t *)(st.lds + (ls) * NPD_SLOTB))[(k) * NPB_WAVE + threadIdx.x])
-#define NPD_LDS_INT(ls, nf, k) (((const int32_t *)(st.lds + ((ls) + (nf)) * NPD_SLOTB))[(k) * NPB_WAVE + threadIdx.x])
+#define NPD_LDS_NARROW(ls, nc, j) \
+  (*(const uint32_t *)(st.lds + ((ls) + (nc) + (j) / NPD_NPC) * NPD_SLOTB + threadIdx.x * NPD_RB + ((j) % NPD_NPC) * 4))
 
-/* staging slot ls -> register struct (all fp64 members first, then the int32 members) */
-template <int NF, int NI, typename S>
+#ifdef NPB_PROBE
+/* liveness probe (diagnostic build, tools/probe_liveness.py): every loaded member passes through a NON-volatile
+ * asm that carries a marker; the compiler deletes the asm when nothing uses its result, so the markers left in the
+ * ISA are exactly the members the step reads.  Marker: PROBE <first fp64 slot of the section type> <member index> */
+template <int SID, int K> __device__ __forceinline__ double npd_probe_f(double v) { double r; asm("v_mov_b64 %0, %1 ; PROBE_F %2 %3" : "=v"(r) : "v"(v), "n"(SID), "n"(K)); return r; }
+template <int SID, int K> __device__ __forceinline__ int32_t npd_probe_i(int32_t v) { int32_t r; asm("v_mov_b32 %0, %1 ; PROBE_I %2 %3" : "=v"(r) : "v"(v), "n"(SID), "n"(K)); return r; }
+template <int SID, int NF, int NI, int K> struct npd_probe_all {
+  static __device__ __forceinline__ void run(double *d, int32_t *q) {
+    if constexpr (K < NF) d[K] = npd_probe_f<SID, K>(d[K]);
+    else q[K - NF] = npd_probe_i<SID, K - NF>(q[K - NF]);
+    if constexpr (K + 1 < NF + NI) npd_probe_all<SID, NF, NI, K + 1>::run(d, q);
+  }
+};
+#define NPD_PROBE_STRUCT(SID, NF, NI, d, q) npd_probe_all<SID, NF, NI, 0>::run(d, q)
+#else
+#define NPD_PROBE_STRUCT(SID, NF, NI, d, q)
+#endif
+
+/* staging slot ls -> register struct (NF fp64 members, the last NO of them outputs kept as float; then NI int32) */
+template <int NF, int NO, int NI, int SID, typename S>
 __device__ __forceinline__ void npd_consume(S &s, const npd_stage_t &st, int ls) {
   double *d = reinterpret_cast<double *>(&s);
+  constexpr int NC = NF - NO;
 #pragma unroll
-  for (int k = 0; k < NF; k++) d[k] = NPD_LDS_REAL(ls, k);
+  for (int k = 0; k < NC; k++) d[k] = NPD_LDS_REAL(ls, k);
+#pragma unroll
+  for (int j = 0; j < NO; j++) d[NC + j] = (double)__uint_as_float(NPD_LDS_NARROW(ls, NC, j));
   int32_t *q = reinterpret_cast<int32_t *>(d + NF);
 #pragma unroll
-  for (int k = 0; k < NI; k++) q[k] = NPD_LDS_INT(ls, NF, k);
+  for (int k = 0; k < NI; k++) q[k] = (int32_t)NPD_LDS_NARROW(ls, NC, NO + k);
+  NPD_PROBE_STRUCT(SID, NF, NI, d, q);
 }
-#define NPD_CONSUME(T, stype, s, ls) npd_consume<NPB_##T##_NF64, NPB_##T##_NI32, stype>(s, st, ls)
+#define NPD_CONSUME(T, stype, s, ls) npd_consume<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, NPB_##T##_F64_BASE, stype>(s, st, ls)
 
-/* single staged members */
-#define NPD_STAGED_F64(T, stype, member, k, ls) NPD_LDS_REAL(ls, NPB_F64_SLOT(stype, member) + (k))
-#define NPD_STAGED_I32(T, stype, member, ls) NPD_LDS_INT(ls, NPB_##T##_NF64, NPB_I32_SLOT(stype, T, member))
+/* single staged members: fp64 member at struct index idx (carried or output), int32 member islot */
+template <int NC> __device__ __forceinline__ double npd_staged_real(const npd_stage_t &st, int ls, int idx) {
+  return idx < NC ? NPD_LDS_REAL(ls, idx) : (double)__uint_as_float(NPD_LDS_NARROW(ls, NC, idx - NC));
+}
+#define NPD_STAGED_F64(T, stype, member, k, ls) npd_staged_real<NPB_##T##_NCARRY>(st, ls, NPB_F64_SLOT(stype, member) + (k))
+#define NPD_STAGED_I32(T, stype, member, ls) ((int32_t)NPD_LDS_NARROW(ls, NPB_##T##_NCARRY, NPB_##T##_NOUT + NPB_I32_SLOT(stype, T, member)))
 
 /* fixed slot plan (see the kernel): groups that are staged together */
 #define NPD_LS_PRIM 0

@@ -173,7 +173,7 @@ typedef struct npd_stagesys_out_t {
  * updated value is written straight to its SoA column; every column is read before it is written and
  * never re-read within a step, so the staged copy does not need the update */
 #define NPD_TSTG_RD(member, k) NPD_LDS_REAL(0, NPB_F64_SLOT(npb_tstg_t, member) + (k))
-#define NPD_TSTG_WR(member, k, v) *NPD_RP(NPB_TSTG_F64_BASE + NPB_F64_SLOT(npb_tstg_t, member) + (k)) = (npd_real_t)(v)
+#define NPD_TSTG_WR(member, k, v) *NPD_RP(NPD_SEC_COL(TSTG, 0) + NPB_F64_SLOT(npb_tstg_t, member) + (k)) = (npd_real_t)(v)
 
 /* one stage's share of TurbineStage.update_degradation (stage_system.py:294-339) and of
  * MetalTemperatureTracker.update_temperatures (enhanced_physics.py:73-166, time constant 1 h, ambient 25 C);

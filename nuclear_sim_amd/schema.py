@@ -38,6 +38,16 @@ class Section:
     ni32: int = 0
     f64_base: int = 0
     i32_base: int = 0
+    nout: int = 0      # the last `nout` fp64 members are outputs of the step, stored as float (npb_fields.h)
+
+    @property
+    def ncarry(self) -> int:
+        return self.nf64 - self.nout
+
+    def ncol(self, storage: str = "f64") -> int:
+        """arena columns of one instance: 8-byte columns (two narrow members each) or 4-byte columns (fp32 storage)"""
+        narrow = self.nout + self.ni32
+        return self.ncarry + ((narrow + 1) // 2 if storage == "f64" else narrow)
 
 
 class Schema:
@@ -48,6 +58,7 @@ class Schema:
         text = header_text.replace("\\\n", " ")
         blocks = {m.group(1): m.group(2)
                   for m in re.finditer(r"#define\s+NPB_(\w+)_FIELDS\(F, A, I\)(.*)", text)}
+        nouts = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+NPB_(\w+)_NOUT\s+(\d+)", header_text)}
         sec_line = re.search(r"#define\s+NPB_SECTIONS\(S\)(.*)", text).group(1)
         self.sections: List[Section] = []
         for m in re.finditer(r"S\(\s*(\w+)\s*,\s*(\w+)\s*,\s*(\w+)\s*,\s*(\w+)\s*\)", sec_line):
@@ -70,6 +81,7 @@ class Schema:
             for name, c, path in i32s:
                 sec.fields.append(Field(member, name, "i32", c, path, off)); off += c
             sec.ni32 = off
+            sec.nout = nouts.get(tag, 0)
             self.sections.append(sec)
         fb = ib = 0
         for sec in self.sections:
@@ -106,9 +118,15 @@ class Schema:
                         out.append((kind, slot, label, path))
         return out
 
-    def state_bytes(self) -> int:
-        """Carried bytes per plant (fp64 slots * 8 + int32 slots * 4)."""
-        return self.total_f64 * 8 + self.total_i32 * 4
+    def state_bytes(self, storage: str = "f64") -> int:
+        """Arena bytes per plant: columns of every section instance * column width."""
+        width = 8 if storage == "f64" else 4
+        return sum(sec.count * sec.ncol(storage) for sec in self.sections) * width
+
+    def is_output(self, name: str) -> bool:
+        """True for an fp64 member that the step only writes (stored as float)."""
+        sec, f = self.by_name[name]
+        return f.kind == "f64" and f.offset >= sec.ncarry
 
 
 def _load() -> Schema:

@@ -376,7 +376,7 @@ def test_full_size_properties():
     assert np.array_equal(o1[perm], o2)
     assert np.array_equal(r1.cpu().numpy()[perm], r2.cpu().numpy())
     sf = env.get_field("sec.total_steam_flow").cpu().numpy()
-    np.testing.assert_allclose(o1[:, 14], sf / 1665, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(o1[:, 14], sf / 1665, rtol=2e-7, atol=0)   # an output member: kept as float in the arena
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ def burst(env, K=300):
 import ctypes
 for rnd in range(2):
     for i, env in enumerate(envs):
-        real = ctypes.c_void_p(); i32 = ctypes.c_void_p(); pitch = ctypes.c_size_t(); stor = ctypes.c_int()
-        env.L.npb_state_arena_raw(env._h, ctypes.byref(real), ctypes.byref(i32), ctypes.byref(pitch), ctypes.byref(stor))
+        real = ctypes.c_void_p(); pitch = ctypes.c_size_t(); stor = ctypes.c_int()
+        env.L.npb_state_arena(env._h, ctypes.byref(real), ctypes.byref(pitch), ctypes.byref(stor))
         mn, md = burst(env)
         print("round %d handle %d arena at 0x%012x: min %.5f median %.5f ms" % (rnd, i, real.value, mn, md), flush=True)

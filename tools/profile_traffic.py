@@ -69,9 +69,8 @@ def summarize(out):
                         "calibration_scale": scale, "step_bytes_calibrated": step * raw_unit_bytes * scale}
         total += step * raw_unit_bytes * scale
     res["step_hbm_bytes_per_launch"] = total
-    maint = next(sec for sec in SCHEMA.sections if sec.member == "maint")
-    step_state = state - (maint.nf64 * 8 + maint.ni32 * 4)   # the step kernel never touches maint.* columns
-    res["algorithmic_bytes_per_launch"] = (2 * step_state + 36 + 269) * N
+    from nuclear_sim_amd.env import BatchedPlantEnv
+    res["algorithmic_bytes_per_launch"] = BatchedPlantEnv.step_bytes_per_plant() * N   # include/npb.h
     print(json.dumps(res, indent=1))
 
 
