@@ -247,7 +247,8 @@ static constexpr uint64_t NPD_ELIDE_COND_F =
   (*NPD_RP(NPD_SEC_COL(T, inst) + npd_carried_slot<NPB_##T##_NCARRY>(NPB_F64_SLOT(stype, member) + (k))))
 template <int NC> __device__ __forceinline__ constexpr int npd_carried_slot(int idx) { return idx; }
 
-/* wave-cooperative store of a [64][W] block held one row per lane into row-major global memory */
+/* wave-cooperative store of a [64][W] block held one row per lane into row-major global memory (non-temporal: see
+ * the reward / done / flags stores) */
 template <int W>
 __device__ __forceinline__ void npd_store_rows(const double *row, double *__restrict__ out, double *lds,
                                                size_t block_base, size_t n_valid) {
@@ -259,7 +260,7 @@ __device__ __forceinline__ void npd_store_rows(const double *row, double *__rest
   for (int k = 0; k < W; k++) {
     int idx = k * NPB_WAVE + lane;
     int r = idx / W, c = idx % W;
-    if (block_base + r < n_valid) out[block_base * W + idx] = lds[r * NPB_OBS_PAD + c];
+    if (block_base + r < n_valid) __builtin_nontemporal_store(lds[r * NPB_OBS_PAD + c], &out[block_base * W + idx]);
   }
   NPD_LDS_DRAIN();
 }
@@ -618,9 +619,12 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   if (nan_reset) trip_flags |= NPB_TRIP_NAN_RESET;
 
   if (live) {
-    if (reward_out) reward_out[p] = reward;
-    if (done_out) done_out[p] = (uint8_t)scram_fired;
-    if (trip_out) trip_out[p] = trip_flags;
+    /* per-step outputs are streamed with the non-temporal bit: nobody on the GPU reads them back before the next
+     * step, and without it their 17 MB per step push arena lines out of the Infinity Cache, which the arena of
+     * 65 536 plants only just fits (tools/membench/ntstore.hip) */
+    if (reward_out) __builtin_nontemporal_store(reward, &reward_out[p]);
+    if (done_out) __builtin_nontemporal_store((uint8_t)scram_fired, &done_out[p]);
+    if (trip_out) __builtin_nontemporal_store(trip_flags, &trip_out[p]);
   }
   NPD_STAMP(21);
   if (obs_out) npd_store_rows<NPB_OBS_DIM>(obs, obs_out, lds, block_base, (size_t)n_plants);
