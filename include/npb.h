@@ -97,6 +97,11 @@ NPB_API int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream);
  * npb_fields.h; buf holds n_plants elements (double or int32_t) on the device or the host. */
 NPB_API int npb_get_field(NpbHandle *h, int kind, int slot, void *buf, int buf_is_device, void *stream);
 NPB_API int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int buf_is_device, void *stream);
+/* Many fields in one launch, every value widened to double: out (device) = [n_fields][n_plants].  This is the sampling
+ * step of a columnar state log -- the batched counterpart of StateManager.collect_states (state_manager.py:152-213),
+ * which walks every provider's get_state_dict() and appends one pandas row per step.  kinds / slots are host arrays;
+ * the request is remembered, so repeating it costs one kernel launch. */
+NPB_API int npb_gather_fields(NpbHandle *h, int n_fields, const int *kinds, const int *slots, double *out, void *stream);
 /* raw arena (checkpointing, external kernels): one allocation of equally wide columns, column-major with `pitch`
  * plants per column; the members of the schema are mapped onto columns as include/npb_fields.h describes */
 NPB_API int npb_state_arena(NpbHandle *h, void **arena, size_t *pitch, int *storage);

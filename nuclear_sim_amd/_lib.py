@@ -69,6 +69,7 @@ def load():
     L.npb_get_field.argtypes = [vp, ci, ci, vp, ci, vp]
     L.npb_set_field.argtypes = [vp, ci, ci, vp, ci, vp]
     L.npb_state_arena.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ci)]
+    L.npb_gather_fields.argtypes = [vp, ci, vp, vp, vp, vp]
     L.npb_locate_field.argtypes = [vp, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.npb_step.argtypes = [vp] + [vp] * 11
     L.npb_observe.argtypes = [vp, vp, vp]

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <vector>
 #include "../../include/npb.h"
 #include "npb_kernels.h"
 
@@ -19,6 +20,8 @@ struct NpbHandle {
   size_t real_bytes;   /* 8 | 4 */
   void *f64;           /* the arena: [NPB_TOTAL_COL64][pitch] 8-byte columns, or [NPB_TOTAL_COL32][pitch] 4-byte ones */
   double *convert;     /* one staging column (pitch doubles) used by get/set_field with host buffers */
+  int *plan_dev;       /* npb_gather_fields: {column, sub, kind} per requested field, and the request it was built for */
+  std::vector<int> plan_key;
   std::string error;
 };
 
@@ -106,7 +109,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   h->n_plants = n_plants; h->device = device;
   h->pitch = ((size_t)n_plants + 63) / 64 * 64;
   h->storage = storage; h->real_bytes = real_bytes;
-  h->f64 = nullptr; h->convert = nullptr;
+  h->f64 = nullptr; h->convert = nullptr; h->plan_dev = nullptr;
   e = hipMalloc(&h->f64, arena_columns(storage) * h->pitch * real_bytes);
   if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double));
   if (e != hipSuccess) {
@@ -129,6 +132,7 @@ int npb_destroy(NpbHandle *h) {
   (void)hipSetDevice(h->device);
   (void)hipFree(h->f64);
   if (h->convert) (void)hipFree(h->convert);
+  if (h->plan_dev) (void)hipFree(h->plan_dev);
   delete h;
   return NPB_OK;
 }
@@ -186,6 +190,26 @@ int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int buf_is_
   (h->storage == NPB_STORAGE_F32 ? npb32_launch_field_set : npb_launch_field_set)(h->f64, h->pitch, col, sub, akind, src, h->n_plants, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
   if (!buf_is_device) NPB_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+  return NPB_OK;
+}
+
+int npb_gather_fields(NpbHandle *h, int n_fields, const int *kinds, const int *slots, double *out, void *stream) {
+  if (!h || !kinds || !slots || !out || n_fields <= 0 || n_fields > NPB_TOTAL_F64 + NPB_TOTAL_I32) return NPB_EINVAL;
+  NPB_HIP(h, hipSetDevice(h->device));
+  std::vector<int> key(2 * (size_t)n_fields);
+  for (int f = 0; f < n_fields; f++) { key[2 * f] = kinds[f]; key[2 * f + 1] = slots[f]; }
+  if (key != h->plan_key) { /* a log asks for the same members every time: build and upload the plan once */
+    std::vector<int> plan(3 * (size_t)n_fields);
+    for (int f = 0; f < n_fields; f++)
+      if ((kinds[f] != NPB_KIND_F64 && kinds[f] != NPB_KIND_I32) || !locate(h->storage, kinds[f], slots[f], &plan[3 * f], &plan[3 * f + 1], &plan[3 * f + 2]))
+        return fail(h, NPB_EINVAL, "npb_gather_fields: bad field kind or slot");
+    if (!h->plan_dev) NPB_HIP(h, hipMalloc((void **)&h->plan_dev, sizeof(int) * 3 * (NPB_TOTAL_F64 + NPB_TOTAL_I32)));
+    NPB_HIP(h, hipMemcpyAsync(h->plan_dev, plan.data(), sizeof(int) * plan.size(), hipMemcpyHostToDevice, (hipStream_t)stream));
+    NPB_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+    h->plan_key = key;
+  }
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_gather : npb_launch_gather)(h->f64, h->pitch, h->plan_dev, n_fields, out, h->n_plants, (hipStream_t)stream);
+  NPB_HIP(h, hipGetLastError());
   return NPB_OK;
 }
 

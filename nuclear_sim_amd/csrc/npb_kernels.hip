@@ -765,6 +765,22 @@ __global__ void npb_field_set_kernel(npd_real_t *__restrict__ arena, size_t N, i
   else if (kind == 1) *(float *)(e + sub * 4) = (float)((const double *)in)[i];
   else *(int32_t *)(e + sub * 4) = ((const int32_t *)in)[i];
 }
+/* many members at once, every value widened to double: out[f * n + plant]; plan[f] = {column, sub, kind} (the state
+ * log's sampling step, nuclear_sim_amd/statelog.py) */
+__global__ void npb_gather_kernel(const npd_real_t *__restrict__ arena, size_t N, const int *__restrict__ plan, double *__restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+  if (i >= n) return;
+  const int col = plan[3 * f], sub = plan[3 * f + 1], kind = plan[3 * f + 2];
+  const char *e = (const char *)(arena + (size_t)col * N + i);
+  double v;
+  if (kind == 0) v = (double)*(const npd_real_t *)e;
+  else if (kind == 1) v = (double)*(const float *)(e + sub * 4);
+  else v = (double)*(const int32_t *)(e + sub * 4);
+  out[(size_t)f * n + i] = v;
+}
+extern "C" void NPB_LAUNCHER(gather)(const void *arena, size_t npad, const int *plan_dev, int n_fields, double *out, int n, hipStream_t stream) {
+  hipLaunchKernelGGL(npb_gather_kernel, dim3((n + 255) / 256, n_fields), dim3(256), 0, stream, (const npd_real_t *)arena, npad, plan_dev, out, n);
+}
 extern "C" void NPB_LAUNCHER(field_get)(const void *arena, size_t npad, int col, int sub, int kind, void *out, int n, hipStream_t stream) {
   hipLaunchKernelGGL(npb_field_get_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const npd_real_t *)arena, npad, col, sub, kind, out, n);
 }

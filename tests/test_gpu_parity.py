@@ -598,3 +598,46 @@ def test_nan_state_propagates_like_the_reference(oracle_lib):
             np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, equal_nan=True, err_msg=label)
     clean = (np.arange(n) % 16) >= 8
     assert np.isnan(of[~clean]).any() and not np.isnan(of[clean]).any()
+
+
+def test_state_log_matches_the_references_log(tmp_path):
+    """the columnar state log sampled every step of the m1 data-gen run holds, under the reference's own
+    log-column names, the values the reference's attributes had at those steps (the fixture's per-step states)."""
+    import pyarrow.parquet as pq
+    from nuclear_sim_amd.statelog import StateLog
+    g = Golden("m1_oil_top_off_staggered")
+    n = 64
+    env = _env(g, n=n)
+    f0, i0 = _host_state(env)
+    f, i, fm, im = g.split_state(g.state[0])
+    f0[fm, :] = f[fm, None]; i0[im, :] = i[im, None]
+    env.load_state_arrays(f0, i0)
+    log = StateLog(env, every=1, capacity=g.T)
+    assert len(log.columns) >= 150
+    for t in range(g.T):
+        sp = None if np.isnan(g.setpoint[t]) else g.setpoint[t]
+        env.step(action=int(g.action[t]), magnitude=float(g.magnitude[t]), power_setpoint=sp, noise_z=float(g.noise_z[t]))
+        assert log.maybe_record(t + 1, (t + 1) * env.dt)
+    data = log.array()                                   # [samples, fields, plants]
+    assert data.shape == (g.T, len(log.columns), n)
+    sampled = {int(s): k for k, s in enumerate(g.state_steps)}
+    labels = [c[2] for c in g.cols]                      # the fixture's states, in schema order
+    checked = 0
+    for fi, (kind, slot, label, name) in enumerate(log.columns):
+        col = labels.index(label)
+        for t in range(g.T):
+            if t + 1 in sampled:
+                want = g.state[sampled[t + 1], col]
+                if np.isnan(want):
+                    continue
+                for lane in (0, n - 1):
+                    assert abs(data[t, fi, lane] - want) <= RTOL * abs(want) + 1e-9, (name, t, data[t, fi, lane], want)
+                checked += 1
+    assert checked > 1000
+    tab = log.table(plants=[0, 5])
+    assert tab.num_rows == g.T * 2 and tab.column_names[:3] == ["step", "time", "plant"]
+    assert "secondary.feedwater_FWP-1.oil_level" in tab.column_names
+    path = str(tmp_path / "m1.parquet")
+    log.write_parquet(path, plants=[0])
+    back = pq.read_table(path)
+    assert back.num_rows == g.T and np.allclose(back["secondary.feedwater_FWP-1.oil_level"].to_numpy(), data[:, [c[3] for c in log.columns].index("secondary.feedwater_FWP-1.oil_level"), 0])
