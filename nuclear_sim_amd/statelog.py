@@ -8,7 +8,7 @@ in a device buffer `[sample, field, plant]`; nothing touches the host until `tab
 
 Columns carry the reference's own log names where the member is one of its log columns -- the mapping
 (`state_names.json`) is made by running the reference and matching whole series value-for-value
-(oracle/ref_harness/make_state_names.py) -- and `npb.<section>.<member>` otherwise.
+(the harness script named in DESIGN.md section 6) -- and `npb.<section>.<member>` otherwise.
 
     log = StateLog(env, fields=["pump.oil_level", "sec.electrical_power_output"], every=12, capacity=64)
     for t in range(steps):
