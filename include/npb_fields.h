@@ -47,11 +47,13 @@
 /* ---- primary side: ReactorState + heat source + simulator-level carried scalars
  * reference: systems/primary/__init__.py:48-106, heat_sources/constant_heat_source.py:47-66,
  *            simulator/core/sim.py:391-399,495 */
+/* the NPB_PRIM_NKIN carried members before the outputs (reactivity ... fuel_burnup) belong to the point-kinetics model:
+ * only ReactorHeatSource reads or writes them, so under ConstantHeatSource the step kernel neither loads nor stores
+ * their columns (they keep their values) */
+#define NPB_PRIM_NKIN 12
 #define NPB_PRIM_NOUT 3   /* the last 3 fp64 members are outputs of the step (see "output members" above) */
 #define NPB_PRIM_FIELDS(F, A, I) \
   F(neutron_flux,          "primary_physics.state.neutron_flux") \
-  F(reactivity,            "primary_physics.state.reactivity") \
-  A(precursors, 6,         "primary_physics.state.delayed_neutron_precursors[{k}]") \
   F(fuel_temperature,      "primary_physics.state.fuel_temperature") \
   F(coolant_temperature,   "primary_physics.state.coolant_temperature") \
   F(coolant_pressure,      "primary_physics.state.coolant_pressure") \
@@ -64,15 +66,17 @@
   F(control_rod_position,  "primary_physics.state.control_rod_position") \
   F(steam_valve_position,  "primary_physics.state.steam_valve_position") \
   F(boron_concentration,   "primary_physics.state.boron_concentration") \
+  F(hs_setpoint_percent,   "primary_physics.heat_source.power_setpoint_percent") \
+  F(hs_filtered_noise_mw,  "primary_physics.heat_source.filtered_noise_mw") \
+  F(last_heat_removal_factor, "_last_heat_removal_factor") \
+  F(sim_time,              "time") \
+  F(reactivity,            "primary_physics.state.reactivity") \
+  A(precursors, 6,         "primary_physics.state.delayed_neutron_precursors[{k}]") \
   F(xenon_concentration,   "primary_physics.state.xenon_concentration") \
   F(iodine_concentration,  "primary_physics.state.iodine_concentration") \
   F(samarium_concentration,"primary_physics.state.samarium_concentration") \
   F(burnable_poison_worth, "primary_physics.state.burnable_poison_worth") \
   F(fuel_burnup,           "primary_physics.state.fuel_burnup") \
-  F(hs_setpoint_percent,   "primary_physics.heat_source.power_setpoint_percent") \
-  F(hs_filtered_noise_mw,  "primary_physics.heat_source.filtered_noise_mw") \
-  F(last_heat_removal_factor, "_last_heat_removal_factor") \
-  F(sim_time,              "time") \
   F(power_level,           "primary_physics.state.power_level") \
   F(thermal_power_mw,      "primary_physics.thermal_power_mw") \
   F(total_reactivity_pcm,  "primary_physics.total_reactivity_pcm") \

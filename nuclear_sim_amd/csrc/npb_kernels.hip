@@ -172,15 +172,27 @@ __device__ __forceinline__ long long npd_real_bits(double v) {
   return __double_as_longlong(v);
 #endif
 }
-template <int NF, int NO, int NI, typename S>
-__device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, const npd_stage_t &st, int col0, uint64_t fmask) {
+/* SKIP0 .. SKIP1: carried members that were not loaded this step and must not be stored (wave-uniform `skip`) */
+template <int NF, int NO, int NI, int SKIP0 = 0, int SKIP1 = 0, typename S>
+__device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, const npd_stage_t &st, int col0, uint64_t fmask, bool skip = false) {
   const double *d = reinterpret_cast<const double *>(&s), *od = reinterpret_cast<const double *>(&old);
   constexpr int NC = NF - NO, NNC = (NO + NI + NPD_NPC - 1) / NPD_NPC;
 #ifdef NPB_PROBE
   fmask = 0; /* the liveness probe looks at the physics only, not at the elision's old copies */
 #endif
+  if (SKIP1 > SKIP0 && !skip) {
+#pragma unroll
+    for (int k = SKIP0; k < SKIP1; k++) {
+      if ((fmask >> k) & 1) {
+        if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) *NPD_RP(col0 + k) = (npd_real_t)d[k];
+      } else {
+        *NPD_RP(col0 + k) = (npd_real_t)d[k];
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < NC; k++) {
+    if (k >= SKIP0 && k < SKIP1) continue;
     if ((fmask >> k) & 1) {
       if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) *NPD_RP(col0 + k) = (npd_real_t)d[k];
     } else {
@@ -200,7 +212,12 @@ __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, con
   }
 }
 #define NPD_ST_STORE_ELIDE(T, stype, s, old, inst) \
-  npd_st_store_elide<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype>(s, old, st, NPD_SEC_COL(T, inst), NPD_ELIDE_##T##_F)
+  npd_st_store_elide<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, 0, 0, stype>(s, old, st, NPD_SEC_COL(T, inst), NPD_ELIDE_##T##_F)
+/* the primary section: the point-kinetics members move only under ReactorHeatSource (npb_fields.h, NPB_PRIM_NKIN) */
+#define NPD_PRIM_KIN0 (NPB_PRIM_NCARRY - NPB_PRIM_NKIN)
+#define NPD_ST_STORE_ELIDE_PRIM(s, old) \
+  npd_st_store_elide<NPB_PRIM_NF64, NPB_PRIM_NOUT, NPB_PRIM_NI32, NPD_PRIM_KIN0, NPB_PRIM_NCARRY, npb_prim_t>( \
+      s, old, st, NPD_SEC_COL(PRIM, 0), NPD_ELIDE_PRIM_F, !kinetics)
 #define NPD_FB(stype, m) (1ull << NPB_F64_SLOT(stype, m))
 #define NPD_FBN(stype, m, n) ((((1ull << (n)) - 1)) << NPB_F64_SLOT(stype, m))
 static constexpr uint64_t NPD_ELIDE_PRIM_F =
@@ -307,7 +324,15 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   in.power_setpoint = (live && setpoint) ? setpoint[p] : NAN;
   in.noise_z = (live && noise_z) ? noise_z[p] : 0.0;
   in.cooling_water_temp = (live && cw_temp) ? cw_temp[p] : NAN;
-  NPD_DMA(PRIM, 0, NPD_LS_PRIM);
+  /* under ConstantHeatSource the point-kinetics columns of the primary section stay where they are: neither staged
+   * nor stored (their register copies are then never used either) */
+  const bool kinetics = P.heat_source == NPB_HEAT_REACTOR;
+  if (kinetics) {
+    NPD_DMA(PRIM, 0, NPD_LS_PRIM);
+  } else {
+    npd_dma<NPD_PRIM_KIN0>(st, NPD_SEC_COL(PRIM, 0), NPD_LS_PRIM);
+    npd_dma<NPD_NCOL(PRIM) - NPB_PRIM_NCARRY>(st, NPD_SEC_COL(PRIM, 0) + NPB_PRIM_NCARRY, NPD_LS_PRIM + NPB_PRIM_NCARRY);
+  }
   NPD_DMA(SEC, 0, NPD_LS_SEC);
 
   double obs[NPB_OBS_DIM];
@@ -398,7 +423,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     /* boundary: fw + pump 0 are staged; store the primary section, stage pump 1 */
     NPD_DMA_WAIT();
     s.has_heat_removal_factor = 1; /* consumed by phase 0; the feedback below always leaves a factor behind (sim.py:495) */
-    NPD_ST_STORE_ELIDE(PRIM, npb_prim_t, s, s_old, 0);
+    NPD_ST_STORE_ELIDE_PRIM(s, s_old);
     NPD_CONSUME(FW, npb_fw_t, fw, NPD_LS_FW);
     NPD_CONSUME(PUMP, npb_pump_t, pm, NPD_LS_PUMP0);
     const npb_fw_t fw_old = fw;
@@ -447,7 +472,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     /* config-2 mode: no feedwater system; boundary straight to SG 0 */
     NPD_DMA_WAIT();
     s.has_heat_removal_factor = 1; /* consumed by phase 0; the feedback below always leaves a factor behind (sim.py:495) */
-    NPD_ST_STORE_ELIDE(PRIM, npb_prim_t, s, s_old, 0);
+    NPD_ST_STORE_ELIDE_PRIM(s, s_old);
     NPD_CONSUME(SG, npb_sg_t, g, 0);
     g_old = g;
     NPD_LDS_DRAIN();
