@@ -62,7 +62,8 @@ NPB_API size_t npb_state_bytes(void);
  * maintenance kernel touches -- + per-step inputs (action 4 + magnitude/setpoint/noise/cooling 4*8) + outputs
  * (obs 22*8 + reward 8 + done 1 + trip_flags 4 + info 10*8) */
 NPB_API size_t npb_step_bytes_per_plant(void);
-/* the same for one handle: with fp32 storage every real-valued column moves 4 bytes instead of 8 */
+/* the same for one handle: with fp32 storage every carried real moves 4 bytes instead of 8, and under
+ * ConstantHeatSource the 12 point-kinetics columns of the primary section are not touched at all */
 NPB_API size_t npb_handle_step_bytes_per_plant(const NpbHandle *h);
 
 NPB_API void npb_default_params(npb_params_t *p);

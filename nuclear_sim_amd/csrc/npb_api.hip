@@ -70,16 +70,19 @@ int npb_num_i32(void) { return NPB_TOTAL_I32; }
 size_t npb_state_bytes(void) { return (size_t)NPB_TOTAL_COL64 * 8; }
 /* carried fp64 members are read and written, int32 members too, output members are only written (as float);
  * the maint.* section belongs to the maintenance kernel */
-static size_t step_bytes(size_t real_bytes) {
+static size_t step_bytes(size_t real_bytes, bool kinetics = true) {
   size_t carried = 0, outputs = 0, ints = 0;
   for (const SectionInfo &s : g_sections) {
     if (s.f64_base == NPB_MAINT_F64_BASE) continue;
     carried += (size_t)(s.nf64 - s.nout) * s.count; outputs += (size_t)s.nout * s.count; ints += (size_t)s.ni32 * s.count;
   }
+  if (!kinetics) carried -= NPB_PRIM_NKIN; /* ConstantHeatSource: the point-kinetics columns are not touched */
   return 2 * carried * real_bytes + 2 * ints * 4 + outputs * 4 + (4 + 4 * 8) + (NPB_OBS_DIM * 8 + 8 + 1 + 4 + NPB_INFO_DIM * 8);
 }
 size_t npb_step_bytes_per_plant(void) { return step_bytes(8); }
-size_t npb_handle_step_bytes_per_plant(const NpbHandle *h) { return step_bytes(h && h->storage == NPB_STORAGE_F32 ? 4 : 8); }
+size_t npb_handle_step_bytes_per_plant(const NpbHandle *h) {
+  return step_bytes(h && h->storage == NPB_STORAGE_F32 ? 4 : 8, !h || h->params.heat_source == NPB_HEAT_REACTOR);
+}
 void npb_default_params(npb_params_t *p) { npb_params_default(p); }
 
 const char *npb_last_error(const NpbHandle *h) { return h ? h->error.c_str() : g_create_error.c_str(); }
