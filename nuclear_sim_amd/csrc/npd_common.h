@@ -76,6 +76,13 @@ NPD_FN double npd_log10(double x) { return npd_log(x) * 4.34294481903251827651e-
 /* x^c for x >= 0: exp(c * log(x)); npd_powc(0, c) = 0 for c > 0 is preserved (log(0) = -inf, exp(-inf) = 0) */
 NPD_FN double npd_powc(double x, double c) { return npd_exp(c * npd_log(x)); }
 
+/* a^p * b^q as ONE exponential of p*log(a) + q*log(b), with the logarithms supplied by the caller: the wear-rate
+ * formulas raise the same few factors to several exponents, and a product of powers needs one exp, not one per
+ * factor (a log + exp pair is ~120 instructions for a lone wave).  Zero factors still give 0 (log 0 = -inf, exp -inf
+ * = 0), NaN and negative factors NaN; the result differs from the product of separately rounded powers in the last
+ * bits only. */
+NPD_FN double npd_pow_logs(double la, double p, double lb, double q) { return npd_exp(p * la + q * lb); }
+
 NPD_FN double npd_sq(double x) { return x * x; }
 /* np.clip / Python max / min on doubles.  A compare + select on fp64 costs a lone wave ~20 cycles (v_cmp_f64 to VCC,
  * the VCC hazard nop, one v_cndmask_b32 per register half) against ~5 for v_max_f64 / v_min_f64, and the path has

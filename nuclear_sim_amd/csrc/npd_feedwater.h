@@ -189,6 +189,9 @@ NPD_FN void npd_pump_update(npb_pump_t *p, const npd_pump_sysconds_t *sc, double
 
   /* update_component_wear  lubrication_base.py:354-401 with calculate_component_wear
    * pump_lubrication.py:275-396; wear levels are read live, so later components see earlier updates */
+  /* the four distinct bases of the wear-rate powers; every rate is then one exp of a sum of their logarithms */
+  const double l_electrical = npd_log(electrical_load_factor), l_speed = npd_log(speed_factor),
+               l_load = npd_log(load_factor), l_pressure = npd_log(pressure_factor);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     const npd_lubcomp_t *c = &NPD_PUMP_COMP[i];
@@ -199,35 +202,34 @@ NPD_FN void npd_pump_update(npb_pump_t *p, const npd_pump_sysconds_t *sc, double
       case 0: { /* impeller: no entry in component_conditions -> all defaults (load 1, speed 1, 55 C, no cavitation) */
         double temp_factor = npd_pymax(1.0, (55.0 - 80.0) / 40.0);
         double bearing_coupling = 1.0 + (max_bearing_wear / 100.0) * 0.3;
-        wear_rate = (c->base * npd_powc(1.0, c->load_exp) * npd_powc(1.0, c->speed_exp) * (1.0 + 0.0 * 3.0) * temp_factor * bearing_coupling);
+        wear_rate = (c->base * 1.0 * 1.0 * (1.0 + 0.0 * 3.0) * temp_factor * bearing_coupling); /* 1 ** e = 1 exactly */
       } break;
       case 1: {
         double temperature = 60.0 + electrical_load_factor * 25.0;
         double temp_factor = npd_pymax(1.0, (temperature - 60.0) / 25.0);
         double coupling = 1.0 + (impeller_wear / 100.0) * 0.2;
-        wear_rate = (c->base * npd_powc(electrical_load_factor, c->load_exp) * npd_powc(speed_factor, c->speed_exp) * temp_factor * coupling);
+        wear_rate = (c->base * npd_pow_logs(l_electrical, c->load_exp, l_speed, c->speed_exp) * temp_factor * coupling);
       } break;
       case 2: {
         double temperature = 50.0 + load_factor * 30.0;
         double cavitation_factor = 1.0 + cav * 2.0;
         double temp_factor = npd_pymax(1.0, (temperature - 50.0) / 30.0);
         double coupling = 1.0 + (impeller_wear / 100.0) * 0.4;
-        wear_rate = (c->base * npd_powc(load_factor, c->load_exp) * npd_powc(speed_factor, c->speed_exp) * cavitation_factor * temp_factor * coupling);
+        wear_rate = (c->base * npd_pow_logs(l_load, c->load_exp, l_speed, c->speed_exp) * cavitation_factor * temp_factor * coupling);
       } break;
       case 3: {
-        double axial_load_factor = 1.0 * load_factor;
-        double coupling = 1.0 + (impeller_wear / 100.0) * 0.25;
-        wear_rate = (c->base * npd_powc(axial_load_factor, c->load_exp) * npd_powc(speed_factor, c->speed_exp) * coupling);
+        double coupling = 1.0 + (impeller_wear / 100.0) * 0.25;   /* axial_load_factor = 1.0 * load_factor */
+        wear_rate = (c->base * npd_pow_logs(l_load, c->load_exp, l_speed, c->speed_exp) * coupling);
       } break;
       case 4: {
         double cavitation_seal_factor = 1.0 + cav * 5.0;
         double impeller_coupling = 1.0 + (impeller_wear / 100.0) * 0.15;
         double bearing_coupling = 1.0 + (max_bearing_wear / 100.0) * 0.2;
-        wear_rate = (c->base * npd_powc(pressure_factor, c->load_exp) * 1.0 * cavitation_seal_factor * impeller_coupling * bearing_coupling);
+        wear_rate = (c->base * npd_exp(c->load_exp * l_pressure) * 1.0 * cavitation_seal_factor * impeller_coupling * bearing_coupling);
       } break;
       default: {
         double bearing_coupling = 1.0 + (max_bearing_wear / 100.0) * 0.3;
-        wear_rate = (c->base * 1.0 * 1.0 * npd_powc(load_factor, c->load_exp) * bearing_coupling);
+        wear_rate = (c->base * 1.0 * 1.0 * npd_exp(c->load_exp * l_load) * bearing_coupling);
       } break;
     }
     wear_rate *= 1.0; /* chemistry_wear_factor default */

@@ -141,7 +141,8 @@ NPD_FN double npd_core_ua(double coolant_flow_rate) {
   double reynolds = density * velocity * fuel_rod_diameter / viscosity;
   reynolds = npd_pymax(reynolds, 1000.0);
   double prandtl = viscosity * specific_heat / thermal_conductivity;
-  double nusselt = 0.023 * npd_powc(reynolds, 0.8) * npd_powc(prandtl, 0.4);
+  (void)prandtl; /* = 0.8509090909090908, a constant: prandtl ** 0.4 = 0.937461121006843 */
+  double nusselt = 0.023 * npd_powc(reynolds, 0.8) * 0.937461121006843;
   double h = nusselt * thermal_conductivity / fuel_rod_diameter;
   double overall_ua = h * heat_transfer_area;
   overall_ua = overall_ua * 0.1;

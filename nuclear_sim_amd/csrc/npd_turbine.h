@@ -446,20 +446,21 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
   t->lub_antioxidant_level = oil.antioxidant; t->lub_anti_wear_level = oil.anti_wear;
   t->lub_corrosion_inhibitor_level = oil.corrosion_inhibitor; t->lub_effectiveness = oil.effectiveness;
   /* update_component_wear with calculate_component_wear :261-333; map_bearing_to_lubrication_components :931-964 */
+  const double l_bspeed = npd_log(b_speed_factor); /* shared base of the three bearing wear-rate powers */
   for (int i = 0; i < 5; i++) {
     double wear_rate;
     if (i == 0) {
       double steam_temp_factor = npd_pymax(1.0, (b_temperature[0] - 70.0) / 20.0);
       double load_factor_adj = b_load_factor[0] * 1.2;
-      wear_rate = (NPD_TLUB_BASE[0] * npd_powc(load_factor_adj, NPD_TLUB_LOAD_EXP[0]) * npd_powc(b_speed_factor, NPD_TLUB_SPEED_EXP[0]) * steam_temp_factor);
+      wear_rate = (NPD_TLUB_BASE[0] * npd_pow_logs(npd_log(load_factor_adj), NPD_TLUB_LOAD_EXP[0], l_bspeed, NPD_TLUB_SPEED_EXP[0]) * steam_temp_factor);
     } else if (i == 1) {
       double moisture_factor = npd_pymax(1.0, (1.0 - 0.99) * 10.0);
       double temp_factor = npd_pymax(1.0, (b_temperature[1] - 60.0) / 25.0);
-      wear_rate = (NPD_TLUB_BASE[1] * npd_powc(b_load_factor[1], NPD_TLUB_LOAD_EXP[1]) * npd_powc(b_speed_factor, NPD_TLUB_SPEED_EXP[1]) * moisture_factor * temp_factor);
+      wear_rate = (NPD_TLUB_BASE[1] * npd_pow_logs(npd_log(b_load_factor[1]), NPD_TLUB_LOAD_EXP[1], l_bspeed, NPD_TLUB_SPEED_EXP[1]) * moisture_factor * temp_factor);
     } else if (i == 2) {
       double axial_load_factor = b_load_factor[2] * 1.0;
       double temp_factor = npd_pymax(1.0, (b_temperature[2] - 50.0) / 30.0);
-      wear_rate = (NPD_TLUB_BASE[2] * npd_powc(axial_load_factor, NPD_TLUB_LOAD_EXP[2]) * npd_powc(b_speed_factor, NPD_TLUB_SPEED_EXP[2]) * temp_factor);
+      wear_rate = (NPD_TLUB_BASE[2] * npd_pow_logs(npd_log(axial_load_factor), NPD_TLUB_LOAD_EXP[2], l_bspeed, NPD_TLUB_SPEED_EXP[2]) * temp_factor);
     } else if (i == 3) {
       double contamination_factor = 1.0 + t->lub_oil_contamination / 10.0;
       wear_rate = (NPD_TLUB_BASE[3] * 1.0 * contamination_factor);
