@@ -201,6 +201,15 @@ class BatchedPlantEnv:
         t = self._col(value, torch.float64 if kind == "f64" else torch.int32)
         _lib.check(self.L.npb_set_field(self._h, 0 if kind == "f64" else 1, slot, self._p(t), 1, self._stream()), self._h)
 
+    def _get_slot(self, kind: str, slot: int) -> torch.Tensor:
+        t = torch.empty(self.n, dtype=torch.float64 if kind == "f64" else torch.int32, device=self.device)
+        _lib.check(self.L.npb_get_field(self._h, 0 if kind == "f64" else 1, slot, self._p(t), 1, self._stream()), self._h)
+        return t
+
+    def _set_slot(self, kind: str, slot: int, value) -> None:
+        t = self._col(value, torch.float64 if kind == "f64" else torch.int32)
+        _lib.check(self.L.npb_set_field(self._h, 0 if kind == "f64" else 1, slot, self._p(t), 1, self._stream()), self._h)
+
     def set_fields(self, fields: dict) -> None:
         for key, v in fields.items():
             if isinstance(key, tuple):
@@ -301,6 +310,62 @@ class _Namespace:
         self.__dict__.update(kw)
 
 
+class _PathProxy:
+    """Read / write the plant's state through the reference's own attribute paths:
+    ``sim.secondary_physics.feedwater_system.pump_system.pumps['FWP-1'].lubrication_system.oil_level`` resolves, step by
+    step, against the reference attribute path every schema member carries (include/npb_fields.h), so code that reads
+    or pokes the reference's object tree runs unchanged.  Only attributes that are state members exist; anything else
+    raises AttributeError (there is no Python object tree behind this)."""
+
+    def __init__(self, env, prefix, extras=None):
+        object.__setattr__(self, "_env", env)
+        object.__setattr__(self, "_prefix", prefix)
+        object.__setattr__(self, "_extras", extras or {})
+
+    @staticmethod
+    def _index():
+        idx = getattr(_PathProxy, "_paths", None)
+        if idx is None:
+            idx = {}
+            for kind, slot, label, path in SCHEMA.columns():
+                if path and not path.startswith("="):
+                    idx[path] = (kind, slot)
+            _PathProxy._paths = idx
+        return idx
+
+    def _resolve(self, path):
+        idx = self._index()
+        if path in idx:
+            kind, slot = idx[path]
+            v = self._env._get_slot(kind, slot)[0].item()
+            return v if kind == "f64" else int(v)
+        if any(p.startswith(path + ".") or p.startswith(path + "[") for p in idx):
+            return _PathProxy(self._env, path)
+        raise AttributeError("%s is not a state member of the plant" % path)
+
+    def __getattr__(self, name):
+        extras = object.__getattribute__(self, "_extras")
+        if name in extras:
+            return extras[name]
+        return self._resolve("%s.%s" % (self._prefix, name) if self._prefix else name)
+
+    def __getitem__(self, key):
+        return self._resolve("%s[%r]" % (self._prefix, key))
+
+    def _assign(self, path, value):
+        idx = self._index()
+        if path not in idx:
+            raise AttributeError("%s is not a state member of the plant" % path)
+        kind, slot = idx[path]
+        self._env._set_slot(kind, slot, [value])
+
+    def __setattr__(self, name, value):
+        self._assign("%s.%s" % (self._prefix, name), value)
+
+    def __setitem__(self, key, value):
+        self._assign("%s[%r]" % (self._prefix, key), value)
+
+
 class NuclearPlantSimulator:
     """Single-plant facade with the reference's signatures (simulator/core/sim.py:27-258), so that loops written
     against the reference -- ``sim.primary_physics.heat_source.set_power_setpoint(p); sim.step(action=...)``
@@ -336,7 +401,10 @@ class NuclearPlantSimulator:
                                     noise_seeds=[heat_source.noise_seed] if (constant and heat_source.noise_enabled and
                                                                              heat_source.noise_seed is not None) else None,
                                     device=device, maintenance=enable_state_management, params=params)
-        self.primary_physics = _Namespace(heat_source=heat_source, rated_power_mw=heat_source.rated_power_mw)
+        # the reference's object tree, as far as it is plant state: attribute paths resolve against the schema
+        self.primary_physics = _PathProxy(self._env, "primary_physics",
+                                          extras={"heat_source": heat_source, "rated_power_mw": heat_source.rated_power_mw})
+        self.secondary_physics = _PathProxy(self._env, "secondary_physics")
         self.ignored_initial_conditions = []
         if secondary_config is not None:
             self._apply_secondary_config(secondary_config)

@@ -641,3 +641,28 @@ def test_state_log_matches_the_references_log(tmp_path):
     log.write_parquet(path, plants=[0])
     back = pq.read_table(path)
     assert back.num_rows == g.T and np.allclose(back["secondary.feedwater_FWP-1.oil_level"].to_numpy(), data[:, [c[3] for c in log.columns].index("secondary.feedwater_FWP-1.oil_level"), 0])
+
+
+def test_facade_reads_and_pokes_through_reference_attribute_paths():
+    """The single-plant facade answers the reference's own attribute chains (they are the quoted paths of the schema), so
+    a loop that reads or pokes the reference's object tree runs unchanged: here the S7 poke -- oil level of FWP-1 to
+    9 % -- written exactly as the reference harness writes it, trips that pump on the next step."""
+    from nuclear_sim_amd.env import NuclearPlantSimulator, ConstantHeatSource
+    sim = NuclearPlantSimulator(dt=1.0, heat_source=ConstantHeatSource(noise_enabled=False))
+    pump = sim.secondary_physics.feedwater_system.pump_system.pumps['FWP-1']
+    assert pump.lubrication_system.oil_level == sim._env.get_field("pump.oil_level", instance=0)[0].item() == 100.0
+    sg1 = sim.secondary_physics.steam_generator_system.steam_generators[1]
+    assert sg1.secondary_pressure == sim._env.get_field("sg.secondary_pressure", instance=1)[0].item()
+    assert sim.primary_physics.state.control_rod_position == sim.state.control_rod_position
+    assert isinstance(pump.state.trip_active, int) and pump.state.trip_active == 0
+    sim.step()
+    pump.lubrication_system.oil_level = 9.0
+    assert pump.lubrication_system.oil_level == 9.0
+    r = sim.step()
+    assert pump.state.trip_active == 1 and (int(r["info"]["trip_flags"]) >> 8) & 1
+    sim.secondary_physics._previous_sg_conditions['levels'][0] = 16.2       # the other S7 poke, dict-and-index syntax
+    assert sim.secondary_physics._previous_sg_conditions['levels'][0] == 16.2
+    with pytest.raises(AttributeError):
+        sim.secondary_physics.turbine.no_such_attribute
+    with pytest.raises(AttributeError):
+        sim.secondary_physics.feedwater_system.pump_system.pumps['FWP-9']
