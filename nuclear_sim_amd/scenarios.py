@@ -11,17 +11,26 @@ state directly as struct-of-arrays columns for ``BatchedPlantEnv.set_fields``:
     fields = action_test_fields("oil_top_off", seeds)        # {column: array[n]}
     env = BatchedPlantEnv(n, dt=5.0, noise_enabled=True, maintenance=True); env.set_fields(fields)
 
-Only the ``oil_top_off`` action is catalogued here (the scenario BASELINE config 4 names); the mapping
-functions take general initial-condition dictionaries, so further catalog entries are data.
-Every column this module produces is checked against the reference's own constructor on several seeds
-(tests/golden/ic_oil_top_off.npz, tests/test_scenarios.py).
+All ten actions the composer maps to the feedwater subsystem are covered (``FEEDWATER_ACTIONS``); their catalog
+entries, scenario tables and the template's ``initial_conditions`` section are data (``feedwater_catalog.json``,
+dumped from the reference by the harness script named in DESIGN.md section 6), the logic that consumes them --
+the composer's filter, the scenario-based randomiser, the constructors' mapping onto state -- is restated here.
+Every column this module produces is checked against the reference's own constructor, per action, for the
+catalog entry and several seeds (tests/golden/ic_*.npz, tests/test_scenarios.py).
 """
 from __future__ import annotations
 
+import copy
+import json
+import os
 import random
-from typing import Dict, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "feedwater_catalog.json")) as _fh:
+    _CATALOG = json.load(_fh)
+FEEDWATER_ACTIONS = tuple(_CATALOG["conditions"])
 
 NUM_PUMPS = 4
 NUM_SG = 3
@@ -40,6 +49,9 @@ FEEDWATER_IC_DEFAULTS = {
     "seal_leakage_rate": [0.001, 0.001, 0.001, 0.0],
     "impeller_cavitation_damage": [0.1, 0.1, 0.1, 0.1],
     "motor_temperature": [70.0, 70.0, 70.0, 70.0],
+    # keys beyond oil_top_off's: None = the constructor leaves the construction-time value alone
+    "pump_oil_water_content": None, "pump_oil_acid_number": None, "oil_temperature": None,
+    "suction_pressure": None, "discharge_pressure": None, "npsh_available": None, "cavitation_intensity": None,
 }
 
 # What the comprehensive template (data_gen/config_engine/templates/nuclear_plant_comprehensive_config.yaml)
@@ -105,6 +117,7 @@ def feedwater_fields(ic: Dict[str, object], n: int, lubrication_effectiveness: f
     (pump_lubrication.py:204-222) -- it enters the performance factors."""
     g = dict(FEEDWATER_IC_DEFAULTS); g.update(ic)
     per_pump = lambda k: np.broadcast_to(np.asarray(g[k], dtype=np.float64), (n, NUM_PUMPS))
+    scalar = lambda k: np.broadcast_to(np.asarray(g[k], dtype=np.float64), (n,))            # one value per plant
     f: Dict[object, np.ndarray] = {}
     motor, pumpb, thrust, seals = (per_pump(k) for k in ("motor_bearing_wear", "pump_bearing_wear", "thrust_bearing_wear", "seal_face_wear"))
     # _calculate_pump_performance_factors(cavitation_damage=0.0)  pump_lubrication.py:1412-1478
@@ -124,7 +137,7 @@ def feedwater_fields(ic: Dict[str, object], n: int, lubrication_effectiveness: f
     flow_per_pump = ((total_steam_flow * 1.02) / MIN_PUMPS_REQUIRED) / degradation_factor
     for k in range(NUM_PUMPS):
         f[("pump.oil_level", k)] = per_pump("pump_oil_levels")[:, k]
-        f[("pump.oil_contamination", k)] = np.broadcast_to(np.float64(g["pump_oil_contamination"]), (n,))
+        f[("pump.oil_contamination", k)] = scalar("pump_oil_contamination")
         f[("pump.wear_motor_bearings", k)] = motor[:, k]
         f[("pump.wear_pump_bearings", k)] = pumpb[:, k]
         f[("pump.wear_thrust_bearing", k)] = thrust[:, k]
@@ -135,6 +148,15 @@ def feedwater_fields(ic: Dict[str, object], n: int, lubrication_effectiveness: f
         f[("pump.vibration_increase", k)] = vibration_increase[:, k]
         f[("pump.cavitation_damage", k)] = per_pump("impeller_cavitation_damage")[:, k] * 10.0
         f[("pump.motor_temperature", k)] = per_pump("motor_temperature")[:, k]
+        # lubrication oil state and pump hydraulics (physics.py:236-262, 283-305): scalars apply to every pump
+        for key, col in (("pump_oil_water_content", "pump.oil_moisture"), ("pump_oil_acid_number", "pump.oil_acidity"),
+                         ("oil_temperature", "pump.oil_temperature"), ("suction_pressure", "pump.suction_pressure"),
+                         ("discharge_pressure", "pump.discharge_pressure")):
+            if g.get(key) is not None:
+                f[(col, k)] = scalar(key)
+        for key, col in (("npsh_available", "pump.npsh_available"), ("cavitation_intensity", "pump.cavitation_intensity")):
+            if g.get(key) is not None:
+                f[(col, k)] = per_pump(key)[:, k]
         if k < MIN_PUMPS_REQUIRED:
             f[("pump.flow_demand", k)] = np.clip(flow_per_pump, 0.0, PUMP_RATED_FLOW * 1.2)    # set_flow_demand :422-447
             required_speed = np.sqrt(flow_per_pump / (PUMP_RATED_FLOW * flow_factor[:, k])) * 100.0
@@ -147,17 +169,98 @@ def feedwater_fields(ic: Dict[str, object], n: int, lubrication_effectiveness: f
     return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in f.items()}
 
 
+def catalog_conditions(action: str) -> Dict[str, object]:
+    """FEEDWATER_CONDITIONS[action] (numbers and lists only)  initial_conditions/feedwater_conditions.py"""
+    if action not in _CATALOG["conditions"]:
+        raise NotImplementedError("%r is not an action the composer maps to the feedwater subsystem (%s)"
+                                  % (action, ", ".join(FEEDWATER_ACTIONS)))
+    return copy.deepcopy(_CATALOG["conditions"][action])
+
+
+def _apply_to_array(base, value, handling):
+    """apply_scenario_to_array_parameter  randomization_utils.py:880-895"""
+    if not base:
+        return base
+    if handling == "preserve_pattern":
+        if base[0] != 0:
+            scale_factor = value / base[0]
+            return [v * scale_factor for v in base]
+        return [value] + base[1:]
+    if handling == "first_element_only":
+        return [value] + base[1:]
+    return [value] * len(base)
+
+
+def randomized_conditions(action: str, seed: Optional[int]) -> Dict[str, object]:
+    """get_randomized_feedwater_conditions(action, seed) for the actions that have a scenario table
+    (randomization_utils.py:799-842 scenario pick and per-parameter draws, :897-941 array handling).  The reference
+    seeds both the stdlib generator and numpy's legacy global generator with the scenario seed; uniform parameters
+    draw from the former, normal ones from the latter (clipped to the range), in the table's parameter order --
+    the same two generators are used here, so the draws are the reference's by construction."""
+    base = catalog_conditions(action)
+    table = _CATALOG["scenarios"].get(action)
+    if not table:
+        raise NotImplementedError("%r has no scenario table: the reference falls back to add_randomness_to_conditions, "
+                                  "which is not restated" % action)
+    r = random.Random(seed)
+    nr = np.random.RandomState(seed)
+    total = sum(sc["probability"] for sc in table)
+    rand_val, cumulative, pick = r.random(), 0.0, table[-1]
+    for sc in table:
+        cumulative += sc["probability"] / total
+        if rand_val <= cumulative:
+            pick = sc
+            break
+    out = copy.deepcopy(base)
+    for name, cfg in pick["parameters"].items():
+        if name not in out:
+            continue
+        lo, hi = cfg["range"]
+        if cfg["distribution"] == "normal":
+            value = float(nr.normal((lo + hi) / 2, (hi - lo) / 4))
+            value = max(lo, min(hi, value))
+        else:
+            value = r.uniform(lo, hi)
+        if isinstance(out[name], list):
+            out[name] = _apply_to_array(out[name], value, cfg["array_handling"] or "preserve_pattern")
+        else:
+            out[name] = value
+    for name, (handling, default) in _CATALOG["array_parameters"].items():
+        if name in out and isinstance(out[name], (int, float)):
+            out[name] = _apply_to_array(base.get(name, default), out[name], handling)
+    return out
+
+
+def composed_feedwater_ic(conditions: Dict[str, object]) -> Dict[str, object]:
+    """The feedwater initial_conditions the composer hands to the simulator: the template's section with the catalog
+    parameters that exist in it overwritten (comprehensive_composer.py:284-293), reduced to the keys that reach state."""
+    tpl = _CATALOG["template_ic"]["feedwater"]
+    ic = {k: copy.deepcopy(tpl[k]) for k in FEEDWATER_IC_DEFAULTS if k in tpl}
+    ic["sg_steam_flows"] = list(_CATALOG["template_ic"]["steam_generator"]["sg_steam_flows"])   # physics.py:196: the SG section's flows
+    for k, v in conditions.items():
+        if k in tpl and k in FEEDWATER_IC_DEFAULTS:
+            ic[k] = v
+    return ic
+
+
+def _stack(ics: Sequence[Dict[str, object]]) -> Dict[str, object]:
+    """per-plant dictionaries -> one dictionary of arrays [n] / [n, 4]"""
+    out = {}
+    for k in ics[0]:
+        out[k] = None if ics[0][k] is None else np.asarray([ic[k] for ic in ics], dtype=np.float64)
+    return out
+
+
 def action_test_fields(action: str, seeds: Sequence[int], lubrication_effectiveness: float, randomize: bool = True) -> Dict[object, np.ndarray]:
     """Columns that turn freshly constructed plants (default configuration) into the plants
     ``MaintenanceScenarioRunner`` would build for ``compose_action_test_scenario(action, randomize=True,
     randomization_seed=seed)``, one per seed."""
-    if action != "oil_top_off":
-        raise NotImplementedError("only the oil_top_off catalog entry is restated (SURVEY.md 8f-2)")
     n = len(seeds)
-    ic = dict(ACTION_TEST_TEMPLATE["feedwater"]); ic.update(OIL_TOP_OFF_CONDITIONS)
     if randomize:
-        ic["pump_oil_levels"] = randomized_oil_top_off_levels(seeds)
-    f = feedwater_fields(ic, n, lubrication_effectiveness)
+        ics = [composed_feedwater_ic(randomized_conditions(action, int(sd))) for sd in seeds]
+    else:
+        ics = [composed_feedwater_ic(catalog_conditions(action))] * n
+    f = feedwater_fields(_stack(ics), n, lubrication_effectiveness)
     for k in range(NUM_SG):
         f[("sg.steam_flow_rate", k)] = np.full(n, ACTION_TEST_TEMPLATE["steam_generator"]["sg_steam_flows"][k])
     f["turb.rotor_temperature"] = np.full(n, ACTION_TEST_TEMPLATE["turbine"]["rotor_temperature"])

@@ -1,0 +1,73 @@
+"""Dump the DATA of the reference's feedwater action-test catalog for nuclear_sim_amd/scenarios.py.
+
+Harness-only (imports the reference).  Writes nuclear_sim_amd/feedwater_catalog.json with
+  template_ic   the feedwater `initial_conditions` section of the comprehensive template (the composer only applies
+                catalog parameters that exist there, comprehensive_composer.py:284-293)
+  conditions    FEEDWATER_CONDITIONS[action] for the actions the composer maps to the feedwater subsystem
+                (initial_conditions/feedwater_conditions.py), metadata strings dropped
+  scenarios     ACTION_SCENARIOS[action] (randomization_utils.py): probability + parameter ranges per scenario
+  array_parameters   the per-parameter array handling of get_randomized_feedwater_conditions (:917-936)
+Tables of numbers only; the logic that consumes them is restated in scenarios.py and pinned by tests/golden/ic_*.npz.
+(python -m oracle.ref_harness.make_catalog)"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.ref_harness import refsim  # noqa: E402
+
+ARRAY_PARAMETERS = {   # randomization_utils.py:917-936
+    "pump_oil_levels": ("preserve_pattern", [100.0, 100.0, 100.0, 100.0]),
+    "motor_bearing_wear": ("first_element_only", [0.0, 0.1, 0.1, 0.0]),
+    "pump_bearing_wear": ("first_element_only", [0.0, 0.1, 0.1, 0.0]),
+    "thrust_bearing_wear": ("first_element_only", [0.0, 0.1, 0.1, 0.0]),
+    "motor_temperature": ("first_element_only", [70.0, 30.0, 30.0, 25.0]),
+    "pump_vibrations": ("first_element_only", [5.0, 1.0, 1.0, 0.0]),
+    "npsh_available": ("first_element_only", [20.0, 20.0, 20.0, 20.0]),
+    "cavitation_intensity": ("first_element_only", [0.05, 0.01, 0.01, 0.01]),
+    "seal_face_wear": ("first_element_only", [0.0, 0.1, 0.1, 0.1]),
+    "impeller_wear": ("first_element_only", [0.0, 0.1, 0.1, 0.1]),
+    "impeller_cavitation_damage": ("first_element_only", [0.0, 0.1, 0.1, 0.1]),
+    "bearing_temperatures": ("first_element_only", [50.0, 30.0, 30.0, 25.0]),
+    "pump_flows": ("first_element_only", [500.0, 500.0, 500.0, 0.0]),
+    "pump_speeds": ("first_element_only", [3600.0, 3600.0, 3600.0, 0.0]),
+    "sg_levels": ("preserve_pattern", [12.5, 12.5, 12.5]),
+    "sg_pressures": ("preserve_pattern", [6.895, 6.895, 6.895]),
+    "sg_steam_flows": ("preserve_pattern", [500.0, 500.0, 500.0]),
+    "sg_steam_qualities": ("preserve_pattern", [0.99, 0.99, 0.99]),
+}
+
+
+def main():
+    import yaml
+    refsim.setup()
+    from data_gen.config_engine.composers.comprehensive_composer import ComprehensiveComposer
+    from data_gen.config_engine.initial_conditions.feedwater_conditions import FEEDWATER_CONDITIONS
+    from data_gen.config_engine.initial_conditions.randomization_utils import ACTION_SCENARIOS
+    with refsim.quiet():
+        comp = ComprehensiveComposer()
+    actions = [a for a, s in comp.action_subsystem_map.items() if s == "feedwater"]
+    import data_gen.config_engine.composers.comprehensive_composer as cc
+    tpl = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(cc.__file__)), "templates",
+                                           "nuclear_plant_comprehensive_config.yaml")))
+    sec = tpl["secondary_system"]
+    out = {"template_ic": {"feedwater": sec["feedwater"]["initial_conditions"],
+                           "steam_generator": sec["steam_generator"].get("initial_conditions", {}),
+                           "turbine": sec["turbine"].get("initial_conditions", {})},
+           "conditions": {}, "scenarios": {}, "array_parameters": {k: list(v) for k, v in ARRAY_PARAMETERS.items()}}
+    for a in actions:
+        out["conditions"][a] = {k: v for k, v in FEEDWATER_CONDITIONS[a].items() if isinstance(v, (int, float, list)) and not isinstance(v, bool)}
+        if a in ACTION_SCENARIOS:
+            out["scenarios"][a] = [{"name": s["name"], "probability": s.get("probability", 1.0),
+                                    "parameters": {p: {"range": list(c["range"]), "distribution": c.get("distribution", "uniform"),
+                                                       "array_handling": c.get("array_handling")} for p, c in s["parameters"].items()}}
+                                   for s in ACTION_SCENARIOS[a]]
+    path = os.path.join(ROOT, "nuclear_sim_amd", "feedwater_catalog.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("%d actions (%d with scenario tables) -> %s" % (len(actions), len(out["scenarios"]), path))
+
+
+if __name__ == "__main__":
+    main()

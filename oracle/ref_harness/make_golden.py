@@ -120,5 +120,13 @@ def make_ic_fixture(action="oil_top_off", seeds=tuple(range(12))):
 if __name__ == "__main__":
     if sys.argv[1:] == ["ic"]:
         make_ic_fixture()
+    elif sys.argv[1:] == ["ic_all"]:
+        # every action the composer maps to the feedwater subsystem: the catalog entry, plus a few seeds where the
+        # reference randomises from a scenario table (the others fall back to a generic jitter that is not restated)
+        from nuclear_sim_amd import scenarios
+        for a in scenarios.FEEDWATER_ACTIONS:
+            if a == "oil_top_off":
+                continue
+            make_ic_fixture(a, seeds=(0, 1, 2, 3, 5, 8) if a in scenarios._CATALOG["scenarios"] else ())
     else:
         main(only=set(sys.argv[1:]) or None)

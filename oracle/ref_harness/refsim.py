@@ -71,6 +71,9 @@ def _build_dataclass(cls, data):
 _ready = False
 
 
+_REAL_NORMAL = _FLAT_NORMAL = None
+
+
 def setup():
     global _ready
     if _ready:
@@ -98,6 +101,8 @@ def setup():
 
     def _random(size=None):
         return 1.0 if size is None else np.ones(size)
+    global _REAL_NORMAL, _FLAT_NORMAL
+    _REAL_NORMAL, _FLAT_NORMAL = np.random.normal, _normal
     np.random.normal = _normal
     np.random.random = _random
     _ready = True
@@ -138,9 +143,14 @@ def make_runner_sim(action="oil_top_off", duration_hours=4.0, feedwater_ic=None,
     with quiet():
         from data_gen.config_engine.composers.comprehensive_composer import ComprehensiveComposer
         from data_gen.runners.maintenance_scenario_runner import MaintenanceScenarioRunner
-        cfg = ComprehensiveComposer().compose_action_test_scenario(
-            target_action=action, duration_hours=duration_hours, randomize=randomization_seed is not None,
-            randomization_seed=randomization_seed)
+        import numpy as np
+        np.random.normal = _REAL_NORMAL    # the composer's randomiser draws its "normal" parameters from the seeded global stream
+        try:
+            cfg = ComprehensiveComposer().compose_action_test_scenario(
+                target_action=action, duration_hours=duration_hours, randomize=randomization_seed is not None,
+                randomization_seed=randomization_seed)
+        finally:
+            np.random.normal = _FLAT_NORMAL
         for k, v in (feedwater_ic or {}).items():
             cfg["secondary_system"]["feedwater"]["initial_conditions"][k] = v
         runner = MaintenanceScenarioRunner(cfg, verbose=False)

@@ -666,3 +666,35 @@ def test_facade_reads_and_pokes_through_reference_attribute_paths():
         sim.secondary_physics.turbine.no_such_attribute
     with pytest.raises(AttributeError):
         sim.secondary_physics.feedwater_system.pump_system.pumps['FWP-9']
+
+
+@pytest.mark.parametrize("action", ["seal_replacement", "oil_change", "motor_bearing_replacement"])
+def test_other_feedwater_action_scenarios_run_on_the_oracle_track(oracle_lib, action):
+    """The other randomised feedwater action-test scenarios (pre-degraded seals / oil / bearings, reduced NPSH): plants
+    built from nuclear_sim_amd.scenarios on the GPU and on the oracle from the same columns, 2 h of the runner's loop,
+    every column compared.  (Only the oil_top_off work order is executed on the device; these check the physics from
+    the scenarios' initial conditions.)"""
+    from nuclear_sim_amd.env import BatchedPlantEnv
+    from nuclear_sim_amd import scenarios
+    n, T = 192, 24
+    seeds = list(range(500, 500 + n))
+    env = BatchedPlantEnv.action_test(action, seeds)
+    P = oracle_lib.Params(); P.dt = 5.0; P.hs_noise_enabled = 1; P.maint_enabled = 1
+    ora = oracle_lib.OraclePlants(n, P)
+    eff = float(ora.get("pump.lubrication_effectiveness"))
+    for key, v in scenarios.action_test_fields(action, seeds, eff).items():
+        name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
+        ora.set(name, v, instance=inst, k=k)
+    z = np.random.RandomState(42).standard_normal(T)
+    for t in range(T):
+        o_obs, _r, o_done, o_flags, _ = ora.step(setpoint=np.full(n, 90.0), noise_z=np.full(n, z[t]))
+        obs, rew, done, info = env.step(power_setpoint=np.full(n, 90.0))
+        np.testing.assert_allclose(obs.cpu().numpy(), o_obs, rtol=RTOL, atol=1e-12, err_msg="obs step %d" % t)
+        assert np.array_equal(info["trip_flags"].cpu().numpy().astype(np.uint32), o_flags), "trip flags step %d" % t
+    f, i = _host_state(env)
+    of, oi = ora.state_all()
+    for kind, slot, label, _p in env_cols():
+        if kind == "i32":
+            assert np.array_equal(i[slot, :n], oi[:, slot]), label
+        else:
+            np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)

@@ -12,8 +12,8 @@ from nuclear_sim_amd.schema import SCHEMA
 from nuclear_sim_amd import scenarios
 
 
-def _load():
-    z = np.load(os.path.join(GOLDEN_DIR, "ic_oil_top_off.npz"), allow_pickle=False)
+def _load(action="oil_top_off"):
+    z = np.load(os.path.join(GOLDEN_DIR, "ic_%s.npz" % action), allow_pickle=False)
     cols = SCHEMA.columns()
     idx = {str(p): j for j, p in enumerate(z["paths"]) if str(p)}
     st = np.full((z["state"].shape[0], len(cols)), np.nan)
@@ -64,6 +64,29 @@ def test_action_test_state_matches_reference_constructor(oracle_lib):
     _check(o, st[:1], cols)
     o = _apply(oracle_lib, scenarios.action_test_fields("oil_top_off", seeds, float(eff)), len(seeds))
     _check(o, st[1:], cols)
+
+
+@pytest.mark.parametrize("action", scenarios.FEEDWATER_ACTIONS)
+def test_every_feedwater_action_matches_reference_constructor(oracle_lib, action):
+    """All ten actions the composer maps to the feedwater subsystem: the catalog entry as composed into the template
+    (row 0) and, where the reference randomises from a scenario table, several seeds -- uniform draws from the stdlib
+    generator, normal ones from numpy's legacy generator, both seeded with the scenario seed -- against the state the
+    reference's own constructor leaves behind, on every column."""
+    st, seeds, cols = _load(action)
+    eff = float(oracle_lib.OraclePlants(1, oracle_lib.Params()).get("pump.lubrication_effectiveness"))
+    o = _apply(oracle_lib, scenarios.action_test_fields(action, [0], eff, randomize=False), 1)
+    _check(o, st[:1], cols)
+    if seeds:
+        o = _apply(oracle_lib, scenarios.action_test_fields(action, seeds, eff), len(seeds))
+        _check(o, st[1:], cols)
+    else:
+        with pytest.raises(NotImplementedError):
+            scenarios.randomized_conditions(action, 0)
+
+
+def test_unknown_action_is_refused():
+    with pytest.raises(NotImplementedError):
+        scenarios.action_test_fields("vibration_analysis", [0], 0.9)   # mapped to the turbine subsystem by the composer
 
 
 def test_scenario_mix_follows_the_catalog_probabilities():
