@@ -24,6 +24,7 @@ import copy
 import json
 import os
 import random
+import re
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -31,6 +32,9 @@ import numpy as np
 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "feedwater_catalog.json")) as _fh:
     _CATALOG = json.load(_fh)
 FEEDWATER_ACTIONS = tuple(_CATALOG["conditions"])
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "action_state_deltas.json")) as _fh:
+    _DELTAS = json.load(_fh)
+ALL_ACTIONS = tuple(_DELTAS["actions"])      # every action of the composer's action -> subsystem map that the reference can build
 
 NUM_PUMPS = 4
 NUM_SG = 3
@@ -236,7 +240,7 @@ def composed_feedwater_ic(conditions: Dict[str, object]) -> Dict[str, object]:
     parameters that exist in it overwritten (comprehensive_composer.py:284-293), reduced to the keys that reach state."""
     tpl = _CATALOG["template_ic"]["feedwater"]
     ic = {k: copy.deepcopy(tpl[k]) for k in FEEDWATER_IC_DEFAULTS if k in tpl}
-    ic["sg_steam_flows"] = list(_CATALOG["template_ic"]["steam_generator"]["sg_steam_flows"])   # physics.py:196: the SG section's flows
+    ic["sg_steam_flows"] = list(ACTION_TEST_TEMPLATE["feedwater"]["sg_steam_flows"])   # what the composed configuration hands physics.py:196
     for k, v in conditions.items():
         if k in tpl and k in FEEDWATER_IC_DEFAULTS:
             ic[k] = v
@@ -251,10 +255,43 @@ def _stack(ics: Sequence[Dict[str, object]]) -> Dict[str, object]:
     return out
 
 
+def _label_key(label: str):
+    """"pump[2].oil_level" / "sg[0].tsp_magnetite[3]" / "cond.scale_thickness" -> the key form of set_fields"""
+    m = re.match(r"^(\w+)(?:\[(\d+)\])?\.(\w+)(?:\[(\d+)\])?$", label)
+    sec, inst, name, k = m.group(1), m.group(2), m.group(3), m.group(4)
+    if inst is None and k is None:
+        return "%s.%s" % (sec, name)
+    return ("%s.%s" % (sec, name), int(inst or 0), int(k or 0))
+
+
 def action_test_fields(action: str, seeds: Sequence[int], lubrication_effectiveness: float, randomize: bool = True) -> Dict[object, np.ndarray]:
     """Columns that turn freshly constructed plants (default configuration) into the plants
     ``MaintenanceScenarioRunner`` would build for ``compose_action_test_scenario(action, randomize=True,
-    randomization_seed=seed)``, one per seed."""
+    randomization_seed=seed)``, one per seed.
+
+    Feedwater actions: restated (catalog + randomiser + constructor mapping, above).  Every other action of the
+    composer's map (turbine, condenser, steam generator, generic; 100 of them): the composed template plus the few
+    state members the action's catalog entry reaches (``action_state_deltas.json``: for 77 of them none at all -- their
+    catalog parameters are not in the template's sections or are never read by a constructor).  For turbine, condenser
+    and generic actions the composer's randomisation never reaches plant state, so that is exact for every seed; the
+    ten steam-generator actions whose randomisation does are available un-randomised only."""
+    if action not in _DELTAS["actions"]:
+        raise NotImplementedError("%r is not an action-test scenario the reference can build%s" % (
+            action, " (its own composition raises)" if action in _DELTAS["failed_in_reference"] else ""))
+    info = _DELTAS["actions"][action]
+    if info["subsystem"] != "feedwater":
+        if randomize and info["randomisation_reaches_state"]:
+            raise NotImplementedError("the randomiser of the %s action %r is not restated; use randomize=False" % (info["subsystem"], action))
+        n = len(seeds)
+        f = feedwater_fields(composed_feedwater_ic({}), n, lubrication_effectiveness)
+        for k in range(NUM_SG):
+            f[("sg.steam_flow_rate", k)] = np.full(n, ACTION_TEST_TEMPLATE["steam_generator"]["sg_steam_flows"][k])
+        f["turb.rotor_temperature"] = np.full(n, ACTION_TEST_TEMPLATE["turbine"]["rotor_temperature"])
+        for k in range(4):
+            f[("turb.bearing_metal_temp", 0, k)] = np.full(n, ACTION_TEST_TEMPLATE["turbine"]["bearing_temperatures"][k])
+        for label, value in info["delta"].items():
+            f[_label_key(label)] = np.full(n, value)
+        return f
     n = len(seeds)
     if randomize:
         ics = [composed_feedwater_ic(randomized_conditions(action, int(sd))) for sd in seeds]

@@ -69,5 +69,33 @@ def main():
     print("%d actions (%d with scenario tables) -> %s" % (len(actions), len(out["scenarios"]), path))
 
 
+def make_action_deltas():
+    """nuclear_sim_amd/action_state_deltas.json from tests/golden/ic_all_actions.npz (make_golden.py ic_actions): for every
+    action of the composer's map, its subsystem and the state members whose construction-time value differs from the
+    plain template's (a generic action's), for the catalog entry.  For the turbine, condenser and generic actions the
+    composer's randomisation never reaches plant state (seeded rows equal the catalog row), so this table IS their
+    initial state; for the steam-generator actions it is the un-randomised entry only."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ic_all_actions.npz"))
+    st, acts, subs, seeds, labels = z["state"], [str(a) for a in z["actions"]], [str(x) for x in z["subsystems"]], z["seeds"], [str(x) for x in z["labels"]]
+    base = st[acts.index("visual_inspection")]
+    out = {"failed_in_reference": sorted({str(f).split("|")[0] for f in z["failed"]}), "actions": {}}
+    for a in dict.fromkeys(acts):
+        rows = {int(seeds[i]): st[i] for i in range(len(acts)) if acts[i] == a}
+        sub = subs[acts.index(a)]
+        delta = {labels[j]: float(rows[-1][j]) for j in range(len(labels))
+                 if not (np.isnan(rows[-1][j]) and np.isnan(base[j])) and rows[-1][j] != base[j]}
+        seeded_same = all(np.array_equal(r, rows[-1], equal_nan=True) for r in rows.values())
+        out["actions"][a] = {"subsystem": sub, "randomisation_reaches_state": not seeded_same, "delta": delta if sub != "feedwater" else None}
+    path = os.path.join(ROOT, "nuclear_sim_amd", "action_state_deltas.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    n_delta = sum(1 for v in out["actions"].values() if v["delta"])
+    print("%d actions, %d with a state delta, failed in the reference: %s -> %s" % (len(out["actions"]), n_delta, out["failed_in_reference"], path))
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["deltas"]:
+        make_action_deltas()
+    else:
+        main()

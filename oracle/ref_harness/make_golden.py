@@ -117,9 +117,37 @@ def make_ic_fixture(action="oil_top_off", seeds=tuple(range(12))):
     print("ic_%s: %d seeds" % (action, len(seeds)))
 
 
+def make_ic_all_actions(seeds=(0,)):
+    """tests/golden/ic_all_actions.npz: for EVERY action of the composer's action -> subsystem map (all four subsystems
+    and the generic ones), the initial state of the simulator the runner builds for the catalog entry and for the
+    given randomisation seeds.  Rows whose construction fails inside the reference are recorded as failed."""
+    from . import refsim
+    refsim.setup()
+    from data_gen.config_engine.composers.comprehensive_composer import ComprehensiveComposer
+    with refsim.quiet():
+        amap = dict(ComprehensiveComposer().action_subsystem_map)
+    cols = SCHEMA.columns()
+    rows, names, subs, seed_of, failed = [], [], [], [], []
+    for a, sub in amap.items():
+        for sd in (None,) + tuple(seeds):
+            try:
+                _runner, sim = refsim.make_runner_sim(action=a, duration_hours=2.0, randomization_seed=sd)
+            except Exception as e:   # the reference's own composition / construction raises for a few entries
+                failed.append("%s|%s|%s" % (a, sd, type(e).__name__))
+                continue
+            rows.append([trace._val(sim, c[3]) for c in cols]); names.append(a); subs.append(sub); seed_of.append(-1 if sd is None else sd)
+        print(a, sub, flush=True)
+    np.savez_compressed(os.path.join(OUT, "ic_all_actions.npz"), state=np.array(rows), actions=np.array(names), subsystems=np.array(subs),
+                        seeds=np.array(seed_of), failed=np.array(failed), labels=np.array([c[2] for c in cols]),
+                        kinds=np.array([c[0] for c in cols]), paths=np.array([c[3] for c in cols]))
+    print("ic_all_actions: %d rows, %d failed" % (len(rows), len(failed)))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["ic"]:
         make_ic_fixture()
+    elif sys.argv[1:] == ["ic_actions"]:
+        make_ic_all_actions()
     elif sys.argv[1:] == ["ic_all"]:
         # every action the composer maps to the feedwater subsystem: the catalog entry, plus a few seeds where the
         # reference randomises from a scenario table (the others fall back to a generic jitter that is not restated)

@@ -84,9 +84,39 @@ def test_every_feedwater_action_matches_reference_constructor(oracle_lib, action
             scenarios.randomized_conditions(action, 0)
 
 
+def _load_all():
+    z = np.load(os.path.join(GOLDEN_DIR, "ic_all_actions.npz"), allow_pickle=False)
+    cols = SCHEMA.columns()
+    idx = {str(p): j for j, p in enumerate(z["paths"]) if str(p)}
+    st = np.full((z["state"].shape[0], len(cols)), np.nan)
+    for j, c in enumerate(cols):
+        if c[3] in idx:
+            st[:, j] = z["state"][:, idx[c[3]]]
+    return st, [str(a) for a in z["actions"]], [int(s) for s in z["seeds"]], cols
+
+
+def test_every_action_of_the_composers_map(oracle_lib):
+    """All 110 action-test scenarios the reference can build (tests/golden/ic_all_actions.npz: the catalog entry and
+    seed 0 of each): the state nuclear_sim_amd.scenarios produces against the reference constructor's, every column."""
+    st, acts, seeds, cols = _load_all()
+    eff = float(oracle_lib.OraclePlants(1, oracle_lib.Params()).get("pump.lubrication_effectiveness"))
+    assert set(acts) == set(scenarios.ALL_ACTIONS) and len(set(acts)) >= 110
+    refused = 0
+    for row, (a, sd) in enumerate(zip(acts, seeds)):
+        try:
+            f = scenarios.action_test_fields(a, [max(sd, 0)], eff, randomize=sd >= 0)
+        except NotImplementedError:
+            refused += 1
+            continue
+        _check(_apply(oracle_lib, f, 1), st[row:row + 1], cols)
+    assert refused == 14     # 10 randomised steam-generator actions + 4 feedwater actions without a scenario table
+
+
 def test_unknown_action_is_refused():
     with pytest.raises(NotImplementedError):
-        scenarios.action_test_fields("vibration_analysis", [0], 0.9)   # mapped to the turbine subsystem by the composer
+        scenarios.action_test_fields("rotor_inspection", [0], 0.9, randomize=False)   # the reference's own composition raises
+    with pytest.raises(NotImplementedError):
+        scenarios.action_test_fields("no_such_action", [0], 0.9)
 
 
 def test_scenario_mix_follows_the_catalog_probabilities():
