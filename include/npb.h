@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NPB_VERSION 100 /* 0.1.0 */
+#define NPB_VERSION 110 /* 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
 #ifndef NPB_API
 #define NPB_API __attribute__((visibility("default")))
 #endif
