@@ -195,6 +195,66 @@ def _apply_to_array(base, value, handling):
     return [value] * len(base)
 
 
+def _is_number(v) -> bool:
+    return isinstance(v, (int, float)) and not isinstance(v, bool)
+
+
+def _jitter(conditions: Dict[str, object], rules: Dict[str, dict], default_scale: float, seed: Optional[int]) -> Dict[str, object]:
+    """add_randomness_to_conditions  randomization_utils.py:13-122: every numeric leaf of the entry -- nested dictionaries
+    included, in the entry's own key order -- is scaled by 1 + U(-s, s), s and the clamp from the parameter's rule or the
+    default scale; one draw per leaf from numpy's legacy generator seeded with the scenario seed (the same generator
+    here: RandomState(seed) is that stream)."""
+    rs = np.random.RandomState(seed)
+
+    def single(value, rule):                               # _apply_single_rule :73-89
+        new = value * (1.0 + rs.uniform(-rule.get("scale_factor", 0.1), rule.get("scale_factor", 0.1)))
+        if rule.get("min_value") is not None:
+            new = max(new, rule["min_value"])
+        if rule.get("max_value") is not None:
+            new = min(new, rule["max_value"])
+        return new
+
+    def default(value):                                    # _apply_default_scaling :91-94
+        return value * (1.0 + rs.uniform(-default_scale, default_scale))
+
+    def array(arr):                                        # _randomize_array :96-122 with an empty rule
+        if not arr or not isinstance(arr[0], (int, float)):
+            return arr
+        return [default(v) for v in arr]
+
+    def rec(obj):                                          # _randomize_recursive :46-64
+        if isinstance(obj, dict):
+            for key, value in obj.items():
+                if key in rules:
+                    obj[key] = [single(v, rules[key]) for v in value] if isinstance(value, list) else single(value, rules[key])
+                elif _is_number(value):
+                    obj[key] = default(value)
+                elif isinstance(value, list):
+                    obj[key] = array(value)
+                else:
+                    rec(value)
+        elif isinstance(obj, list):
+            for item in obj:
+                rec(item)
+
+    out = copy.deepcopy(conditions)
+    rec(out)
+    return out
+
+
+def _violates(conditions: Dict[str, object], rules: Dict[str, dict]) -> bool:
+    """validate_safety_limits :214-262, for rule tables whose entries are all safety limits"""
+    for key, value in conditions.items():
+        if key in rules:
+            lim, less = rules[key]["safety_limit"], rules[key].get("safety_direction", "greater_than") == "less_than"
+            for v in (value if isinstance(value, list) else [value]):
+                if _is_number(v) and ((v < lim) if less else (v > lim)):
+                    return True
+        elif isinstance(value, dict) and _violates(value, rules):
+            return True
+    return False
+
+
 def randomized_conditions(action: str, seed: Optional[int]) -> Dict[str, object]:
     """get_randomized_feedwater_conditions(action, seed) for the actions that have a scenario table
     (randomization_utils.py:799-842 scenario pick and per-parameter draws, :897-941 array handling).  The reference
@@ -203,9 +263,10 @@ def randomized_conditions(action: str, seed: Optional[int]) -> Dict[str, object]
     the same two generators are used here, so the draws are the reference's by construction."""
     base = catalog_conditions(action)
     table = _CATALOG["scenarios"].get(action)
-    if not table:
-        raise NotImplementedError("%r has no scenario table: the reference falls back to add_randomness_to_conditions, "
-                                  "which is not restated" % action)
+    jit = _CATALOG["jitter"]
+    if not table:      # no scenario table: the generic jitter over the complete entry (get_scenario_based_conditions :816-818)
+        out = _jitter(jit["full_conditions"][action], jit["default_rules"], jit["default_scale"], seed)
+        return base if _violates(out, jit["feedwater_safety_rules"]) else out
     r = random.Random(seed)
     nr = np.random.RandomState(seed)
     total = sum(sc["probability"] for sc in table)
@@ -232,7 +293,9 @@ def randomized_conditions(action: str, seed: Optional[int]) -> Dict[str, object]
     for name, (handling, default) in _CATALOG["array_parameters"].items():
         if name in out and isinstance(out[name], (int, float)):
             out[name] = _apply_to_array(base.get(name, default), out[name], handling)
-    return out
+    # a draw beyond a safety limit makes the reference raise, and the composer then uses the plain catalog entry
+    # (get_randomized_feedwater_conditions :962-965, comprehensive_composer.py:251-254)
+    return base if _violates(out, jit["feedwater_safety_rules"]) else out
 
 
 def composed_feedwater_ic(conditions: Dict[str, object]) -> Dict[str, object]:
@@ -261,7 +324,37 @@ def _label_key(label: str):
     sec, inst, name, k = m.group(1), m.group(2), m.group(3), m.group(4)
     if inst is None and k is None:
         return "%s.%s" % (sec, name)
-    return ("%s.%s" % (sec, name), int(inst or 0), int(k or 0))
+    if k is None:
+        return ("%s.%s" % (sec, name), int(inst))           # the same key form feedwater_fields / the template entries use
+    return ("%s.%s" % (sec, name), int(inst or 0), int(k))
+
+
+# steam-generator initial conditions that are plain per-SG state (steam_generator/system.py _apply_initial_conditions):
+_SG_DIRECT = {"sg_levels": "sg.water_level", "sg_pressures": "sg.secondary_pressure", "sg_temperatures": "sg.secondary_temperature",
+              "sg_steam_qualities": "sg.steam_quality", "sg_steam_flows": "sg.steam_flow_rate"}
+_SG_AVERAGES = {"sg_pressures": "sec.sg_avg_pressure", "sg_temperatures": "sec.sg_avg_temperature", "sg_steam_qualities": "sec.sg_avg_quality"}
+
+
+def _sg_randomized_fields(action: str, seeds: Sequence[int]) -> Dict[object, np.ndarray]:
+    """get_randomized_sg_conditions(action, seed) (steam_generator_conditions.py:191-300: the generic jitter with the
+    steam-generator rule table) -> the per-SG state members its parameters reach, for the parameters that exist in the
+    template's steam_generator section."""
+    jit = _CATALOG["jitter"]
+    tpl = _CATALOG["template_ic"]["steam_generator"]
+    vals = {}
+    for sd in seeds:
+        cond = _jitter(jit["full_conditions"][action], jit["sg_rules"], jit["sg_scale"], int(sd))
+        for key, col in _SG_DIRECT.items():
+            if key in cond and key in tpl:
+                vals.setdefault(key, []).append(cond[key])
+    f: Dict[object, np.ndarray] = {}
+    for key, rows in vals.items():
+        a = np.asarray(rows, dtype=np.float64)
+        for k in range(NUM_SG):
+            f[(_SG_DIRECT[key], k)] = a[:, k]
+        if key in _SG_AVERAGES:
+            f[_SG_AVERAGES[key]] = (0.0 + a[:, 0] + a[:, 1] + a[:, 2]) / NUM_SG
+    return f
 
 
 def action_test_fields(action: str, seeds: Sequence[int], lubrication_effectiveness: float, randomize: bool = True) -> Dict[object, np.ndarray]:
@@ -280,8 +373,10 @@ def action_test_fields(action: str, seeds: Sequence[int], lubrication_effectiven
             action, " (its own composition raises)" if action in _DELTAS["failed_in_reference"] else ""))
     info = _DELTAS["actions"][action]
     if info["subsystem"] != "feedwater":
-        if randomize and info["randomisation_reaches_state"]:
-            raise NotImplementedError("the randomiser of the %s action %r is not restated; use randomize=False" % (info["subsystem"], action))
+        sg_rand = randomize and info["randomisation_reaches_state"]
+        if sg_rand and any(("tsp_" in lab or "scale_" in lab) for lab in info["delta"]):
+            raise NotImplementedError("the TSP / scale constructors' mapping of randomised deposit thicknesses is not restated "
+                                      "(%r); use randomize=False" % action)
         n = len(seeds)
         f = feedwater_fields(composed_feedwater_ic({}), n, lubrication_effectiveness)
         for k in range(NUM_SG):
@@ -291,6 +386,8 @@ def action_test_fields(action: str, seeds: Sequence[int], lubrication_effectiven
             f[("turb.bearing_metal_temp", 0, k)] = np.full(n, ACTION_TEST_TEMPLATE["turbine"]["bearing_temperatures"][k])
         for label, value in info["delta"].items():
             f[_label_key(label)] = np.full(n, value)
+        if sg_rand:
+            f.update(_sg_randomized_fields(action, seeds))
         return f
     n = len(seeds)
     if randomize:

@@ -63,6 +63,33 @@ def main():
                                     "parameters": {p: {"range": list(c["range"]), "distribution": c.get("distribution", "uniform"),
                                                        "array_handling": c.get("array_handling")} for p, c in s["parameters"].items()}}
                                    for s in ACTION_SCENARIOS[a]]
+    # the generic jitter (add_randomness_to_conditions): its rule tables and, for the actions that go through it, the
+    # catalog entries complete and in their own key order (it draws one number per numeric leaf, nested dictionaries
+    # included, so the traversal order is part of the behaviour)
+    import data_gen.config_engine.initial_conditions.randomization_utils as ru
+    import data_gen.config_engine.initial_conditions.steam_generator_conditions as sgc
+    captured = {}
+    real = ru.add_randomness_to_conditions
+
+    def spy(conditions_dict, parameter_rules=None, scaling_factor=0.18, seed=None):
+        captured["rules"], captured["scale"] = parameter_rules, scaling_factor
+        return real(conditions_dict, parameter_rules, scaling_factor, seed)
+    sgc.add_randomness_to_conditions = spy
+    try:
+        sgc.get_randomized_sg_conditions("level_control_check", 0, 0.1)
+    finally:
+        sgc.add_randomness_to_conditions = real
+    sg_actions = [a for a, s2 in comp.action_subsystem_map.items() if s2 == "steam_generator"]
+    out["jitter"] = {
+        "default_rules": ru.get_default_parameter_rules(), "default_scale": 0.18,
+        "sg_rules": captured["rules"], "sg_scale": 0.1,
+        "feedwater_safety_rules": {"motor_temperature": {"safety_limit": 130.0, "safety_direction": "greater_than"},
+                                   "npsh_available": {"safety_limit": 12.0, "safety_direction": "less_than"},
+                                   "pump_vibrations": {"safety_limit": 25.0, "safety_direction": "greater_than"},
+                                   "bearing_temperatures": {"safety_limit": 120.0, "safety_direction": "greater_than"}},
+        "full_conditions": {**{a: FEEDWATER_CONDITIONS[a] for a in actions if a not in ACTION_SCENARIOS},
+                            **{a: sgc.STEAM_GENERATOR_CONDITIONS[a] for a in sg_actions}},
+    }
     path = os.path.join(ROOT, "nuclear_sim_amd", "feedwater_catalog.json")
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)

@@ -149,12 +149,14 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["ic_actions"]:
         make_ic_all_actions()
     elif sys.argv[1:] == ["ic_all"]:
-        # every action the composer maps to the feedwater subsystem: the catalog entry, plus a few seeds where the
-        # reference randomises from a scenario table (the others fall back to a generic jitter that is not restated)
+        # every action the composer maps to the feedwater subsystem: the catalog entry plus a few seeds
         from nuclear_sim_amd import scenarios
         for a in scenarios.FEEDWATER_ACTIONS:
             if a == "oil_top_off":
                 continue
-            make_ic_fixture(a, seeds=(0, 1, 2, 3, 5, 8) if a in scenarios._CATALOG["scenarios"] else ())
+            make_ic_fixture(a, seeds=(0, 1, 2, 3, 5, 8))
+    elif len(sys.argv) > 2 and sys.argv[1] == "ic_one":
+        for a in sys.argv[2:]:
+            make_ic_fixture(a, seeds=(0, 1, 2, 3, 5, 8))
     else:
         main(only=set(sys.argv[1:]) or None)

@@ -69,19 +69,26 @@ def test_action_test_state_matches_reference_constructor(oracle_lib):
 @pytest.mark.parametrize("action", scenarios.FEEDWATER_ACTIONS)
 def test_every_feedwater_action_matches_reference_constructor(oracle_lib, action):
     """All ten actions the composer maps to the feedwater subsystem: the catalog entry as composed into the template
-    (row 0) and, where the reference randomises from a scenario table, several seeds -- uniform draws from the stdlib
-    generator, normal ones from numpy's legacy generator, both seeded with the scenario seed -- against the state the
-    reference's own constructor leaves behind, on every column."""
+    (row 0) and several seeds -- scenario tables (uniform draws from the stdlib generator, normal ones from numpy's
+    legacy generator) or, for the four actions without a table, the generic jitter (numpy's legacy generator), all
+    seeded with the scenario seed -- against the state the reference's own constructor leaves behind, on every column."""
     st, seeds, cols = _load(action)
     eff = float(oracle_lib.OraclePlants(1, oracle_lib.Params()).get("pump.lubrication_effectiveness"))
     o = _apply(oracle_lib, scenarios.action_test_fields(action, [0], eff, randomize=False), 1)
     _check(o, st[:1], cols)
-    if seeds:
-        o = _apply(oracle_lib, scenarios.action_test_fields(action, seeds, eff), len(seeds))
-        _check(o, st[1:], cols)
-    else:
-        with pytest.raises(NotImplementedError):
-            scenarios.randomized_conditions(action, 0)
+    assert len(seeds) >= 6
+    o = _apply(oracle_lib, scenarios.action_test_fields(action, seeds, eff), len(seeds))
+    _check(o, st[1:], cols)
+
+
+@pytest.mark.parametrize("action", ["level_control_check", "steam_system_check"])
+def test_randomized_steam_generator_actions(oracle_lib, action):
+    """Steam-generator actions go through the generic jitter with the SG rule table; the parameters that are per-SG state
+    (levels, pressures, temperatures, qualities, steam flows) against the reference constructor, six seeds."""
+    st, seeds, cols = _load(action)
+    eff = float(oracle_lib.OraclePlants(1, oracle_lib.Params()).get("pump.lubrication_effectiveness"))
+    _check(_apply(oracle_lib, scenarios.action_test_fields(action, [0], eff, randomize=False), 1), st[:1], cols)
+    _check(_apply(oracle_lib, scenarios.action_test_fields(action, seeds, eff), len(seeds)), st[1:], cols)
 
 
 def _load_all():
@@ -109,7 +116,7 @@ def test_every_action_of_the_composers_map(oracle_lib):
             refused += 1
             continue
         _check(_apply(oracle_lib, f, 1), st[row:row + 1], cols)
-    assert refused == 14     # 10 randomised steam-generator actions + 4 feedwater actions without a scenario table
+    assert refused == 3      # the randomised TSP / scale deposit scenarios of the steam generators (constructor mapping not restated)
 
 
 def test_unknown_action_is_refused():
