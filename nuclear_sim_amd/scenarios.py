@@ -335,6 +335,53 @@ _SG_DIRECT = {"sg_levels": "sg.water_level", "sg_pressures": "sg.secondary_press
 _SG_AVERAGES = {"sg_pressures": "sec.sg_avg_pressure", "sg_temperatures": "sec.sg_avg_temperature", "sg_steam_qualities": "sec.sg_avg_quality"}
 
 
+NUM_TSP = 7
+
+
+def _sg_deposit_fields(tsp_thickness: Optional[np.ndarray], scale_thickness: Optional[np.ndarray]) -> Dict[object, np.ndarray]:
+    """EnhancedSteamGeneratorPhysics._apply_tsp_fouling_initial_conditions / _apply_scale_initial_conditions
+    (steam_generator/enhanced_physics.py:156-226) on arrays [n, 3]: the total TSP deposit thickness spread over the seven
+    support plates (lower plates foul more) and four species, then the flow restriction and heat-transfer degradation
+    the fouling model derives from them (tsp_fouling_model.py:302-367); tube scale with its composition and thermal
+    resistance (tube_interior_fouling.py:190-243).  A thickness of zero leaves the construction-time values."""
+    f: Dict[object, np.ndarray] = {}
+    if tsp_thickness is not None:
+        level_factors = [1.0 + 0.3 * (NUM_TSP - level - 1) / (NUM_TSP - 1) for level in range(NUM_TSP)]
+        factor_sum = sum(level_factors)
+        hole = 0.023 * 1000.0
+        for i in range(NUM_SG):
+            t = tsp_thickness[:, i]
+            on = t > 0
+            total_restriction = np.zeros_like(t)
+            for level in range(NUM_TSP):
+                lt = t * (level_factors[level] / factor_sum)
+                parts = (lt * 0.50, lt * 0.20, lt * 0.25, lt * 0.05)
+                for name, v in zip(("tsp_magnetite", "tsp_copper", "tsp_silica", "tsp_biological"), parts):
+                    f[("sg." + name, i, level)] = np.where(on, v, 0.0)
+                total = parts[0] + parts[1] + parts[2] + parts[3]
+                eff = np.maximum(hole - 2.0 * total, hole * 0.1)
+                area_ratio = (np.pi * (eff / 2.0) ** 2) / (np.pi * (hole / 2.0) ** 2)
+                total_restriction = total_restriction + (1.0 - area_ratio)
+            ff = total_restriction / NUM_TSP
+            pdr = (1.0 / np.maximum(1.0 - ff, 0.1)) ** 2
+            ht = np.minimum((ff ** 1.5 + ff * 0.3) * 0.6, 0.9)
+            f[("sg.tsp_fouling_fraction", i)] = np.where(on, ff, 0.0)
+            f[("sg.tsp_pressure_drop_ratio", i)] = np.where(on, pdr, 1.0)
+            f[("sg.tsp_ht_degradation", i)] = np.where(on, ht, 0.0)
+    if scale_thickness is not None:
+        for i in range(NUM_SG):
+            t = scale_thickness[:, i]
+            on = t > 0
+            iron, crud, corr = t * 0.6, t * 0.3, t * 0.1
+            tot = np.maximum(t, 0.001)
+            k = np.maximum((iron / tot) * .5 + (crud / tot) * 0.15 + (corr / tot) * 0.3, 0.05)
+            r = (t / 1000.0) / k + 1e-5 + (t / 1000.0) * 0.001
+            for name, v in (("scale_thickness", t), ("scale_iron_oxide", iron), ("scale_crud", crud), ("scale_corrosion", corr),
+                            ("scale_thermal_resistance", r)):
+                f[("sg." + name, i)] = np.where(on, v, 0.0)
+    return f
+
+
 def _sg_randomized_fields(action: str, seeds: Sequence[int]) -> Dict[object, np.ndarray]:
     """get_randomized_sg_conditions(action, seed) (steam_generator_conditions.py:191-300: the generic jitter with the
     steam-generator rule table) -> the per-SG state members its parameters reach, for the parameters that exist in the
@@ -344,10 +391,12 @@ def _sg_randomized_fields(action: str, seeds: Sequence[int]) -> Dict[object, np.
     vals = {}
     for sd in seeds:
         cond = _jitter(jit["full_conditions"][action], jit["sg_rules"], jit["sg_scale"], int(sd))
-        for key, col in _SG_DIRECT.items():
+        for key in list(_SG_DIRECT) + ["tsp_fouling_thicknesses", "scale_thicknesses"]:
             if key in cond and key in tpl:
                 vals.setdefault(key, []).append(cond[key])
-    f: Dict[object, np.ndarray] = {}
+    f: Dict[object, np.ndarray] = _sg_deposit_fields(
+        np.asarray(vals.pop("tsp_fouling_thicknesses"), dtype=np.float64) if "tsp_fouling_thicknesses" in vals else None,
+        np.asarray(vals.pop("scale_thicknesses"), dtype=np.float64) if "scale_thicknesses" in vals else None)
     for key, rows in vals.items():
         a = np.asarray(rows, dtype=np.float64)
         for k in range(NUM_SG):
@@ -374,9 +423,6 @@ def action_test_fields(action: str, seeds: Sequence[int], lubrication_effectiven
     info = _DELTAS["actions"][action]
     if info["subsystem"] != "feedwater":
         sg_rand = randomize and info["randomisation_reaches_state"]
-        if sg_rand and any(("tsp_" in lab or "scale_" in lab) for lab in info["delta"]):
-            raise NotImplementedError("the TSP / scale constructors' mapping of randomised deposit thicknesses is not restated "
-                                      "(%r); use randomize=False" % action)
         n = len(seeds)
         f = feedwater_fields(composed_feedwater_ic({}), n, lubrication_effectiveness)
         for k in range(NUM_SG):

@@ -81,10 +81,11 @@ def test_every_feedwater_action_matches_reference_constructor(oracle_lib, action
     _check(o, st[1:], cols)
 
 
-@pytest.mark.parametrize("action", ["level_control_check", "steam_system_check"])
+@pytest.mark.parametrize("action", ["level_control_check", "steam_system_check", "tsp_chemical_cleaning", "scale_removal"])
 def test_randomized_steam_generator_actions(oracle_lib, action):
     """Steam-generator actions go through the generic jitter with the SG rule table; the parameters that are per-SG state
-    (levels, pressures, temperatures, qualities, steam flows) against the reference constructor, six seeds."""
+    (levels, pressures, temperatures, qualities, steam flows) and the TSP / tube-scale deposits with the quantities the
+    fouling models derive from them, against the reference constructor, six seeds."""
     st, seeds, cols = _load(action)
     eff = float(oracle_lib.OraclePlants(1, oracle_lib.Params()).get("pump.lubrication_effectiveness"))
     _check(_apply(oracle_lib, scenarios.action_test_fields(action, [0], eff, randomize=False), 1), st[:1], cols)
@@ -108,15 +109,9 @@ def test_every_action_of_the_composers_map(oracle_lib):
     st, acts, seeds, cols = _load_all()
     eff = float(oracle_lib.OraclePlants(1, oracle_lib.Params()).get("pump.lubrication_effectiveness"))
     assert set(acts) == set(scenarios.ALL_ACTIONS) and len(set(acts)) >= 110
-    refused = 0
     for row, (a, sd) in enumerate(zip(acts, seeds)):
-        try:
-            f = scenarios.action_test_fields(a, [max(sd, 0)], eff, randomize=sd >= 0)
-        except NotImplementedError:
-            refused += 1
-            continue
+        f = scenarios.action_test_fields(a, [max(sd, 0)], eff, randomize=sd >= 0)
         _check(_apply(oracle_lib, f, 1), st[row:row + 1], cols)
-    assert refused == 3      # the randomised TSP / scale deposit scenarios of the steam generators (constructor mapping not restated)
 
 
 def test_unknown_action_is_refused():
