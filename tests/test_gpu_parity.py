@@ -668,9 +668,11 @@ def test_facade_reads_and_pokes_through_reference_attribute_paths():
         sim.secondary_physics.feedwater_system.pump_system.pumps['FWP-9']
 
 
-@pytest.mark.parametrize("action", ["seal_replacement", "oil_change", "motor_bearing_replacement"])
+@pytest.mark.parametrize("action", ["seal_replacement", "oil_change", "motor_bearing_replacement", "pump_inspection",
+                                    "tsp_chemical_cleaning", "scale_removal", "vacuum_leak_detection"])
 def test_other_feedwater_action_scenarios_run_on_the_oracle_track(oracle_lib, action):
-    """The other randomised feedwater action-test scenarios (pre-degraded seals / oil / bearings, reduced NPSH): plants
+    """Other randomised action-test scenarios -- feedwater (pre-degraded seals / oil / bearings, reduced NPSH), steam
+    generator (TSP and tube-scale deposits), condenser (air in-leakage): plants
     built from nuclear_sim_amd.scenarios on the GPU and on the oracle from the same columns, 2 h of the runner's loop,
     every column compared.  (Only the oil_top_off work order is executed on the device; these check the physics from
     the scenarios' initial conditions.)"""
