@@ -11,6 +11,7 @@ a raw device pointer (``tensor.data_ptr()``).
 from __future__ import annotations
 
 import ctypes
+import os
 import enum
 from typing import Dict, Optional, Sequence
 
@@ -462,8 +463,27 @@ class NuclearPlantSimulator:
         inf = {k: (v[0].item()) for k, v in info.items()}
         inf["scram_activated"] = bool(inf["scram_activated"])
         inf["datetime"] = None
-        inf["secondary_system"] = {"feedwater_total_flow": inf["feedwater_flow"]}
+        inf["secondary_system"] = self._secondary_result()
         return {"observation": o, "reward": float(rew[0].item()), "done": bool(done[0].item()), "info": inf}
+
+    def _secondary_result(self) -> Dict[str, float]:
+        """The scalars of the reference's info["secondary_system"] (secondary/__init__.py:930-1010) that are plant state:
+        which key is which member was established on a reference run, series for series (state_names.json)."""
+        if getattr(self, "_sec_keys", None) is None:
+            import json as _json
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "state_names.json")) as fh:
+                keys = _json.load(fh)["secondary_result_keys"]
+            labels = {c[2]: (c[0], c[1]) for c in SCHEMA.columns()}
+            self._sec_keys = [(k, labels[lab]) for k, lab in sorted(keys.items())]
+            nf = len(self._sec_keys)
+            self._sec_kinds = (ctypes.c_int * nf)(*[0 if kd == "f64" else 1 for _k, (kd, _s) in self._sec_keys])
+            self._sec_slots = (ctypes.c_int * nf)(*[sl for _k, (_kd, sl) in self._sec_keys])
+            self._sec_buf = torch.empty((nf, 1), dtype=torch.float64, device=self._env.device)
+        env = self._env
+        _lib.check(env.L.npb_gather_fields(env._h, len(self._sec_keys), self._sec_kinds, self._sec_slots,
+                                           ctypes.c_void_p(self._sec_buf.data_ptr()), env._stream()), env._h)
+        vals = self._sec_buf[:, 0].cpu().numpy()
+        return {k: float(v) for (k, _), v in zip(self._sec_keys, vals)}
 
     def reset(self, start_at_steady_state: bool = True):
         return self._env.reset()[0].cpu().numpy().copy()

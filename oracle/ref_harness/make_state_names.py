@@ -28,9 +28,10 @@ def main(steps=60):
         runner, sim = refsim.make_runner_sim(action="oil_top_off", duration_hours=steps * 5.0 / 60.0)
         profile = runner._generate_power_profile(steps)
         mine = np.full((steps, len(cols)), np.nan)
+        results = []
         for t in range(steps):
             runner._set_target_power(float(np.clip(profile[t] - 8.0 + 8.0 * np.sin(t / 3.0), 50.0, 100.0)))   # a load that moves
-            sim.step()
+            results.append(sim.step()["info"]["secondary_system"])
             for j, (_kind, _slot, _label, path) in enumerate(cols):
                 mine[t, j] = _val(sim, path) if path and not path.startswith("=") else np.nan
     df = sim.state_manager.data
@@ -79,10 +80,27 @@ def main(steps=60):
                 del out[label]
         else:
             taken[name] = label
+    # the scalars of step()'s info["secondary_system"] dictionary (secondary/__init__.py:930-1010) that are state members
+    result_keys = {}
+    numeric = [k for k, v in results[0].items() if isinstance(v, (int, float, bool))]
+    for k in numeric:
+        series = np.array([float(r[k]) for r in results])
+        hits = [cols[j][2] for j in range(len(cols)) if not np.isnan(mine[:, j]).any() and np.array_equal(mine[:, j], series)]
+        if len(hits) > 1:   # twins: prefer the section the key names, then the member whose name ends the key
+            pref = {"condenser": "cond.", "turbine": "turb.", "feedwater": "fw.", "sg": "sec.sg_", "water_chemistry": "chem[0].", "ph_control": "ph."}
+            for word, sec_prefix in pref.items():
+                if k.startswith(word):
+                    hits = [h for h in hits if h.startswith(sec_prefix)] or hits
+            narrowed = [h for h in hits if k.endswith(h.split(".")[-1].split("[")[0])] or [h for h in hits if h.startswith("sec.")]
+            hits = narrowed if narrowed else hits
+        if hits and np.ptp(series) > 0:      # a constant series proves nothing
+            result_keys[k] = hits[0]
     path = os.path.join(ROOT, "nuclear_sim_amd", "state_names.json")
     with open(path, "w") as fh:
         json.dump({"source": "reference StateManager log, oil_top_off action-test run, %d steps" % steps,
-                   "log_columns": len(df.columns) - 1, "names": out}, fh, indent=1, sort_keys=True)
+                   "log_columns": len(df.columns) - 1, "names": out,
+                   "secondary_result_keys": result_keys, "secondary_result_numeric_keys": len(numeric)}, fh, indent=1, sort_keys=True)
+    print("%d of %d numeric keys of step()'s secondary_system result are state members" % (len(result_keys), len(numeric)))
     print("%d of %d schema columns mapped onto the reference's %d log columns (%d ambiguous left out) -> %s"
           % (len(out), len(cols), len(df.columns) - 1, ambiguous, path))
 
