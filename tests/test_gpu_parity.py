@@ -703,3 +703,29 @@ def test_other_feedwater_action_scenarios_run_on_the_oracle_track(oracle_lib, ac
             assert np.array_equal(i[slot, :n], oi[:, slot]), label
         else:
             np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)
+
+
+def test_largest_handle_uses_the_whole_32bit_offset_range():
+    """One handle at the top of what npb_create accepts (1 000 000 plants: the last arena column starts 4.07 GB into
+    the arena, 95 % of the kernel's 32-bit byte offsets): the first and the last wave must do exactly what the same
+    plants do in a small batch -- an offset that wrapped would read or write somebody else's column."""
+    import torch
+    n = 1_000_000
+    big = _env(n=n, noise_enabled=True)
+    rng = np.random.default_rng(123)
+    pick = np.r_[0:64, n - 64:n]
+    small = _env(n=len(pick), noise_enabled=True)
+    lv = rng.uniform(20, 100, n)
+    big.set_field("pump.oil_level", lv, instance=3); small.set_field("pump.oil_level", lv[pick], instance=3)
+    tr = rng.uniform(300, 360, n)
+    big.set_field("turb.rotor_temperature", tr); small.set_field("turb.rotor_temperature", tr[pick])
+    for t in range(4):
+        z = rng.standard_normal(n); sp = rng.uniform(70, 100, n)
+        ob, rb, db, ib = big.step(power_setpoint=sp, noise_z=z)
+        os_, rs, ds, is_ = small.step(power_setpoint=sp[pick], noise_z=z[pick])
+    idx = torch.as_tensor(pick, device=big.device)
+    assert torch.equal(ob[idx], os_) and torch.equal(rb[idx], rs) and torch.equal(ib["trip_flags"][idx], is_["trip_flags"])
+    assert bool(torch.isfinite(ob).all())
+    for name, inst in (("sec.operating_hours", 0), ("cond.rotation_timer", 0), ("pump.oil_level", 3), ("maint.last_check_time", 0)):
+        assert torch.equal(big.get_field(name, instance=inst)[idx], small.get_field(name, instance=inst)), name
+    big.close()
