@@ -729,3 +729,22 @@ def test_largest_handle_uses_the_whole_32bit_offset_range():
     for name, inst in (("sec.operating_hours", 0), ("cond.rotation_timer", 0), ("pump.oil_level", 3), ("maint.last_check_time", 0)):
         assert torch.equal(big.get_field(name, instance=inst)[idx], small.get_field(name, instance=inst)), name
     big.close()
+
+
+def test_c_abi_accepts_null_inputs_and_outputs():
+    """npb_step with every optional pointer NULL (include/npb.h: defaults NO_ACTION, magnitude 1, setpoint / cooling
+    unchanged, noise 0; no outputs wanted) advances the state exactly like a call that passes the defaults explicitly."""
+    import ctypes
+    import torch
+    from nuclear_sim_amd import _lib
+    n = 100
+    a = _env(n=n); b = _env(n=n)
+    none = ctypes.c_void_p(None)
+    for _ in range(3):
+        _lib.check(a.L.npb_step(a._h, none, none, none, none, none, none, none, none, none, none, a._stream()), a._h)
+        b.step(action=np.full(n, 8, dtype=np.int32), magnitude=np.ones(n), noise_z=np.zeros(n))
+    torch.cuda.synchronize()
+    fa, ia = _host_state(a); fb, ib = _host_state(b)
+    assert np.array_equal(fa, fb, equal_nan=True) and np.array_equal(ia, ib)
+    obs = a.get_observation()
+    assert torch.equal(obs, b.get_observation())
