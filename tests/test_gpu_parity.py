@@ -748,3 +748,50 @@ def test_c_abi_accepts_null_inputs_and_outputs():
     assert np.array_equal(fa, fb, equal_nan=True) and np.array_equal(ia, ib)
     obs = a.get_observation()
     assert torch.equal(obs, b.get_observation())
+
+
+def test_two_handles_on_two_streams_are_independent():
+    """Distinct handles are independent (include/npb.h): two batches stepped on two HIP streams at the same time end
+    where the same batches end when stepped one after the other."""
+    import torch
+    n, T = 4096, 25
+    rng = np.random.default_rng(8)
+    z = rng.standard_normal((T, 2, n)); sp = rng.uniform(70, 100, (2, n))
+    seq = [_env(n=n, noise_enabled=True) for _ in range(2)]
+    for t in range(T):
+        for k in range(2):
+            seq[k].step(power_setpoint=sp[k], noise_z=z[t, k])
+    torch.cuda.synchronize()
+    par = [_env(n=n, noise_enabled=True) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    zs = [torch.as_tensor(z[:, k], device=par[k].device) for k in range(2)]
+    sps = [torch.as_tensor(sp[k], device=par[k].device) for k in range(2)]
+    torch.cuda.synchronize()
+    for t in range(T):
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                par[k].step(power_setpoint=sps[k], noise_z=zs[k][t])
+    torch.cuda.synchronize()
+    for k in range(2):
+        f1, i1 = _host_state(seq[k]); f2, i2 = _host_state(par[k])
+        assert np.array_equal(f1, f2, equal_nan=True) and np.array_equal(i1, i2), "handle %d" % k
+
+
+def test_set_params_takes_effect_at_the_next_step(oracle_lib):
+    """npb_set_params: a new time step mid-run (the reference's sim.dt) applies from the next step on, like the oracle's."""
+    import ctypes
+    from nuclear_sim_amd import _lib
+    n = 96
+    env = _env(n=n, noise_enabled=True)
+    P = oracle_lib.Params(); P.hs_noise_enabled = 1
+    ora = oracle_lib.OraclePlants(n, P)
+    rng = np.random.default_rng(4)
+    for t in range(12):
+        if t == 6:
+            env.params.dt = 0.25; P.dt = 0.25
+            _lib.check(env.L.npb_set_params(env._h, ctypes.byref(env.params)), env._h)
+        z = rng.standard_normal(n)
+        o_obs = ora.step(noise_z=z)[0]
+        obs = env.step(noise_z=z)[0].cpu().numpy()
+        np.testing.assert_allclose(obs, o_obs, rtol=RTOL, atol=1e-12, err_msg="step %d" % t)
+    assert abs(env.get_field("prim.sim_time")[0].item() - (6 * 1.0 + 6 * 0.25)) < 1e-12
