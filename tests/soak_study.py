@@ -1,0 +1,50 @@
+"""Long-run parity soak (not collected by pytest): the HIP stepper against the CPU oracle for tens of thousands of steps
+on one wave of heterogeneous plants with load swings, noise and random operator actions; prints the worst relative
+deviation per checkpoint.  python tests/soak_study.py [steps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+from oracle import npo
+from nuclear_sim_amd.env import BatchedPlantEnv
+from nuclear_sim_amd.schema import SCHEMA
+
+
+def main(steps=20000):
+    n = 64
+    rng = np.random.default_rng(2025)
+    env = BatchedPlantEnv(n, noise_enabled=True, maintenance=True)
+    P = npo.Params(); P.hs_noise_enabled = 1; P.maint_enabled = 1
+    ora = npo.OraclePlants(n, P)
+    for k in range(4):
+        lv = rng.uniform(58.5, 100, n)
+        env.set_field("pump.oil_level", lv, instance=k); ora.set("pump.oil_level", lv, instance=k)
+    cols = SCHEMA.columns()
+    for t in range(steps):
+        z = rng.standard_normal(n)
+        sp = 85.0 + 15.0 * np.sin(t / 700.0 + np.arange(n))
+        act = np.where(rng.random(n) < 0.02, rng.choice([0, 1, 4, 5, 9, 10], n), 8).astype(np.int32)
+        mag = rng.uniform(0, 1, n)
+        cw = 25.0 + 4.0 * np.sin(t / 3000.0 + np.arange(n) * 0.1)
+        o = ora.step(action=act, magnitude=mag, setpoint=sp, noise_z=z, cw_temp=cw)
+        g = env.step(action=act, magnitude=mag, power_setpoint=sp, noise_z=z, cooling_water_temp=cw)
+        if (t + 1) % (steps // 10) == 0 or t + 1 == steps:
+            f, i = env.state_arrays(); f = f.cpu().numpy(); i = i.cpu().numpy()
+            of, oi = ora.state_all()
+            worst, where, ints = 0.0, "", 0
+            for kind, slot, label, _p in cols:
+                if kind == "i32":
+                    ints += int((i[slot, :n] != oi[:, slot]).sum())
+                else:
+                    tol = 6e-8 if SCHEMA.is_output(label.split("[")[0] + "." + label.split(".")[-1].split("[")[0] if "[" in label.split(".")[0] else label.split("[")[0]) else 0.0
+                    d = np.max(np.abs(f[slot, :n] - of[:, slot]) / np.maximum(np.abs(of[:, slot]), 1e-9))
+                    if d - tol > worst:
+                        worst, where = d, label
+            obs_d = float(np.max(np.abs(g[0].cpu().numpy() - o[0]) / np.maximum(np.abs(o[0]), 1e-9)))
+            print("step %6d: worst carried-member deviation %.2e (%s), observations %.2e, int mismatches %d, flags equal %s"
+                  % (t + 1, worst, where, obs_d, ints, bool(np.array_equal(g[3]["trip_flags"].cpu().numpy().astype(np.uint32), o[3]))), flush=True)
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 20000)
