@@ -1,6 +1,6 @@
 """Long-run parity soak (not collected by pytest): the HIP stepper against the CPU oracle for tens of thousands of steps
 on one wave of heterogeneous plants with load swings, noise and random operator actions; prints the worst relative
-deviation per checkpoint.  python tests/soak_study.py [steps]"""
+deviation per checkpoint.  python tests/soak_study.py [steps] [constant|reactor]"""
 import os
 import sys
 
@@ -11,12 +11,18 @@ from nuclear_sim_amd.env import BatchedPlantEnv
 from nuclear_sim_amd.schema import SCHEMA
 
 
-def main(steps=20000):
+def main(steps=20000, heat="constant"):
     n = 64
     rng = np.random.default_rng(2025)
-    env = BatchedPlantEnv(n, noise_enabled=True, maintenance=True)
-    P = npo.Params(); P.hs_noise_enabled = 1; P.maint_enabled = 1
+    env = BatchedPlantEnv(n, heat_source=heat, noise_enabled=True, maintenance=True)
+    P = npo.Params(); P.hs_noise_enabled = 1; P.maint_enabled = 1; P.heat_source = 1 if heat == "reactor" else 0
     ora = npo.OraclePlants(n, P)
+    if heat == "reactor":
+        from nuclear_sim_amd.env import equilibrium_state
+        env.set_fields(equilibrium_state())
+        for key, v in equilibrium_state().items():
+            name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
+            ora.set(name, v, instance=inst, k=k)
     for k in range(4):
         lv = rng.uniform(58.5, 100, n)
         env.set_field("pump.oil_level", lv, instance=k); ora.set("pump.oil_level", lv, instance=k)
@@ -47,4 +53,4 @@ def main(steps=20000):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 20000)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 20000, sys.argv[2] if len(sys.argv) > 2 else "constant")
