@@ -72,6 +72,17 @@ def scenarios():
     for tag, seed in (("a", 4), ("b", 5), ("c", 2)):
         S.append(dict(name="m3%s_oil_top_off_seed%d" % (tag, seed), steps=120, dt=5.0, noise=True, noise_seed=42, every=4,
                       runner=dict(action="oil_top_off", duration_hours=10.0, randomization_seed=seed)))
+    # M4-M7: other action-test scenarios of the composer (randomised initial conditions, nuclear_sim_amd/scenarios.py):
+    # physics from pre-degraded seals / oil / bearings with reduced NPSH, TSP deposits, condenser air in-leakage.  The
+    # reference's maintenance control plane raises work orders of its own in these runs (action types the components do
+    # not know); they change no plant state, and the maint.* members are not compared for these fixtures.
+    # (m5 stops after 75 min: at 80 min the reference executes an oil_change work order -- an action whose trigger /
+    # queueing behind those other work orders is part of the control plane that is not restated.)
+    for name, action, seed, steps in (("m4_seal_replacement_seed3", "seal_replacement", 3, 60), ("m5_oil_change_seed1", "oil_change", 1, 15),
+                                      ("m6_tsp_chemical_cleaning_seed0", "tsp_chemical_cleaning", 0, 60),
+                                      ("m7_vacuum_leak_detection", "vacuum_leak_detection", None, 60)):
+        S.append(dict(name=name, steps=steps, dt=5.0, noise=True, noise_seed=42, every=3, maint_unchecked=True,
+                      runner=dict(action=action, duration_hours=5.0, randomization_seed=seed)))
     return S
 
 
