@@ -27,15 +27,38 @@ PLANTS_PER_GPU = 65536
 HBM_PEAK_GBS = 8000.0  # MI355X spec HBM3E bandwidth (guides/MI355X_MICROARCH.md)
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The CPU oracle (plain-C restatement, 'port') timed on this box's host cores on a bounded
-    sample of the same workload.  Reported beside the GPU number; it is a baseline, not a target."""
-    from oracle import npo
-    n = 32768
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+REFERENCE_PYTHON_STEPS_PER_S_PER_CORE = 147.7  # the reference's own step(), survey container, 1 core
+
+
+def allowed_cores():
+    """Cores this process may actually use: its affinity mask, bounded by the cgroup CPU quota (cgroup v2 cpu.max or
+    v1 cfs quota).  os.cpu_count() is the machine, not the allowance."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
+def _time_oracle(npo, n, threads, seconds_budget):
     P = npo.Params(); P.hs_noise_enabled = 1
     ora = npo.OraclePlants(n, P)
+    used = int(ora.L.npo_set_threads(int(threads)))
     rng = np.random.default_rng(1)
     sp = 90.0 + 10.0 * np.sin(np.arange(n) / 16.0)
     ora.step(setpoint=sp, noise_z=rng.standard_normal(n))  # warm-up
@@ -47,23 +70,53 @@ def cpu_baseline(seconds_budget=15.0):
         dt = time.perf_counter() - t0
         if dt > seconds_budget or steps >= 2000:
             break
-    return {"value": n * steps / dt, "unit": "plant-env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d plants x %d steps of the same C3 workload through oracle/libnpo.so (OpenMP over plants, %.1f s)" % (n, steps, dt)}
+    return n * steps / dt, used, steps, dt
+
+
+def cpu_baseline():
+    """The CPU oracle (plain-C restatement, 'port') timed on this box's host cores on a bounded sample of the same
+    workload: one thread, then every core this process is allowed (affinity / cgroup quota; OpenMP over plants).
+    Reported beside the GPU number; it is a baseline, not a target.  The reference's own Python step() cannot
+    travel to this box; its survey-container figure is quoted beside it."""
+    from oracle import npo
+    cores = allowed_cores()
+    v1, _, s1, d1 = _time_oracle(npo, 2048, 1, 6.0)
+    n = max(4096, 512 * cores)
+    vN, used, sN, dN = _time_oracle(npo, n, cores, 12.0)
+    return {"value": vN, "unit": "plant-env-steps/s", "cores": used, "kind": "port",
+            "value_1_thread": v1, "machine_cpus": os.cpu_count(),
+            "reference_python": {"value_per_core": REFERENCE_PYTHON_STEPS_PER_S_PER_CORE, "unit": "plant-env-steps/s/core",
+                                 "where": "reference NuclearPlantSimulator.step(), state management off, survey container "
+                                          "(BASELINE.md section 2) -- a different box; the reference never travels to the GPU box"},
+            "sample": "the same C3 workload through oracle/libnpo.so: %d plants x %d steps on %d thread(s) (%.1f s), "
+                      "2048 plants x %d steps on 1 thread (%.1f s)" % (n, sN, used, dN, s1, d1)}
 
 
 def measured_traffic(n):
-    """HBM bytes per npb_step_kernel launch from the committed rocprofv3 PMC passes (profiles/README.md);
-    only meaningful for the plant count it was measured at."""
-    best = None
+    """HBM bytes per npb_step_kernel launch from the COMMITTED rocprofv3 PMC passes (profiles/README.md) -- a constant
+    read from a file of an earlier profiling run of the same workload, not measured by this run; only meaningful
+    for the plant count it was measured at.  Returns (bytes, source file) or (None, None)."""
+    best = (None, None)
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
             d = json.load(open(f))
             if d.get("plants") == n and isinstance(d.get("step_hbm_bytes_per_launch"), (int, float)):
-                best = float(d["step_hbm_bytes_per_launch"])
+                best = (float(d["step_hbm_bytes_per_launch"]), os.path.relpath(f, ROOT))
         except Exception:
             pass
     return best
+
+
+def c3_noise(lo, n, total):
+    """BASELINE config 3's heat-source noise exactly as specified: plant i draws from
+    np.random.RandomState(42 + i) -- the reference's own generator (constant_heat_source.py:58-62,178), seeded by
+    GLOBAL plant id, so the samples a plant sees do not depend on how many GPUs share the batch.  Drawn on the host
+    before the timed region and uploaded as one [total, n] block (inputs resident in HBM)."""
+    z = np.empty((n, total))
+    for i in range(n):
+        z[i] = np.random.RandomState(42 + lo + i).standard_normal(total)
+    return np.ascontiguousarray(z.T)
 
 
 def main():
@@ -107,14 +160,21 @@ def main():
     # trace (90 % + 10 % sin, period 600 + 60*(i mod 16) steps) and N(0,1) noise samples
     gid = torch.arange(lo, lo + n, device=dev, dtype=torch.float64)
     period = 600.0 + 60.0 * (gid % 16)
-    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
     total = K + W
     tt = torch.arange(total, device=dev, dtype=torch.float64)[:, None]
-    setpoints = (90.0 + 10.0 * torch.sin(2.0 * np.pi * tt / period[None, :])).contiguous()
-    noise = torch.randn((total, n), device=dev, dtype=torch.float64, generator=gen)
+    target = 90.0 + 10.0 * torch.sin(2.0 * np.pi * tt / period[None, :])
+    # rate-limited to 0.02 % per step exactly as the data-gen runner's _set_target_power does
+    # (maintenance_scenario_runner.py:651-671): the first target is taken as it is, later ones are approached
+    setpoints = torch.empty_like(target)
+    setpoints[0] = target[0]
+    for t in range(1, total):
+        d = target[t] - setpoints[t - 1]
+        setpoints[t] = torch.where(d.abs() > 0.02, setpoints[t - 1] + 0.02 * torch.sign(d), target[t])
+    setpoints = setpoints.contiguous()
+    noise = torch.from_numpy(c3_noise(lo, n, total)).to(dev)
 
     def one_step(t):
-        return env.step(power_setpoint=setpoints[t], noise_z=noise[t])
+        return env.step(power_setpoint=setpoints[t % total], noise_z=noise[t % total])
 
     for t in range(W):
         one_step(t)
@@ -139,12 +199,29 @@ def main():
     KE = min(K, 100)
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(KE)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(KE)]
+    import ctypes
+    from nuclear_sim_amd import _lib
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def raw_step(t):  # the C-ABI call alone: npb_step_kernel (+ npb_maint_kernel with --maintenance), no host-side extras
+        _lib.check(env.L.npb_step(env._h, None, None, ctypes.c_void_p(setpoints[t % total].data_ptr()),
+                                  ctypes.c_void_p(noise[t % total].data_ptr()), None, env._p(env._obs), env._p(env._reward),
+                                  env._p(env._done), env._p(env._flags), env._p(env._info), stream), env._h)
     for k in range(KE):
         starts[k].record()
-        one_step(W + k)
+        raw_step(W + k)
         ends[k].record()
     torch.cuda.synchronize(dev)
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    # self-check: the same loop as the timed region over >= 0.6 s of launches (the driver's --steps 20 is a 2 ms
+    # timed region; one scheduling hiccup there is a 10 % error), inputs cycled
+    K_long = max(K, int(np.ceil(0.6 / max(elapsed / K, 1e-6))))
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for k in range(K_long):
+        one_step(W + k)
+    torch.cuda.synchronize(dev)
+    long_elapsed = time.perf_counter() - t1
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     km = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
     if distributed:
@@ -160,8 +237,13 @@ def main():
     elapsed = float(el.item()); kernel_ms = float(km.item())
 
     if rank == 0:
-        bytes_per_plant = env.handle_step_bytes_per_plant()
+        # algorithmic bytes of one plant-step for this handle (npb_handle_step_bytes_per_plant: carried members read +
+        # written, outputs written, per-step inputs and outputs), minus the three input columns this workload passes
+        # as NULL (action 4 B, magnitude 8 B, cooling-water temperature 8 B): they are not read
+        null_input_bytes = 4 + 8 + 8
+        bytes_per_plant = env.handle_step_bytes_per_plant() - null_input_bytes
         achieved = bytes_per_plant * n / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(n) if args.storage == "f64" else (None, None)
         out = {
             "metric": "plant-env-steps/s", "value": n_global * K / elapsed, "unit": "plant-env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
@@ -174,9 +256,19 @@ def main():
                        "algorithmic_bytes_per_plant_step": bytes_per_plant, "maintenance_kernel": bool(args.maintenance),
                        "state_storage": args.storage},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n) if args.storage == "f64" else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("%s: committed rocprofv3 PMC passes of an earlier run of this workload, "
+                                            "not measured by this run" % traffic_src) if traffic_src else None,
+                         "frac_of_peak_by_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "algorithmic_bytes_per_launch": bytes_per_plant * n,
-                         "kernel": "npb_step_kernel", "kernel_ms": kernel_ms},
+                         "bytes_not_moved": "the algorithmic figure counts every carried column as read + written; the kernel "
+                                            "skips the store of a column whose bits did not change for any plant of a wave "
+                                            "(measured writes 212 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "
+                                            "of the reads is served by the 256 MB Infinity Cache; NULL inputs (20 B/plant) are "
+                                            "already excluded",
+                         "kernel": "npb_step_kernel" + (" + npb_maint_kernel" if args.maintenance else ""), "kernel_ms": kernel_ms},
+            "selfcheck": {"steps": K_long, "seconds": long_elapsed, "value": n * K_long / long_elapsed, "ms_per_step": long_elapsed / K_long * 1e3,
+                          "what": "rank 0's own rate over a longer run of the same loop (inputs cycled); not the headline"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

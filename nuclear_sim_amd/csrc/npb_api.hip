@@ -33,6 +33,19 @@ static int fail(NpbHandle *h, int code, const char *what, hipError_t e = hipSucc
   if (h) h->error = msg; else g_create_error = msg;
   return code;
 }
+/* every entry point that launches makes the handle's device current for the duration of the call and puts the
+ * caller's device back afterwards: a process may hold handles on several GPUs, and a launch on whichever device
+ * happened to be current would run against another device's arena.  hipGetDevice is a thread-local read;
+ * hipSetDevice is paid only when the caller was elsewhere. */
+struct DeviceGuard {
+  int prev = -1; bool switched = false; hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) { err = hipSetDevice(device); switched = err == hipSuccess; }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define NPB_USE_DEVICE(h) DeviceGuard guard__((h)->device); if (guard__.err != hipSuccess) return fail(h, NPB_EHIP, "hipSetDevice", guard__.err)
 #define NPB_HIP(h, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(h, NPB_EHIP, #call, e__); } while (0)
 
 /* where the members of the schema live in the arena (include/npb_fields.h: carried fp64 members one per column,
@@ -106,6 +119,8 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) return fail(nullptr, NPB_EHIP, "npb_create: no HIP device", e);
   if (device < 0 || device >= ndev) return fail(nullptr, NPB_EINVAL, "npb_create: device index out of range");
+  int caller_device = -1;
+  (void)hipGetDevice(&caller_device);
   NPB_HIP(nullptr, hipSetDevice(device));
   NpbHandle *h = new NpbHandle();
   if (params) h->params = *params; else npb_params_default(&h->params);
@@ -118,12 +133,16 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   if (e != hipSuccess) {
     if (h->f64) (void)hipFree(h->f64);
     delete h;
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
     return fail(nullptr, NPB_ENOMEM, "npb_create: hipMalloc of the state arena failed", e);
   }
   (storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, n_plants, h->pitch, h->f64, nullptr, nullptr);
   e = hipDeviceSynchronize();
+  if (caller_device >= 0 && caller_device != device) (void)hipSetDevice(caller_device); /* the caller's current device is left as it was */
   if (e != hipSuccess) {
+    (void)hipSetDevice(device);
     (void)hipFree(h->f64); if (h->convert) (void)hipFree(h->convert);
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
     delete h; return fail(nullptr, NPB_EHIP, "npb_create: init kernel failed", e);
   }
   *out = h;
@@ -132,7 +151,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
 
 int npb_destroy(NpbHandle *h) {
   if (!h) return NPB_OK;
-  (void)hipSetDevice(h->device);
+  DeviceGuard guard__(h->device);
   (void)hipFree(h->f64);
   if (h->convert) (void)hipFree(h->convert);
   if (h->plan_dev) (void)hipFree(h->plan_dev);
@@ -148,7 +167,7 @@ int npb_set_params(NpbHandle *h, const npb_params_t *params) {
 
 int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream) {
   if (!h) return NPB_EINVAL;
-  NPB_HIP(h, hipSetDevice(h->device));
+  NPB_USE_DEVICE(h);
   (h->storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, h->pitch, h->f64, mask, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
   return NPB_OK;
@@ -168,7 +187,7 @@ int npb_get_field(NpbHandle *h, int kind, int slot, void *buf, int buf_is_device
   int col, sub, akind; size_t bytes;
   int rc = field_args(h, kind, slot, &col, &sub, &akind, &bytes);
   if (rc) return rc;
-  NPB_HIP(h, hipSetDevice(h->device));
+  NPB_USE_DEVICE(h);
   void *dst = buf_is_device ? buf : (void *)h->convert;
   (h->storage == NPB_STORAGE_F32 ? npb32_launch_field_get : npb_launch_field_get)(h->f64, h->pitch, col, sub, akind, dst, h->n_plants, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
@@ -184,7 +203,7 @@ int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int buf_is_
   int col, sub, akind; size_t bytes;
   int rc = field_args(h, kind, slot, &col, &sub, &akind, &bytes);
   if (rc) return rc;
-  NPB_HIP(h, hipSetDevice(h->device));
+  NPB_USE_DEVICE(h);
   const void *src = buf;
   if (!buf_is_device) {
     NPB_HIP(h, hipMemcpyAsync(h->convert, buf, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -198,7 +217,7 @@ int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int buf_is_
 
 int npb_gather_fields(NpbHandle *h, int n_fields, const int *kinds, const int *slots, double *out, void *stream) {
   if (!h || !kinds || !slots || !out || n_fields <= 0 || n_fields > NPB_TOTAL_F64 + NPB_TOTAL_I32) return NPB_EINVAL;
-  NPB_HIP(h, hipSetDevice(h->device));
+  NPB_USE_DEVICE(h);
   std::vector<int> key(2 * (size_t)n_fields);
   for (int f = 0; f < n_fields; f++) { key[2 * f] = kinds[f]; key[2 * f + 1] = slots[f]; }
   if (key != h->plan_key) { /* a log asks for the same members every time: build and upload the plan once */
@@ -238,6 +257,7 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
              const double *noise_z, const double *cooling_water_temp, double *obs, double *reward, uint8_t *done,
              uint32_t *trip_flags, double *info, void *stream) {
   if (!h) return NPB_EINVAL;
+  NPB_USE_DEVICE(h);
   const bool narrow = h->storage == NPB_STORAGE_F32;
   (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, action, magnitude, power_setpoint,
                                                  noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, (hipStream_t)stream);
@@ -250,6 +270,7 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
 int npb_debug_touch(NpbHandle *h, void *stream) {
   if (!h) return NPB_EINVAL;
   if (h->storage != NPB_STORAGE_F64) return fail(h, NPB_EINVAL, "npb_debug_touch: fp64-storage handles only");
+  NPB_USE_DEVICE(h);
   npb_launch_touch(h->pitch, (double *)h->f64, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_debug_touch: kernel launch failed", e);
@@ -258,6 +279,7 @@ int npb_debug_touch(NpbHandle *h, void *stream) {
 
 int npb_observe(NpbHandle *h, double *obs, void *stream) {
   if (!h || !obs) return NPB_EINVAL;
+  NPB_USE_DEVICE(h);
   (h->storage == NPB_STORAGE_F32 ? npb32_launch_observe : npb_launch_observe)(h->params.mode, h->n_plants, h->pitch, h->f64, obs, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_observe: kernel launch failed", e);

@@ -4,6 +4,9 @@
  * bench.py's cpu_baseline leg; never by the product path.
  */
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "npo_step.h"
 #include "npo_init.h"
 
@@ -14,6 +17,17 @@ NPO_API int npo_num_f64(void) { return NPB_TOTAL_F64; }
 NPO_API int npo_num_i32(void) { return NPB_TOTAL_I32; }
 NPO_API int npo_params_size(void) { return (int)sizeof(npb_params_t); }
 NPO_API void npo_params_default(npb_params_t *p) { npb_params_default(p); }
+
+/* worker threads of npo_step_batch (bench.py's cpu_baseline times 1 thread and all allowed cores); returns the
+ * count in effect (1 without OpenMP) */
+NPO_API int npo_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n; return 1;
+#endif
+}
 
 /* plants: n contiguous npo_plant_t records */
 NPO_API void npo_init(npo_plant_t *plants, int n, const npb_params_t *P) {

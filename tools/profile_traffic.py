@@ -70,7 +70,9 @@ def summarize(out):
         total += step * raw_unit_bytes * scale
     res["step_hbm_bytes_per_launch"] = total
     from nuclear_sim_amd.env import BatchedPlantEnv
-    res["algorithmic_bytes_per_launch"] = BatchedPlantEnv.step_bytes_per_plant() * N   # include/npb.h
+    # this workload's handle runs a ConstantHeatSource (the 12 point-kinetics columns are neither read nor written:
+    # -12 * 16 B) and passes action / magnitude / cooling-water temperature as NULL (-20 B), as bench.py does
+    res["algorithmic_bytes_per_launch"] = (BatchedPlantEnv.step_bytes_per_plant() - 12 * 16 - 20) * N
     print(json.dumps(res, indent=1))
 
 
