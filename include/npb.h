@@ -93,6 +93,13 @@ NPB_API int npb_set_params(NpbHandle *h, const npb_params_t *params);
  * Stands in for constructing a fresh simulator (the data-gen runner's episode start,
  * maintenance_scenario_runner.py:210-244). */
 NPB_API int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream);
+/* NuclearPlantSimulator.reset(start_at_steady_state)  sim.py:546-581 with the reference's own semantics: each
+ * subsystem's reset() puts part of its state back to literals, re-applies initial conditions for another part and
+ * leaves the rest (lubrication systems, metal temperatures, pH controller, tube scale, the previous step's SG
+ * conditions) as the history left it; start_at_steady_state != 0 additionally runs initialize_to_steady_state
+ * (secondary/__init__.py:1074-1357: one steam-generator update as a side effect, every pump force-set).
+ * mask as for npb_reset.  Follow with npb_observe for reset()'s return value. */
+NPB_API int npb_reset_reference(NpbHandle *h, const uint8_t *mask, int start_at_steady_state, void *stream);
 
 /* state columns: sim.state.<attr> / component attribute access.  `slot` is the global slot of
  * npb_fields.h; buf holds n_plants elements (double or int32_t) on the device or the host. */

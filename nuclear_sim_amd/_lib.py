@@ -66,6 +66,7 @@ def load():
     L.npb_num_plants.argtypes = [vp]
     L.npb_set_params.argtypes = [vp, ctypes.POINTER(NpbParams)]
     L.npb_reset.argtypes = [vp, vp, vp]
+    L.npb_reset_reference.argtypes = [vp, vp, ci, vp]
     L.npb_get_field.argtypes = [vp, ci, ci, vp, ci, vp]
     L.npb_set_field.argtypes = [vp, ci, ci, vp, ci, vp]
     L.npb_state_arena.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ci)]

@@ -173,6 +173,14 @@ int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream) {
   return NPB_OK;
 }
 
+int npb_reset_reference(NpbHandle *h, const uint8_t *mask, int start_at_steady_state, void *stream) {
+  if (!h) return NPB_EINVAL;
+  NPB_USE_DEVICE(h);
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_reset : npb_launch_reset)(&h->params, h->n_plants, h->pitch, h->f64, mask, start_at_steady_state != 0, (hipStream_t)stream);
+  NPB_HIP(h, hipGetLastError());
+  return NPB_OK;
+}
+
 /* one member of every plant <-> a contiguous buffer: a small gather / scatter kernel (members share columns and
  * outputs are stored as float, so this is never a plain copy); host buffers go through the staging column */
 static int field_args(NpbHandle *h, int kind, int slot, int *col, int *sub, int *akind, size_t *bytes) {

@@ -16,6 +16,7 @@ extern "C" {
   void prefix##maint(const npb_params_t *P, size_t npad, void *arena, hipStream_t stream); \
   void prefix##observe(int mode, int n_plants, size_t npad, const void *arena, double *obs, hipStream_t stream); \
   void prefix##init(const npb_params_t *P, int n_plants, size_t npad, void *arena, const uint8_t *mask, hipStream_t stream); \
+  void prefix##reset(const npb_params_t *P, int n_plants, size_t npad, void *arena, const uint8_t *mask, int steady, hipStream_t stream); \
   /* kind: 0 carried real, 1 output real (float), 2 int32; buffers: double for reals, int32 for ints */ \
   void prefix##field_get(const void *arena, size_t npad, int col, int sub, int kind, void *out, int n, hipStream_t stream); \
   void prefix##field_set(void *arena, size_t npad, int col, int sub, int kind, const void *in, int n, hipStream_t stream); \

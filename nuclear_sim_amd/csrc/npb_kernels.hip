@@ -48,6 +48,7 @@ extern "C" __attribute__((visibility("default"))) int npb_debug_set_stamp_buffer
 #include "npd_ph.h"
 #include "npd_maintenance.h"
 #include "npd_init.h"
+#include "npd_reset.h"
 #include "npb_kernels.h"
 
 #define NPB_OBS_PAD 23 /* LDS row stride in doubles: 22 + 1 keeps the transpose at <= 2-way bank conflicts */
@@ -723,6 +724,49 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size
   (void)P;
 }
 
+/* NuclearPlantSimulator.reset(start_at_steady_state)  sim.py:546-581 for every plant selected by mask (NULL = all):
+ * the reference's own reset semantics (npd_reset.h), which keep part of the plant's history -- unlike
+ * npb_init_kernel, which stands in for constructing a new simulator.  The maint.* section is left alone (the
+ * maintenance system is not reset; only the state manager's log is cleared, sim.py:573-574). */
+__global__ __launch_bounds__(NPB_WAVE) void npb_reset_kernel(npb_params_t P, size_t N, npd_real_t *__restrict__ f64,
+                                                             const uint8_t *__restrict__ mask, int n_plants, int steady) {
+  const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
+  if (mask && (p >= (size_t)n_plants || !mask[p])) return;
+  { npb_prim_t s; NPD_LOAD(PRIM, npb_prim_t, s, 0); npd_prim_reset(&s); NPD_STORE(PRIM, npb_prim_t, s, 0); }
+  npb_sec_t sec;
+  NPD_LOAD(SEC, npb_sec_t, sec, 0);
+  npd_sec_reset(&sec);
+  npb_sg_t sg[NPB_NUM_SG];
+  for (int i = 0; i < NPB_NUM_SG; i++) { NPD_LOAD(SG, npb_sg_t, sg[i], i); npd_sg_reset(&sg[i]); }
+  npd_equilibrium_t eq;
+  if (steady) {
+    /* sim.py:558-563: primary_physics.thermal_power_mw was zeroed by reset_system, so the rated power is used */
+    npd_steady_state_equilibrium(sg, &sec, &P, P.rated_power_mw, &eq);
+    npd_sec_steady_state(&sec, &eq);
+  }
+  for (int i = 0; i < NPB_NUM_SG; i++) NPD_STORE(SG, npb_sg_t, sg[i], i);
+  NPD_STORE(SEC, npb_sec_t, sec, 0);
+#pragma unroll 1
+  for (int i = 0; i < NPB_NUM_PUMPS; i++) {
+    npb_pump_t pm;
+    NPD_LOAD(PUMP, npb_pump_t, pm, i);
+    npd_pump_reset(&pm, i);
+    if (steady) npd_pump_steady_state(&pm, i, eq.steam_pressure, eq.feedwater_flow, eq.pumps_needed, eq.pump_speed);
+    NPD_STORE(PUMP, npb_pump_t, pm, i);
+  }
+  { npb_fw_t fw; npd_fw_reset(&fw); NPD_STORE(FW, npb_fw_t, fw, 0); }
+  {
+    npb_turb_t t; npb_tstg_t g;
+    NPD_LOAD(TURB, npb_turb_t, t, 0); NPD_LOAD(TSTG, npb_tstg_t, g, 0);
+    npd_turb_reset(&t, &g, steady, steady ? eq.load_demand : 0.0, steady ? eq.electrical_power : 0.0);
+    NPD_STORE(TURB, npb_turb_t, t, 0); NPD_STORE(TSTG, npb_tstg_t, g, 0);
+  }
+#pragma unroll 1
+  for (int i = 0; i < 2; i++) { npb_chem_t ch; npd_chem_reset(&ch); NPD_STORE(CHEM, npb_chem_t, ch, i); }
+  { npb_cond_t cd; NPD_LOAD(COND, npb_cond_t, cd, 0); npd_cond_reset(&cd); NPD_STORE(COND, npb_cond_t, cd, 0); }
+  /* the pH controller and its pending doses are not reset (secondary/__init__.py:1041-1072 never touches them) */
+}
+
 /* automatic maintenance after a step (params.maint_enabled): AutoMaintenanceSystem.update then the
  * state manager's threshold scan (npd_maintenance.h).  HBM-bound and small: per plant it reads
  * sim_time, the maint section and four oil levels (184 B); it writes only what changed -- the
@@ -827,6 +871,10 @@ extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, size_t npad, void *ar
 extern "C" void NPB_LAUNCHER(observe)(int mode, int n_plants, size_t npad, const void *arena, double *obs, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
   hipLaunchKernelGGL(npb_observe_kernel, grid, block, 0, stream, mode, n_plants, npad, (const npd_real_t *)arena, obs);
+}
+extern "C" void NPB_LAUNCHER(reset)(const npb_params_t *P, int n_plants, size_t npad, void *arena, const uint8_t *mask, int steady, hipStream_t stream) {
+  dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
+  hipLaunchKernelGGL(npb_reset_kernel, grid, block, 0, stream, *P, npad, (npd_real_t *)arena, mask, n_plants, steady);
 }
 extern "C" void NPB_LAUNCHER(init)(const npb_params_t *P, int n_plants, size_t npad, void *arena, const uint8_t *mask, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);

@@ -250,10 +250,18 @@ class BatchedPlantEnv:
         return int(self.L.npb_handle_step_bytes_per_plant(self._h))
 
     # ------------------------------------------------------------------ reference API
-    def reset(self, mask=None) -> torch.Tensor:
-        """Back to the construction-time state (episode start of the data-gen runner)."""
+    def reset(self, mask=None, reference: bool = False, start_at_steady_state: bool = True) -> torch.Tensor:
+        """``reference=False``: back to the construction-time state, i.e. a freshly constructed simulator (the
+        episode start of the data-gen runner, which never calls reset()).  ``reference=True``:
+        NuclearPlantSimulator.reset(start_at_steady_state) with the reference's own semantics (sim.py:546-581): part of
+        the state goes back to literals, part keeps its history, and with ``start_at_steady_state`` the secondary side
+        is force-set to the reference's "steady state" (include/npb.h, npb_reset_reference).  Initial conditions set
+        through ``set_fields`` are the caller's to re-apply.  Returns the observation, as the reference does."""
         m = self._col(mask, torch.uint8)
-        _lib.check(self.L.npb_reset(self._h, self._p(m), self._stream()), self._h)
+        if reference:
+            _lib.check(self.L.npb_reset_reference(self._h, self._p(m), int(bool(start_at_steady_state)), self._stream()), self._h)
+        else:
+            _lib.check(self.L.npb_reset(self._h, self._p(m), self._stream()), self._h)
         return self.get_observation()
 
     def get_observation(self) -> torch.Tensor:
@@ -375,8 +383,7 @@ class NuclearPlantSimulator:
     Differences, all explicit: ``enable_state_management=True`` turns on what the path needs of it (the automatic
     oil_top_off maintenance rule), not the pandas state log; ``secondary_config`` is honoured for the
     initial-condition keys nuclear_sim_amd.scenarios can map (others are listed in ``ignored_initial_conditions``);
-    ``reset()`` returns to the construction-time state (the data-gen runner's episode start), not to the
-    reference's partial reset."""
+    ``reset()`` follows the reference's own reset (default configuration; pinned by tests/golden/r1_*.npz)."""
 
     def __init__(self, dt: float = 1.0, heat_source=None, enable_secondary: bool = True,
                  enable_state_management: bool = False, max_state_rows: int = 100000, secondary_config=None,
@@ -420,6 +427,7 @@ class NuclearPlantSimulator:
         fw_ic = dict(sec.get("feedwater", {}).get("initial_conditions", {}) or {})
         known = set(scenarios.FEEDWATER_IC_DEFAULTS)
         self.ignored_initial_conditions += ["feedwater." + k for k in fw_ic if k not in known]
+        self._feedwater_ic = {k: v for k, v in fw_ic.items() if k in known}
         if fw_ic:
             eff = float(self._env.get_field("pump.lubrication_effectiveness")[0].item())
             fields.update(scenarios.feedwater_fields({k: v for k, v in fw_ic.items() if k in known}, 1, eff))
@@ -486,7 +494,21 @@ class NuclearPlantSimulator:
         return {k: float(v) for (k, _), v in zip(self._sec_keys, vals)}
 
     def reset(self, start_at_steady_state: bool = True):
-        return self._env.reset()[0].cpu().numpy().copy()
+        """sim.py:546-581: the reference's reset (not a re-construction); the configured feedwater initial conditions
+        are re-applied as EnhancedFeedwaterPhysics.reset does (feedwater/physics.py:1286-1323)."""
+        env = self._env
+        obs = env.reset(reference=True, start_at_steady_state=start_at_steady_state)
+        if getattr(self, "_feedwater_ic", None):
+            from . import scenarios
+            eff = torch.stack([env.get_field("pump.lubrication_effectiveness", instance=k) for k in range(scenarios.NUM_PUMPS)], dim=1).cpu().numpy()
+            env.set_fields(scenarios.feedwater_reset_fields(self._feedwater_ic, 1, eff, start_at_steady_state))
+            obs = env.get_observation()
+        self.primary_physics.heat_source._pending = None
+        if hasattr(self.primary_physics.heat_source, "power_setpoint_percent"):
+            self.primary_physics.heat_source.power_setpoint_percent = 100.0
+        self.load_demand = 100.0
+        self.cooling_water_temp = 25.0
+        return obs[0].cpu().numpy().copy()
 
     def get_observation(self) -> np.ndarray:
         return self._env.get_observation()[0].cpu().numpy().copy()

@@ -173,6 +173,22 @@ def feedwater_fields(ic: Dict[str, object], n: int, lubrication_effectiveness: f
     return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in f.items()}
 
 
+def feedwater_reset_fields(ic: Dict[str, object], n: int, lubrication_effectiveness, start_at_steady_state: bool) -> Dict[object, np.ndarray]:
+    """The columns EnhancedFeedwaterPhysics.reset (feedwater/physics.py:1286-1323) puts back when it re-applies the
+    configured initial conditions after NuclearPlantSimulator.reset(): ``feedwater_fields`` evaluated with the
+    lubrication effectiveness the history left (the lubrication system is never reset; array [n, 4] or scalar),
+    minus what the reset decides itself -- the system flow is the sum of the 555 kg/s the reset has just written, and
+    with ``start_at_steady_state`` the pump hydraulics, speeds, demands, cavitation state and motor temperatures are
+    force-set afterwards by _initialize_feedwater_system_to_steady_state (secondary/__init__.py:1247-1357)."""
+    f = feedwater_fields(ic, n, lubrication_effectiveness)
+    f.pop("fw.total_flow_rate", None)
+    if start_at_steady_state:
+        forced = ("pump.speed_percent", "pump.speed_setpoint", "pump.flow_demand", "pump.cavitation_damage", "pump.motor_temperature",
+                  "pump.suction_pressure", "pump.discharge_pressure", "pump.npsh_available", "pump.cavitation_intensity")
+        f = {k: v for k, v in f.items() if not (isinstance(k, tuple) and k[0] in forced)}
+    return f
+
+
 def catalog_conditions(action: str) -> Dict[str, object]:
     """FEEDWATER_CONDITIONS[action] (numbers and lists only)  initial_conditions/feedwater_conditions.py"""
     if action not in _CATALOG["conditions"]:

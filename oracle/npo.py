@@ -34,6 +34,7 @@ def lib():
         L.npo_get_all.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.npo_step_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 10
         L.npo_observe_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.npo_reset_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         _LIB = L
     return _LIB
 
@@ -143,6 +144,12 @@ class OraclePlants:
             self.L.npo_set_f64(_ptr(self._buf), plant, s, float(v))
         for s, v in enumerate(i32):
             self.L.npo_set_i32(_ptr(self._buf), plant, s, int(v))
+
+    def reset(self, start_at_steady_state=True, mask=None):
+        """NuclearPlantSimulator.reset(start_at_steady_state) (the reference's semantics, npo_reset.h); returns obs"""
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self.L.npo_reset_batch(_ptr(self._buf), self.n, self.params.ptr, _ptr(m), int(bool(start_at_steady_state)))
+        return self.observe()
 
     def observe(self):
         obs = np.zeros((self.n, 22))

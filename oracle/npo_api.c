@@ -9,6 +9,7 @@
 #endif
 #include "npo_step.h"
 #include "npo_init.h"
+#include "npo_reset.h"
 
 #define NPO_API __attribute__((visibility("default")))
 
@@ -51,6 +52,30 @@ NPO_API void npo_round_state_f32(npo_plant_t *plants, int n, const uint8_t *keep
       if (keep_f64 && keep_f64[s]) continue;   /* columns the mode keeps in fp64 (slow integrators) */
       double *v = npo_f64_slot(&plants[i], s); *v = (double)(float)*v;
     }
+}
+
+/* NuclearPlantSimulator.reset(start_at_steady_state) for n plants (npo_reset.h); mask NULL = all */
+NPO_API void npo_reset_batch(npo_plant_t *plants, int n, const npb_params_t *P, const uint8_t *mask, int steady) {
+  for (int i = 0; i < n; i++) {
+    if (mask && !mask[i]) continue;
+    npo_plant_t *pl = &plants[i];
+    npo_prim_reset(&pl->prim);
+    npo_sec_reset(&pl->sec);
+    for (int k = 0; k < NPB_NUM_SG; k++) npo_sg_reset(&pl->sg[k]);
+    npo_equilibrium_t eq;
+    if (steady) {
+      npo_steady_state_equilibrium(pl->sg, &pl->sec, P, P->rated_power_mw, &eq);
+      npo_sec_steady_state(&pl->sec, &eq);
+    }
+    for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+      npo_pump_reset(&pl->pump[k], k);
+      if (steady) npo_pump_steady_state(&pl->pump[k], k, eq.steam_pressure, eq.feedwater_flow, eq.pumps_needed, eq.pump_speed);
+    }
+    npo_fw_reset(&pl->fw);
+    npo_turb_reset(&pl->turb, &pl->tstg, steady, steady ? eq.load_demand : 0.0, steady ? eq.electrical_power : 0.0);
+    for (int k = 0; k < 2; k++) npo_chem_reset(&pl->chem[k]);
+    npo_cond_reset(&pl->cond);
+  }
 }
 
 /* One step for n plants. Per-plant input columns may be NULL (defaults: NO_ACTION,

@@ -83,6 +83,19 @@ def scenarios():
                                       ("m7_vacuum_leak_detection", "vacuum_leak_detection", None, 60)):
         S.append(dict(name=name, steps=steps, dt=5.0, noise=True, noise_seed=42, every=3, maint_unchecked=True,
                       runner=dict(action=action, duration_hours=5.0, randomization_seed=seed)))
+    # R1-R3: NuclearPlantSimulator.reset() (sim.py:546-581) in the middle of a run -- the reference's reset is not a
+    # re-construction (parts of the history survive, start_at_steady_state force-sets the secondary side and advances the
+    # steam generators once), so the state it leaves and the trajectory after it are pinned here
+    S.append(dict(name="r1_reset_steady", steps=90, noise=True, noise_seed=42, every=3, resets={30: True}))
+    S.append(dict(name="r2_reset_cold_then_steady", steps=110, noise=True, noise_seed=5, every=3, resets={30: False, 70: True},
+                  setpoints=lambda t: 100.0 - 0.25 * t if t < 30 else None))
+    S.append(dict(name="r3_reset_reactor", steps=100, heat_source="reactor", equilibrium=(100.0, 95.0), every=3, resets={40: True},
+                  actions=lambda t: (int(acts[t]), float(mags[t]))))
+    # R4: the same with configured feedwater initial conditions, which EnhancedFeedwaterPhysics.reset re-applies
+    S.append(dict(name="r4_reset_feedwater_ic", steps=80, noise=True, noise_seed=42, every=2, resets={25: True},
+                  secondary={"feedwater": {"initial_conditions": {"pump_oil_levels": [59.4, 62.0, 64.0, 90.0], "pump_oil_contamination": 8.0,
+                                                                   "seal_face_wear": [12.0, 0.1, 0.1, 0.1], "motor_bearing_wear": [1.0, 0.1, 0.1, 0.0],
+                                                                   "motor_temperature": [71.0, 72.0, 73.0, 74.0]}}}))
     return S
 
 
@@ -98,8 +111,10 @@ def main(only=None):
         ref, _sim = trace.run_reference(sc, cols)
         T = sc["steps"]
         every = sc.get("every", 1)
-        steps = sorted(set(list(range(0, T + 1, every)) + [T] + [t + 1 for t in sc.get("pokes", {})] + list(sc.get("pokes", {}).keys())))
-        meta = {k: v for k, v in sc.items() if not callable(v) and k not in ("pokes",)}
+        steps = sorted(set(list(range(0, T + 1, every)) + [T] + [t + 1 for t in sc.get("pokes", {})] + list(sc.get("pokes", {}).keys())
+                           + [t for t in sc.get("resets", {})] + [t + 1 for t in sc.get("resets", {})]))
+        meta = {k: v for k, v in sc.items() if not callable(v) and k not in ("pokes", "resets")}
+        meta["resets"] = {str(k): bool(v) for k, v in sc.get("resets", {}).items()}
         meta["pokes"] = {str(k): [[p, float(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
         # pokes expressed in schema labels so tests can replay them without the reference
         path_to_label = {c[3]: (c[0], c[1], c[2]) for c in cols}
@@ -108,6 +123,8 @@ def main(only=None):
                             action=ref["action"], magnitude=ref["magnitude"], setpoint=ref["setpoint"],
                             cooling=ref["cooling"], noise_z=ref["noise_z"], obs=ref["obs"], reward=ref["reward"],
                             done=ref["done"], info=ref["info"], state_steps=np.array(steps),
+                            reset_steps=ref["reset_steps"], reset_modes=ref["reset_modes"], reset_obs=ref["reset_obs"],
+                            reset_state=ref["reset_state"],
                             state=ref["state"][steps], labels=labels, kinds=kinds, paths=paths, meta=json.dumps(meta))
         print(sc["name"], "steps", T, "dones", int(ref["done"].sum()), "elec", float(ref["obs"][-1, 12] * 1100))
 

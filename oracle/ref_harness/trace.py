@@ -10,6 +10,8 @@ Scenario dict keys:
   setpoints: callable(step)->percent or None,
   cooling: callable(step)->degC or None,
   pokes: {step: [(python_path, value), ...]} applied to the sim before that step.
+  resets: {step: start_at_steady_state} -> sim.reset(start_at_steady_state) is called before that step (after the
+          step's pokes); the observation it returns and the state it leaves are recorded (reset_obs / reset_state).
   runner: {"action": name, "duration_hours": h, "feedwater_ic": {...}} -> build the simulator the
           way data_gen's MaintenanceScenarioRunner does (state management + AutoMaintenanceSystem
           on, ComprehensiveComposer action-test config, maintenance_scenario_runner.py:210-244)
@@ -72,9 +74,16 @@ def run_reference(sc, columns):
     if sc.get("noise", False):
         z[:] = np.random.RandomState(sc.get("noise_seed", 42)).standard_normal(T)
     actions = sc.get("actions")
+    resets = sc.get("resets", {})
+    reset_steps, reset_modes, reset_obs, reset_state = [], [], [], []
     for t in range(T):
         for path, v in sc.get("pokes", {}).get(t, []):
             exec("sim.%s = v" % path, {"sim": sim, "v": v})
+        if t in resets:
+            with refsim.quiet():
+                ob = sim.reset(start_at_steady_state=bool(resets[t]))
+            reset_steps.append(t); reset_modes.append(int(bool(resets[t]))); reset_obs.append(np.asarray(ob, dtype=np.float64))
+            reset_state.append([_val(sim, p) for p in paths])
         if actions is not None:
             a = actions(t) if callable(actions) else actions.get(t)
             if a is not None:
@@ -104,4 +113,7 @@ def run_reference(sc, columns):
                    i["secondary_system"]["feedwater_total_flow"] if "secondary_system" in i else np.nan]
         state[t + 1] = [_val(sim, p) for p in paths]
     return dict(state=state, obs=obs, reward=rew, done=done, info=info,
-                action=act, magnitude=mag, setpoint=sp, cooling=cw, noise_z=z), sim
+                action=act, magnitude=mag, setpoint=sp, cooling=cw, noise_z=z,
+                reset_steps=np.array(reset_steps, dtype=np.int64), reset_modes=np.array(reset_modes, dtype=np.int64),
+                reset_obs=np.array(reset_obs, dtype=np.float64).reshape(len(reset_steps), 22),
+                reset_state=np.array(reset_state, dtype=np.float64).reshape(len(reset_steps), len(paths))), sim

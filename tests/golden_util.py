@@ -43,6 +43,15 @@ class Golden:
                 st[:, j] = raw[:, idx[c[3]]]
         self.state = st
         self.cols = cols
+        # NuclearPlantSimulator.reset() calls recorded in the run: {step: (start_at_steady_state, obs, state row)}
+        self.resets = {}
+        if "reset_steps" in z.files:
+            for k, t in enumerate(z["reset_steps"]):
+                rs = np.full(len(cols), np.nan)
+                for j, c in enumerate(cols):
+                    if c[3] in idx:
+                        rs[j] = z["reset_state"][k, idx[c[3]]]
+                self.resets[int(t)] = (bool(z["reset_modes"][k]), z["reset_obs"][k], rs)
         self.pokes = {int(k): v for k, v in self.meta.get("pokes_schema", {}).items()}
 
     def split_state(self, row):

@@ -66,6 +66,19 @@ def test_hip_replays_golden(name):
             from nuclear_sim_amd import _lib
             import ctypes
             _lib.check(env.L.npb_set_field(env._h, 0 if kind == "f64" else 1, slot, ctypes.c_void_p(col.data_ptr()), 1, env._stream()), env._h)
+        if t in g.resets:    # NuclearPlantSimulator.reset(start_at_steady_state) in mid-run (sim.py:546-581)
+            steady, ref_obs, ref_state = g.resets[t]
+            env.reset(reference=True, start_at_steady_state=steady)
+            ic = ((g.meta.get("secondary") or {}).get("feedwater") or {}).get("initial_conditions")
+            if ic:   # EnhancedFeedwaterPhysics.reset re-applies the configured initial conditions (physics.py:1286-1323)
+                from nuclear_sim_amd import scenarios
+                eff = torch.stack([env.get_field("pump.lubrication_effectiveness", instance=k) for k in range(4)], dim=1).cpu().numpy()
+                env.set_fields(scenarios.feedwater_reset_fields(ic, n, eff, steady))
+            robs = env.get_observation().cpu().numpy()
+            fs, is_ = _host_state(env)
+            for lane in (0, n - 1):
+                np.testing.assert_allclose(robs[lane], ref_obs, rtol=RTOL, atol=1e-12, err_msg="%s reset obs before step %d" % (name, t))
+                compare_state(g, fs[:, lane], is_[:, lane], ref_state, "after reset before step %d (lane %d)" % (t, lane))
         sp = None if np.isnan(g.setpoint[t]) else g.setpoint[t]
         cw = None if np.isnan(g.cooling[t]) else g.cooling[t]
         obs, rew, done, info = env.step(action=int(g.action[t]), magnitude=float(g.magnitude[t]), power_setpoint=sp,
@@ -292,6 +305,27 @@ def test_single_plant_facade_runs_the_data_gen_loop():
     lab = [c[2] for c in g.cols]
     assert events == int(g.state[-1, lab.index("maint.maintenance_actions_performed")]) == 3
     assert abs(sim.state.power_level - g.state[-1, lab.index("prim.power_level")]) <= RTOL * 100
+
+
+@pytest.mark.parametrize("name", ["r1_reset_steady", "r4_reset_feedwater_ic"])
+def test_facade_reset_follows_the_reference(name):
+    """Drop-in check of reset(): an RL loop that calls NuclearPlantSimulator.reset() in mid-run (sim.py:546-581) gets the
+    reference's observation back and the reference's trajectory afterwards -- default configuration (r1) and
+    configured feedwater initial conditions, which the reference's reset re-applies (r4)."""
+    from nuclear_sim_amd.env import NuclearPlantSimulator, ConstantHeatSource, ControlAction
+    g = Golden(name)
+    hs = ConstantHeatSource(rated_power_mw=3000.0, noise_enabled=True, noise_std_percent=0.1, noise_seed=g.meta["noise_seed"])
+    cfg = {"secondary_system": g.meta["secondary"]} if g.meta.get("secondary") else None
+    sim = NuclearPlantSimulator(heat_source=hs, dt=1.0, secondary_config=cfg)
+    assert not sim.ignored_initial_conditions
+    for t in range(g.T):
+        if t in g.resets:
+            steady, ref_obs, _ = g.resets[t]
+            np.testing.assert_allclose(sim.reset(start_at_steady_state=steady), ref_obs, rtol=RTOL, atol=1e-12, err_msg="reset obs")
+        r = sim.step(action=ControlAction.NO_ACTION)
+        np.testing.assert_allclose(r["observation"], g.obs[t], rtol=RTOL, atol=1e-12, err_msg="%s obs step %d" % (name, t))
+        np.testing.assert_allclose(r["reward"], g.reward[t], rtol=RTOL, atol=1e-9)
+        assert r["done"] == bool(g.done[t])
 
 
 def test_lane_independence_and_determinism():
