@@ -19,12 +19,13 @@
 #include <stdint.h>
 #include "npb_fields.h"
 #include "npb_params.h"
+#include "npb_maint.h"
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define NPB_VERSION 110 /* 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
+#define NPB_VERSION 120 /* 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
 #ifndef NPB_API
 #define NPB_API __attribute__((visibility("default")))
 #endif
@@ -88,6 +89,11 @@ NPB_API int npb_destroy(NpbHandle *h);
 NPB_API const char *npb_last_error(const NpbHandle *h); /* h may be NULL: last create error */
 NPB_API int npb_num_plants(const NpbHandle *h);
 NPB_API int npb_set_params(NpbHandle *h, const npb_params_t *params);
+/* thresholds of the automatic maintenance of the feedwater pumps (include/npb_maint.h): what the reference reads from
+ * the maintenance_system section of its configuration into StateManager.maintenance_thresholds.  A new handle carries
+ * npb_maint_table_default() (the data-gen action-test configuration). */
+NPB_API int npb_set_maintenance_table(NpbHandle *h, const npb_maint_table_t *table);
+NPB_API void npb_default_maintenance_table(npb_maint_table_t *table);
 
 /* re-initialise plants to the construction-time state; mask (device, uint8[n], NULL = all) selects plants.
  * Stands in for constructing a fresh simulator (the data-gen runner's episode start,

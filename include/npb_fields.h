@@ -321,22 +321,34 @@
   I(has_previous_sg_conditions, "") \
   I(sg_system_availability,   "secondary_physics.steam_generator_system.system_availability")
 
-/* ---- automatic maintenance, oil_top_off action: the emergent rule of
- * AutoMaintenanceSystem.update + StateManager threshold checks for the feedwater pumps' oil_level
- * threshold.  Carried only when params.maint_enabled; the step kernel never touches these columns.
- * reference: systems/maintenance/auto_maintenance.py:200-236 (check cadence), :392-456 (work-order
- *            creation, duplicate/cooldown rules), :468-488,:504-580 (execution),
- *            simulator/state/state_manager.py:1267-1369 (threshold cooldown + violation scan).
- * "=H.*" paths are evaluated by oracle/ref_harness/leaves.py helpers (dict lookups with defaults).
- * wo_order[k]: 0 = pump k has no open work order, n = its open order was the n-th created
- * (WorkOrderManager.work_orders is insertion ordered and executed in that order). */
+/* ---- automatic maintenance of the feedwater pumps: what a run observes of the reference's control
+ * plane -- StateManager threshold scan with per-threshold cooldowns (simulator/state/state_manager.py:1267-1369), the
+ * orchestrator's choice of one action per pump and step (systems/maintenance/maintenance_orchestrator.py:81-524),
+ * AutoMaintenanceSystem's work-order creation with its duplicate rules (systems/maintenance/auto_maintenance.py:331-456)
+ * and the one-execution-per-check queue (:200-236, :468-580) -- restated in nuclear_sim_amd/csrc/npd_maintenance.h.
+ * Carried only when params.maint_enabled; the step kernel never touches these columns.
+ * mpump (one per pump): array index = catalogued parameter / action of include/npb_maint.h.
+ *   last_violation_time[p]  StateManager.threshold_last_violation_times[pump][parameter]; -1 = never
+ *   wo_order[a]             0 = the pump has no open work order for action a, n = its open order was the n-th created
+ *                           (WorkOrderManager.work_orders is insertion ordered and executed in that order)
+ *   wo_planned_start[a]     planned_start_date of that order (minutes)
+ *   last_trigger_time[a]    AutoMaintenanceSystem.recent_work_order_triggers[pump:action]; -1 = never
+ *   wo_bearing              which bearing the open bearing_replacement order names (work_order.metadata), NPB_BEARING_*
+ * "=H.*" paths are evaluated by oracle/ref_harness/leaves.py helpers (dict lookups with defaults). */
+#define NPB_MPUMP_NOUT 0
+#define NPB_MPUMP_FIELDS(F, A, I) \
+  A(last_violation_time, 16,  "=H.last_violation(root, {i}, {k})") \
+  A(wo_order, 18,             "=H.open_wo(root, {i}, {k}, 'order')") \
+  A(wo_planned_start, 18,     "=H.open_wo(root, {i}, {k}, 'planned_start_date')") \
+  A(last_trigger_time, 18,    "=H.last_trigger(root, {i}, {k})") \
+  F(wo_bearing,               "=H.open_wo_bearing(root, {i})")
+
+/* maint (one per plant): check cadence and counters; executed[a] = work orders of action a carried out so far, on any
+ * pump (the reference keeps them as COMPLETED work orders) */
 #define NPB_MAINT_NOUT 0
 #define NPB_MAINT_FIELDS(F, A, I) \
   F(last_check_time,          "maintenance_system.last_check_time") \
-  A(wo_order, 4,              "=H.open_wo(root, {k}, 'order')") \
-  A(wo_planned_start, 4,      "=H.open_wo(root, {k}, 'planned_start_date')") \
-  A(last_violation_time, 4,   "=H.last_violation(root, {k})") \
-  A(last_trigger_time, 4,     "=H.last_trigger(root, {k})") \
+  A(executed, 18,             "=H.executed(root, {k})") \
   I(work_orders_created,      "maintenance_system.work_orders_created") \
   I(maintenance_actions_performed, "maintenance_system.maintenance_actions_performed")
 
@@ -352,6 +364,7 @@
   S(ph,   PH,   npb_ph_t,   1) \
   S(cond, COND, npb_cond_t, 1) \
   S(sec,  SEC,  npb_sec_t,  1) \
+  S(mpump, MPUMP, npb_mpump_t, NPB_NUM_PUMPS) \
   S(maint, MAINT, npb_maint_t, 1)
 
 /* ------------------------------------------------------------------ structs */

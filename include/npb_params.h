@@ -42,14 +42,19 @@
   P(sgchem_silica,                20.0,     "secondary_physics.steam_generator_system.water_chemistry.silica_concentration") \
   P(sgchem_ph,                    9.2,      "secondary_physics.steam_generator_system.water_chemistry.ph") \
   P(sgchem_dissolved_oxygen,      0.005,    "secondary_physics.steam_generator_system.water_chemistry.dissolved_oxygen") \
-  /* ---- automatic maintenance, oil_top_off (used only when maint_enabled; values of the data-gen \
-   *      action-test scenario: auto_maintenance.py:121-160 aggressive mode, feedwater thresholds YAML) */ \
+  /* ---- automatic maintenance of the feedwater pumps (used only when maint_enabled; values of the data-gen \
+   *      action-test scenario: auto_maintenance.py:121-160,187-198 aggressive mode = no start delays).  The threshold \
+   *      table is separate (include/npb_maint.h, npb_set_maintenance_table); the two oil_level entries here \
+   *      override the table's oil_level row (kept from ABI version 1) */ \
   P(maint_check_interval_hours,   0.25,     "maintenance_system.check_interval_hours") \
   P(maint_oil_level_threshold,    58.0,     "state_manager.maintenance_thresholds['FWP-1']['oil_level']['threshold']") \
   P(maint_oil_level_cooldown_hours, 168.0,  "state_manager.maintenance_thresholds['FWP-1']['oil_level']['cooldown_hours']") \
   P(maint_work_order_cooldown,    24.0,     "maintenance_system.work_order_cooldown_hours") \
   P(maint_start_delay_hours,      0.0,      "maintenance_system.high_priority_delay_hours") \
-  P(maint_top_off_target,         95.0,     "")
+  P(maint_top_off_target,         95.0,     "") \
+  P(maint_medium_delay_hours,     0.0,      "maintenance_system.medium_priority_delay_hours") \
+  P(maint_low_delay_hours,        0.0,      "maintenance_system.low_priority_delay_hours") \
+  P(maint_emergency_delay_hours,  0.0,      "maintenance_system.emergency_delay_hours")
 
 typedef struct npb_params_t {
 #define NPB__P(name, dflt, path) double name;

@@ -33,6 +33,55 @@ def _make_params_struct():
 
 NpbParams = _make_params_struct()
 
+MAINT_NPARAM, MAINT_NACT = 16, 18
+
+
+class NpbMaintTable(ctypes.Structure):
+    """npb_maint_table_t (include/npb_maint.h): one row per catalogued threshold parameter"""
+    _fields_ = [("threshold", ctypes.c_double * MAINT_NPARAM), ("cooldown_hours", ctypes.c_double * MAINT_NPARAM),
+                ("rank", ctypes.c_int * MAINT_NPARAM), ("comparison", ctypes.c_int * MAINT_NPARAM),
+                ("action", ctypes.c_int * MAINT_NPARAM), ("priority", ctypes.c_int * MAINT_NPARAM),
+                ("bearing", ctypes.c_int * MAINT_NPARAM)]
+
+
+def _maint_catalog():
+    import re
+    text = open(os.path.join(os.path.dirname(_HERE), "include", "npb_maint.h")).read()
+    params = re.findall(r'^\s*X\(\w+,\s*"(\w+)"\)', text, flags=re.M)
+    actions = re.findall(r'^\s*X\(\w+,\s*"(\w+)",\s*[01]\)', text, flags=re.M)
+    assert len(params) == MAINT_NPARAM and len(actions) == MAINT_NACT
+    return params, actions
+
+
+MAINT_PARAMS, MAINT_ACTIONS = _maint_catalog()
+MAINT_COMPARISONS = ("greater_than", "less_than", "greater_equal", "less_equal", "equals", "not_equals")
+MAINT_PRIORITIES = {"LOW": 1, "MEDIUM": 2, "HIGH": 3, "CRITICAL": 4, "EMERGENCY": 5}
+MAINT_BEARINGS = {None: 0, "all": 0, "motor_bearings": 1, "pump_bearings": 2, "thrust_bearing": 3}
+
+
+def maint_table_from_thresholds(thresholds: dict) -> "NpbMaintTable":
+    """The reference's thresholds dict of a feedwater pump (maintenance_system.component_configs.feedwater.thresholds of
+    the configuration, = StateManager.maintenance_thresholds['FWP-1'], in ITS order) -> table.  Names that do not
+    resolve in a pump's state log are dropped, as the reference's scan drops them (state_manager.py:1371-1411)."""
+    t = NpbMaintTable()
+    for k in range(MAINT_NPARAM):
+        t.rank[k] = -1
+    for rank, (name, cfg) in enumerate(thresholds.items()):
+        if name not in MAINT_PARAMS or cfg.get("threshold") is None:
+            continue
+        k = MAINT_PARAMS.index(name)
+        action = cfg.get("action")
+        if action not in MAINT_ACTIONS:
+            raise NpbError("maintenance action %r of threshold %r is not in the action catalog (include/npb_maint.h)" % (action, name))
+        t.rank[k] = rank
+        t.threshold[k] = float(cfg["threshold"])
+        t.cooldown_hours[k] = float(cfg.get("cooldown_hours", 24.0))
+        t.comparison[k] = MAINT_COMPARISONS.index(cfg.get("comparison", "greater_than"))
+        t.action[k] = MAINT_ACTIONS.index(action)
+        t.priority[k] = MAINT_PRIORITIES.get(str(cfg.get("priority", "MEDIUM")).upper(), 2)
+        t.bearing[k] = MAINT_BEARINGS.get(cfg.get("component_id"), 0)
+    return t
+
 _lib = None
 
 
@@ -66,6 +115,8 @@ def load():
     L.npb_num_plants.argtypes = [vp]
     L.npb_set_params.argtypes = [vp, ctypes.POINTER(NpbParams)]
     L.npb_reset.argtypes = [vp, vp, vp]
+    L.npb_set_maintenance_table.argtypes = [vp, ctypes.POINTER(NpbMaintTable)]
+    L.npb_default_maintenance_table.argtypes = [ctypes.POINTER(NpbMaintTable)]
     L.npb_reset_reference.argtypes = [vp, vp, ci, vp]
     L.npb_get_field.argtypes = [vp, ci, ci, vp, ci, vp]
     L.npb_set_field.argtypes = [vp, ci, ci, vp, ci, vp]

@@ -20,6 +20,7 @@ struct NpbHandle {
   size_t real_bytes;   /* 8 | 4 */
   void *f64;           /* the arena: [NPB_TOTAL_COL64][pitch] 8-byte columns, or [NPB_TOTAL_COL32][pitch] 4-byte ones */
   double *convert;     /* one staging column (pitch doubles) used by get/set_field with host buffers */
+  npb_maint_table_t maint_table;   /* thresholds of the automatic maintenance (include/npb_maint.h) */
   int *plan_dev;       /* npb_gather_fields: {column, sub, kind} per requested field, and the request it was built for */
   std::vector<int> plan_key;
   std::string error;
@@ -86,7 +87,7 @@ size_t npb_state_bytes(void) { return (size_t)NPB_TOTAL_COL64 * 8; }
 static size_t step_bytes(size_t real_bytes, bool kinetics = true) {
   size_t carried = 0, outputs = 0, ints = 0;
   for (const SectionInfo &s : g_sections) {
-    if (s.f64_base == NPB_MAINT_F64_BASE) continue;
+    if (s.f64_base == NPB_MAINT_F64_BASE || s.f64_base == NPB_MPUMP_F64_BASE) continue;
     carried += (size_t)(s.nf64 - s.nout) * s.count; outputs += (size_t)s.nout * s.count; ints += (size_t)s.ni32 * s.count;
   }
   if (!kinetics) carried -= NPB_PRIM_NKIN; /* ConstantHeatSource: the point-kinetics columns are not touched */
@@ -124,6 +125,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   NPB_HIP(nullptr, hipSetDevice(device));
   NpbHandle *h = new NpbHandle();
   if (params) h->params = *params; else npb_params_default(&h->params);
+  npb_maint_table_default(&h->maint_table);
   h->n_plants = n_plants; h->device = device;
   h->pitch = ((size_t)n_plants + 63) / 64 * 64;
   h->storage = storage; h->real_bytes = real_bytes;
@@ -164,6 +166,19 @@ int npb_set_params(NpbHandle *h, const npb_params_t *params) {
   h->params = *params;
   return NPB_OK;
 }
+
+int npb_set_maintenance_table(NpbHandle *h, const npb_maint_table_t *table) {
+  if (!h || !table) return NPB_EINVAL;
+  for (int k = 0; k < NPB_MAINT_NPARAM; k++) {
+    if (table->rank[k] < 0) continue;
+    if (table->action[k] < 0 || table->action[k] >= NPB_MAINT_NACT || table->comparison[k] < 0 || table->comparison[k] > NPB_CMP_NOT_EQUALS ||
+        table->priority[k] < NPB_PRIO_LOW || table->priority[k] > NPB_PRIO_EMERGENCY || table->bearing[k] < 0 || table->bearing[k] > NPB_BEARING_THRUST)
+      return fail(h, NPB_EINVAL, "npb_set_maintenance_table: action / comparison / priority / bearing code out of range");
+  }
+  h->maint_table = *table;
+  return NPB_OK;
+}
+void npb_default_maintenance_table(npb_maint_table_t *table) { if (table) npb_maint_table_default(table); }
 
 int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream) {
   if (!h) return NPB_EINVAL;
@@ -269,7 +284,12 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
   const bool narrow = h->storage == NPB_STORAGE_F32;
   (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, action, magnitude, power_setpoint,
                                                  noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, (hipStream_t)stream);
-  if (h->params.maint_enabled) (narrow ? npb32_launch_maint : npb_launch_maint)(&h->params, h->pitch, h->f64, (hipStream_t)stream);
+  if (h->params.maint_enabled) {
+    npb_maint_table_t table = h->maint_table;   /* the two oil_level params of ABI version 1 override their table row */
+    table.threshold[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_threshold;
+    table.cooldown_hours[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_cooldown_hours;
+    (narrow ? npb32_launch_maint : npb_launch_maint)(&h->params, &table, h->pitch, h->f64, (hipStream_t)stream);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_step: kernel launch failed", e);
   return NPB_OK;

@@ -721,6 +721,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size
   { npb_cond_t cd; npd_cond_init(&cd); NPD_STORE(COND, npb_cond_t, cd, 0); }
   { npb_sec_t sec; npd_sec_init(&sec); NPD_STORE(SEC, npb_sec_t, sec, 0); }
   { npb_maint_t m; npd_maint_init(&m); NPD_STORE(MAINT, npb_maint_t, m, 0); }
+#pragma unroll 1
+  for (int i = 0; i < NPB_NUM_PUMPS; i++) { npb_mpump_t mp; npd_mpump_init(&mp); NPD_STORE(MPUMP, npb_mpump_t, mp, i); }
   (void)P;
 }
 
@@ -767,29 +769,71 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_reset_kernel(npb_params_t P, siz
   /* the pH controller and its pending doses are not reset (secondary/__init__.py:1041-1072 never touches them) */
 }
 
-/* automatic maintenance after a step (params.maint_enabled): AutoMaintenanceSystem.update then the
- * state manager's threshold scan (npd_maintenance.h).  HBM-bound and small: per plant it reads
- * sim_time, the maint section and four oil levels (184 B); it writes only what changed -- the
- * maint section when a check ran or a violation was recorded, one pump record when a top-off ran. */
-__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, size_t N, npd_real_t *__restrict__ f64) {
+/* automatic maintenance after a step (params.maint_enabled): AutoMaintenanceSystem.update, then the state manager's
+ * threshold scan with work-order creation (npd_maintenance.h), for the four feedwater pumps.  HBM-bound and small:
+ * every step it reads, per pump, the 16 last-violation stamps and the ~15 pump members thresholds look at (~1 KB
+ * per plant); the work-order arrays are read only at a check with open orders and at a violation, and everything
+ * is written only where it changed. */
+#define NPD_MP_COL(inst, member, k) (NPD_SEC_COL(MPUMP, inst) + NPB_F64_SLOT(npb_mpump_t, member) + (k))
+#define NPD_MP_LOAD(inst, member, count) do { _Pragma("unroll") for (int q__ = 0; q__ < (count); q__++) \
+    mp.member[q__] = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(inst, member, q__)); } while (0)
+#define NPD_MP_STORE(inst, member, count) do { _Pragma("unroll") for (int q__ = 0; q__ < (count); q__++) \
+    *(npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(inst, member, q__)) = (npd_real_t)mp.member[q__]; } while (0)
+__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, npb_maint_table_t T, size_t N, npd_real_t *__restrict__ f64) {
   const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
   const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
   npb_maint_t m;
   NPD_LOAD(MAINT, npb_maint_t, m, 0);
-  double oil_level[NPB_NUM_PUMPS];
-#pragma unroll
-  for (int k = 0; k < NPB_NUM_PUMPS; k++) oil_level[k] = NPD_F64_COL(PUMP, npb_pump_t, oil_level, k);
   int dirty = 0;
-  const int pick = npd_maint_pick_due(&m, &P, t, &dirty);
-  if (pick >= 0) {
-    npb_pump_t pm;
-    NPD_LOAD(PUMP, npb_pump_t, pm, pick);
-    npd_oil_top_off(&pm, P.maint_top_off_target);
-    NPD_STORE(PUMP, npb_pump_t, pm, pick);
-#pragma unroll
-    for (int k = 0; k < NPB_NUM_PUMPS; k++) if (k == pick) oil_level[k] = pm.oil_level;
+  /* ---- AutoMaintenanceSystem.update: one due order, the earliest created, is carried out */
+  if (npd_maint_check_due(&m, &P, t)) {
+    dirty = 1;
+    if (m.work_orders_created > m.maintenance_actions_performed) {      /* some order is open */
+      double best = 0.0; int pick = -1, pick_action = -1;
+#pragma unroll 1
+      for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+        npb_mpump_t mp;
+        NPD_MP_LOAD(k, wo_order, NPB_MAINT_NACT); NPD_MP_LOAD(k, wo_planned_start, NPB_MAINT_NACT);
+        int a; const double o = npd_maint_first_due(&mp, t, &a);
+        if (o > 0.0 && (best == 0.0 || o < best)) { best = o; pick = k; pick_action = a; }
+      }
+      if (pick >= 0) {
+        npb_mpump_t mp;
+        NPD_MP_LOAD(pick, wo_order, NPB_MAINT_NACT); NPD_MP_LOAD(pick, wo_planned_start, NPB_MAINT_NACT);
+        mp.wo_bearing = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(pick, wo_bearing, 0));
+        const int bearing = npd_maint_close_order(&mp, &m, pick_action);
+        NPD_MP_STORE(pick, wo_order, NPB_MAINT_NACT); NPD_MP_STORE(pick, wo_planned_start, NPB_MAINT_NACT);
+        *(npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(pick, wo_bearing, 0)) = (npd_real_t)mp.wo_bearing;
+        npb_pump_t pm;
+        NPD_LOAD(PUMP, npb_pump_t, pm, pick);
+        npd_maint_execute(&pm, &P, pick_action, bearing);
+        NPD_STORE(PUMP, npb_pump_t, pm, pick);
+      }
+    }
   }
-  npd_maint_scan(&m, &P, t, oil_level, &dirty);
+  /* ---- StateManager.collect_states: threshold scan, one orchestrated event per pump */
+#pragma unroll 1
+  for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+    npb_pump_t pm;
+    NPD_LOAD(PUMP, npb_pump_t, pm, k);
+    npb_mpump_t mp;
+    NPD_MP_LOAD(k, last_violation_time, NPB_MAINT_NPARAM);
+    /* would any threshold fire?  (the cheap pre-test: the work-order arrays are needed only then) */
+    double values[NPB_MAINT_NPARAM];
+    npd_maint_values(&pm, values);
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < NPB_MAINT_NPARAM; q++)
+      any = any || (T.rank[q] >= 0 && !(mp.last_violation_time[q] >= 0.0 && t - mp.last_violation_time[q] < T.cooldown_hours[q] * 60) &&
+                    npd_maint_violates(values[q], T.threshold[q], T.comparison[q]));
+    if (!any) continue;
+    NPD_MP_LOAD(k, wo_order, NPB_MAINT_NACT); NPD_MP_LOAD(k, wo_planned_start, NPB_MAINT_NACT);
+    NPD_MP_LOAD(k, last_trigger_time, NPB_MAINT_NACT);
+    mp.wo_bearing = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, wo_bearing, 0));
+    npd_maint_scan_pump(&mp, &m, &P, &T, &pm, t);
+    dirty = 1;
+    NPD_STORE(MPUMP, npb_mpump_t, mp, k);
+  }
   if (dirty) NPD_STORE(MAINT, npb_maint_t, m, 0);
 }
 
@@ -864,9 +908,9 @@ extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t n
   hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                      noise_z, cw_temp, obs, reward, done, trip_flags, info);
 }
-extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, size_t npad, void *arena, hipStream_t stream) {
+extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, const npb_maint_table_t *T, size_t npad, void *arena, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_maint_kernel, grid, block, 0, stream, *P, npad, (npd_real_t *)arena);
+  hipLaunchKernelGGL(npb_maint_kernel, grid, block, 0, stream, *P, *T, npad, (npd_real_t *)arena);
 }
 extern "C" void NPB_LAUNCHER(observe)(int mode, int n_plants, size_t npad, const void *arena, double *obs, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);

@@ -109,7 +109,7 @@ class BatchedPlantEnv:
     def __init__(self, n_envs: int, dt: float = 1.0, heat_source: str = "constant", noise_enabled: bool = False,
                  noise_std_percent: float = 0.1, noise_seeds: Optional[Sequence[int]] = None,
                  mode: str = "full", device: int = 0, params: Optional[dict] = None, maintenance: bool = False,
-                 storage: str = "f64"):
+                 storage: str = "f64", maintenance_thresholds: Optional[dict] = None):
         if not torch.cuda.is_available():
             raise _lib.NpbError("BatchedPlantEnv needs a HIP device (torch.cuda.is_available() is False); "
                                 "there is no CPU fallback")
@@ -134,6 +134,9 @@ class BatchedPlantEnv:
         self.storage = storage
         kind = {"f64": _lib.STORAGE_F64, "f32": _lib.STORAGE_F32}[storage]
         _lib.check(self.L.npb_create_storage(ctypes.byref(p), self.n, device, kind, ctypes.byref(self._h)))
+        if maintenance_thresholds is not None:   # the reference's thresholds dict for a feedwater pump, in its order
+            table = _lib.maint_table_from_thresholds(maintenance_thresholds)
+            _lib.check(self.L.npb_set_maintenance_table(self._h, ctypes.byref(table)), self._h)
         with torch.cuda.device(self.device):
             self._obs = torch.zeros((self.n, 22), dtype=torch.float64, device=self.device)
             self._reward = torch.zeros(self.n, dtype=torch.float64, device=self.device)

@@ -34,6 +34,7 @@ def lib():
         L.npo_get_all.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.npo_step_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p] + [ctypes.c_void_p] * 10
         L.npo_observe_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        L.npo_set_maint_table.argtypes = [ctypes.c_void_p]
         L.npo_reset_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         _LIB = L
     return _LIB
@@ -88,6 +89,17 @@ class Params:
     @property
     def ptr(self):
         return _ptr(self._buf)
+
+
+def set_maint_table(table=None):
+    """thresholds of the automatic maintenance for every oracle plant of this process (None = the default table);
+    table: nuclear_sim_amd._lib.NpbMaintTable"""
+    L = lib()
+    if table is None:
+        L.npo_set_maint_table(None)
+    else:
+        assert ctypes.sizeof(table) == L.npo_maint_table_size()
+        L.npo_set_maint_table(ctypes.cast(ctypes.byref(table), ctypes.c_void_p))
 
 
 class OraclePlants:

@@ -30,8 +30,16 @@ NPO_API int npo_set_threads(int n) {
 #endif
 }
 
+NPO_API void npo_set_maint_table(const npb_maint_table_t *t) {
+  if (t) npo_maint_table = *t; else npb_maint_table_default(&npo_maint_table);
+  npo_maint_table_set = 1;
+}
+NPO_API int npo_maint_table_size(void) { return (int)sizeof(npb_maint_table_t); }
+NPO_API void npo_default_maint_table(npb_maint_table_t *t) { npb_maint_table_default(t); }
+
 /* plants: n contiguous npo_plant_t records */
 NPO_API void npo_init(npo_plant_t *plants, int n, const npb_params_t *P) {
+  if (!npo_maint_table_set) npo_set_maint_table(0);
   for (int i = 0; i < n; i++) npo_plant_init(&plants[i], P);
 }
 NPO_API double npo_get_f64(npo_plant_t *plants, int plant, int slot) { return *npo_f64_slot(&plants[plant], slot); }

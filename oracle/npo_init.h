@@ -11,6 +11,7 @@
 #include "npo_feedwater.h"
 #include "npo_turbine.h"
 #include "npo_condenser.h"
+#include "npo_maintenance.h"
 
 /* ReactorState defaults  systems/primary/__init__.py:48-106 */
 NPO_FN void npo_prim_init(npb_prim_t *s) {
@@ -154,13 +155,6 @@ NPO_FN void npo_cond_init(npb_cond_t *cd) {
   cd->ej_operating_mask = 0; cd->lead_ejector = -1; cd->lag_ejector = -1;
 }
 
-/* AutoMaintenanceSystem.__init__ auto_maintenance.py:60-100, WorkOrderManager / StateManager empty dicts
- * (-1 = "key absent" for the two last-time dicts) */
-NPO_FN void npo_maint_init(npb_maint_t *m) {
-  memset(m, 0, sizeof(*m));
-  for (int k = 0; k < NPB_NUM_PUMPS; k++) { m->last_violation_time[k] = -1.0; m->last_trigger_time[k] = -1.0; }
-}
-
 NPO_FN void npo_plant_init(npo_plant_t *pl, const npb_params_t *P) {
   (void)P;
   npo_prim_init(&pl->prim);
@@ -172,6 +166,7 @@ NPO_FN void npo_plant_init(npo_plant_t *pl, const npb_params_t *P) {
   npo_ph_init(&pl->ph);
   npo_cond_init(&pl->cond);
   npo_sec_init(&pl->sec);
+  for (int i = 0; i < NPB_NUM_PUMPS; i++) npo_mpump_init(&pl->mpump[i]);
   npo_maint_init(&pl->maint);
 }
 #endif

@@ -18,6 +18,7 @@ typedef struct npo_plant_t {
   npb_ph_t ph;
   npb_cond_t cond;
   npb_sec_t sec;
+  npb_mpump_t mpump[NPB_NUM_PUMPS];
   npb_maint_t maint;
 } npo_plant_t;
 

@@ -56,27 +56,66 @@ def walk(obj, path="", out=None, seen=None, depth=0, skip=SKIP_ATTRS):
     return out
 
 
+def _maint_catalog():
+    """parameter / action names of include/npb_maint.h, in catalog order"""
+    import os, re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "include", "npb_maint.h")).read()
+    params = re.findall(r'^\s*X\(\w+,\s*"(\w+)"\)', text, flags=re.M)
+    actions = re.findall(r'^\s*X\(\w+,\s*"(\w+)",\s*[01]\)', text, flags=re.M)
+    return params, actions
+
+
 class H:
-    """Lookups the maint.* schema columns use (include/npb_fields.h NPB_MAINT_FIELDS): the
-    reference keeps this state in dicts keyed by component id, absent until first use."""
+    """Lookups the mpump.* / maint.* schema columns use (include/npb_fields.h): the reference keeps this state in dicts
+    keyed by component id, absent until first use.  k indexes the parameter / action catalog of include/npb_maint.h."""
+    PARAMS, ACTIONS = _maint_catalog()
+    BEARINGS = {None: 0.0, "all": 0.0, "motor_bearings": 1.0, "pump_bearings": 2.0, "thrust_bearing": 3.0}
 
     @staticmethod
-    def open_wo(root, k, what):
+    def _open(root, pump, action):
         ms = root.maintenance_system
         for w in ms.work_order_manager.work_orders.values():
-            if w.component_id == "FWP-%d" % (k + 1) and w.status.name == "SCHEDULED":
-                if what == "order":
-                    return float(int(w.work_order_id.split("-")[1]))
-                return float(getattr(w, what))
-        return 0.0
+            if w.component_id == "FWP-%d" % (pump + 1) and w.status.name == "SCHEDULED" and \
+                    any(a.action_type == action for a in w.maintenance_actions):
+                return w
+        return None
 
     @staticmethod
-    def last_violation(root, k):
-        return root.state_manager.threshold_last_violation_times.get("FWP-%d" % (k + 1), {}).get("oil_level", -1.0)
+    def open_wo(root, pump, k, what):
+        w = H._open(root, pump, H.ACTIONS[k])
+        if w is None:
+            return 0.0
+        if what == "order":
+            return float(int(w.work_order_id.split("-")[1]))
+        return float(getattr(w, what))
 
     @staticmethod
-    def last_trigger(root, k):
-        return root.maintenance_system.recent_work_order_triggers.get("FWP-%d:oil_top_off" % (k + 1), -1.0)
+    def open_wo_bearing(root, pump):
+        w = H._open(root, pump, "bearing_replacement")
+        if w is None:
+            return 0.0
+        return H.BEARINGS[(getattr(w, "metadata", None) or {}).get("extracted_component_id")]
+
+    @staticmethod
+    def last_violation(root, pump, k):
+        return root.state_manager.threshold_last_violation_times.get("FWP-%d" % (pump + 1), {}).get(H.PARAMS[k], -1.0)
+
+    @staticmethod
+    def last_trigger(root, pump, k):
+        return root.maintenance_system.recent_work_order_triggers.get("FWP-%d:%s" % (pump + 1, H.ACTIONS[k]), -1.0)
+
+    @staticmethod
+    def executed(root, k):
+        n = 0
+        for w in root.maintenance_system.work_order_manager.work_orders.values():
+            if w.component_id.startswith("FWP-") and w.status.name not in ("SCHEDULED", "PLANNED") and \
+                    any(a.action_type == H.ACTIONS[k] for a in w.maintenance_actions):
+                n += 1
+        # completed orders may also be moved to a history list
+        for w in getattr(root.maintenance_system.work_order_manager, "completed_work_orders", []) or []:
+            if w.component_id.startswith("FWP-") and any(a.action_type == H.ACTIONS[k] for a in w.maintenance_actions):
+                n += 1
+        return float(n)
 
 
 def resolve(root, path):

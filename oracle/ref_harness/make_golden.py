@@ -73,16 +73,54 @@ def scenarios():
         S.append(dict(name="m3%s_oil_top_off_seed%d" % (tag, seed), steps=120, dt=5.0, noise=True, noise_seed=42, every=4,
                       runner=dict(action="oil_top_off", duration_hours=10.0, randomization_seed=seed)))
     # M4-M7: other action-test scenarios of the composer (randomised initial conditions, nuclear_sim_amd/scenarios.py):
-    # physics from pre-degraded seals / oil / bearings with reduced NPSH, TSP deposits, condenser air in-leakage.  The
-    # reference's maintenance control plane raises work orders of its own in these runs (action types the components do
-    # not know); they change no plant state, and the maint.* members are not compared for these fixtures.
-    # (m5 stops after 75 min: at 80 min the reference executes an oil_change work order -- an action whose trigger /
-    # queueing behind those other work orders is part of the control plane that is not restated.)
-    for name, action, seed, steps in (("m4_seal_replacement_seed3", "seal_replacement", 3, 60), ("m5_oil_change_seed1", "oil_change", 1, 15),
-                                      ("m6_tsp_chemical_cleaning_seed0", "tsp_chemical_cleaning", 0, 60),
-                                      ("m7_vacuum_leak_detection", "vacuum_leak_detection", None, 60)):
-        S.append(dict(name=name, steps=steps, dt=5.0, noise=True, noise_seed=42, every=3, maint_unchecked=True,
+    # physics from pre-degraded seals / oil / bearings with reduced NPSH, TSP deposits, condenser air in-leakage.  In the
+    # feedwater scenarios (m4, m5) the reference's control plane raises work orders besides the target action's
+    # (npsh_analysis, lubrication_inspection: action types the pump's dispatcher does not know) which sit in the same
+    # one-execution-per-check queue; all of that is restated (npd_maintenance.h) and compared.  In m6 / m7 the work
+    # orders belong to steam generators / the condenser (not feedwater pumps; out of scope): maint.* not compared there.
+    for name, action, seed, steps, unchecked in (("m4_seal_replacement_seed3", "seal_replacement", 3, 60, False), ("m5_oil_change_seed1", "oil_change", 1, 60, False),
+                                                 ("m6_tsp_chemical_cleaning_seed0", "tsp_chemical_cleaning", 0, 60, True),
+                                                 ("m7_vacuum_leak_detection", "vacuum_leak_detection", None, 60, True)):
+        S.append(dict(name=name, steps=steps, dt=5.0, noise=True, noise_seed=42, every=3, maint_unchecked=unchecked,
                       runner=dict(action=action, duration_hours=5.0, randomization_seed=seed)))
+    # M8-M12: one run per maintenance handler / orchestrator branch.  The composer's scenarios reach oil_top_off, oil_change,
+    # seal_replacement and bearing_replacement; the other thresholds are fired by starting pumps from poked states
+    # (every pump of a plant in a different condition, so the cross-pump execution queue is exercised too).
+    P = "secondary_physics.feedwater_system.pump_system.pumps['FWP-%d']"
+    W = P + ".lubrication_system.component_wear['%s']"
+    L = P + ".lubrication_system.%s"
+    S.append(dict(name="m8_handlers_inspection_overhaul_promotion", steps=60, dt=5.0, noise=True, noise_seed=42, every=2,
+                  runner=dict(action="oil_top_off", duration_hours=5.0),
+                  init_pokes=[(W % (1, "impeller"), 8.5),                                           # impeller_inspection
+                              (P % 2 + ".state.cavitation_damage", 8.5),                            # impeller_replacement
+                              (W % (3, "mechanical_seals"), 17.0), (W % (3, "motor_bearings"), 9.0),  # two major actions -> component_overhaul
+                              (L % (4, "oil_level"), 57.0), (L % (4, "oil_contamination_level"), 15.5)]))  # oil_top_off promoted to oil_change
+    S.append(dict(name="m9_handlers_lubrication_check_bearings_cavitation", steps=60, dt=5.0, noise=True, noise_seed=42, every=2,
+                  runner=dict(action="oil_top_off", duration_hours=5.0),
+                  init_pokes=[(L % (1, "antioxidant_level"), 5.0), (L % (1, "anti_wear_additive_level"), 5.0), (L % (1, "corrosion_inhibitor_level"), 5.0),
+                              (L % (1, "oil_contamination_level"), 14.0), (L % (1, "oil_acidity_number"), 1.5), (L % (1, "oil_moisture_content"), 0.07),  # lubrication_system_check
+                              (W % (2, "pump_bearings"), 7.0),                                      # bearing_replacement: pump_bearings
+                              (P % 3 + ".state.npsh_available", 13.0),                              # npsh_analysis / cavitation_analysis (no handler)
+                              (W % (4, "thrust_bearing"), 5.0), (W % (4, "motor_bearings"), 9.0), (W % (4, "pump_bearings"), 7.0),
+                              (W % (4, "mechanical_seals"), 17.0)]))                                # four violations -> component_overhaul
+    S.append(dict(name="m10_motor_bearing_replacement_seed1", steps=40, dt=5.0, noise=True, noise_seed=42, every=2,
+                  runner=dict(action="motor_bearing_replacement", duration_hours=8.0, randomization_seed=1)))
+    S.append(dict(name="m11_thrust_bearing_replacement_seed1", steps=24, dt=5.0, noise=True, noise_seed=42, every=2,
+                  runner=dict(action="thrust_bearing_replacement", duration_hours=8.0, randomization_seed=1)))
+    S.append(dict(name="m12_seal_replacement_seed1", steps=90, dt=5.0, noise=True, noise_seed=42, every=3,
+                  runner=dict(action="seal_replacement", duration_hours=8.0, randomization_seed=1)))
+    # M13a-e: the handlers no threshold of the action-test configuration can reach (a pump's motor temperature, vibration
+    # level and seal leakage stay below their thresholds by construction), run with an edited thresholds dict -- which
+    # also pins the table path (npb_set_maintenance_table) against a configuration other than the default one
+    for tag, override, pokes in (
+            ("a_motor_inspection", [("motor_temperature", {"threshold": 75.0})], [(W % (1, "motor_bearings"), 4.0)]),
+            ("b_oil_analysis", [("lubrication_effectiveness", {"threshold": 0.9, "action": "oil_analysis"})], []),
+            ("c_vibration_analysis", [("npsh_available", {"threshold": 25.0, "action": "vibration_analysis", "priority": "LOW"})], []),
+            ("d_system_cleaning", [("impeller_wear", {"threshold": 0.0001, "action": "system_cleaning", "cooldown_hours": 0.5})], []),
+            ("e_bearing_inspection", [("cavitation_damage", {"threshold": -1.0, "action": "bearing_inspection", "comparison": "greater_equal"})],
+             [(W % (2, "pump_bearings"), 6.0)])):
+        S.append(dict(name="m13" + tag, steps=14, dt=5.0, noise=True, noise_seed=42, every=1, thresholds_override=override, init_pokes=pokes,
+                      runner=dict(action="oil_top_off", duration_hours=2.0)))
     # R1-R3: NuclearPlantSimulator.reset() (sim.py:546-581) in the middle of a run -- the reference's reset is not a
     # re-construction (parts of the history survive, start_at_steady_state force-sets the secondary side and advances the
     # steam generators once), so the state it leaves and the trajectory after it are pinned here
@@ -113,7 +151,9 @@ def main(only=None):
         every = sc.get("every", 1)
         steps = sorted(set(list(range(0, T + 1, every)) + [T] + [t + 1 for t in sc.get("pokes", {})] + list(sc.get("pokes", {}).keys())
                            + [t for t in sc.get("resets", {})] + [t + 1 for t in sc.get("resets", {})]))
-        meta = {k: v for k, v in sc.items() if not callable(v) and k not in ("pokes", "resets")}
+        meta = {k: v for k, v in sc.items() if not callable(v) and k not in ("pokes", "resets", "_maint_thresholds")}
+        if sc.get("_maint_thresholds"):
+            meta["maint_thresholds"] = sc["_maint_thresholds"]   # the FWP thresholds dict the run used, in its order
         meta["resets"] = {str(k): bool(v) for k, v in sc.get("resets", {}).items()}
         meta["pokes"] = {str(k): [[p, float(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
         # pokes expressed in schema labels so tests can replay them without the reference
@@ -171,8 +211,41 @@ def make_ic_all_actions(seeds=(0,)):
     print("ic_all_actions: %d rows, %d failed" % (len(rows), len(failed)))
 
 
+def make_maint_table():
+    """tests/golden/maint_table.json: StateManager.maintenance_thresholds['FWP-1'] of the data-gen action-test simulator, in
+    its dict order, with the state-log key each threshold name resolves to (None = never resolves, never fires), plus the
+    AutoMaintenanceSystem settings.  Pins include/npb_maint.h (npb_maint_table_default, the parameter catalog)."""
+    from . import refsim
+    refsim.setup()
+    _runner, sim = refsim.make_runner_sim(action="oil_top_off", duration_hours=2.0)
+    sm, ms = sim.state_manager, sim.maintenance_system
+    captured = {}
+    orig = sm._check_maintenance_thresholds
+    sm._check_maintenance_thresholds = lambda ts, row: (captured.update(row=dict(row)), orig(ts, row))[1]
+    from systems.primary import ControlAction
+    with refsim.quiet():
+        sim.step(ControlAction.NO_ACTION)
+    row = captured["row"]
+    out = {"thresholds": [], "settings": {k: getattr(ms, k) for k in ("check_interval_hours", "work_order_cooldown_hours", "emergency_delay_hours",
+                                                                      "high_priority_delay_hours", "medium_priority_delay_hours", "low_priority_delay_hours")}}
+    cid = "FWP-1"
+    for name, cfg in sm.maintenance_thresholds[cid].items():
+        keys = ["%s.%s" % (cid, name), "secondary.feedwater_%s.%s" % (cid, name), "secondary.feedwater.%s" % name, "secondary.%s.%s" % (cid, name)]
+        hit = [k for k in keys if k in row and isinstance(row[k], (int, float))]
+        out["thresholds"].append({"name": name, "resolves_to": hit[0] if hit else None, **{k: cfg.get(k) for k in
+                                  ("threshold", "comparison", "action", "cooldown_hours", "priority", "component_id")}})
+    from systems.maintenance.maintenance_actions import MaintenanceActionType
+    out["valid_action_types"] = sorted(a.value for a in MaintenanceActionType)
+    out["pump_state_log_keys"] = sorted(k.split(".")[-1] for k in row if "feedwater_FWP-1." in k)
+    with open(os.path.join(OUT, "maint_table.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("maint_table.json: %d thresholds, %d resolve" % (len(out["thresholds"]), sum(1 for t in out["thresholds"] if t["resolves_to"])))
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["ic"]:
+    if sys.argv[1:] == ["maint_table"]:
+        make_maint_table()
+    elif sys.argv[1:] == ["ic"]:
         make_ic_fixture()
     elif sys.argv[1:] == ["ic_actions"]:
         make_ic_all_actions()

@@ -53,6 +53,14 @@ def run_reference(sc, columns):
                           noise=sc.get("noise", False), noise_std_percent=sc.get("noise_std_percent", 0.1),
                           noise_seed=sc.get("noise_seed", 42), secondary=sc.get("secondary"))
     from systems.primary import ControlAction
+    if sc.get("thresholds_override"):
+        # edit the live maintenance thresholds of every feedwater pump (what another maintenance configuration would load)
+        for cid, th in sim.state_manager.maintenance_thresholds.items():
+            if cid.startswith("FWP-"):
+                for name, changes in sc["thresholds_override"]:
+                    th[name].update(changes)
+        sc["_maint_thresholds"] = [[n, {k: c.get(k) for k in ("threshold", "comparison", "action", "cooldown_hours", "priority", "component_id")}]
+                                   for n, c in sim.state_manager.maintenance_thresholds["FWP-1"].items()]
     if sc.get("equilibrium") is not None:
         from systems.primary.reactor.reactivity_model import create_equilibrium_state
         p, rods = sc["equilibrium"]

@@ -18,6 +18,8 @@ def _env(g=None, n=1, **kw):
         kw.setdefault("noise_enabled", bool(m.get("noise")))
         kw.setdefault("noise_std_percent", m.get("noise_std_percent", 0.1))
         kw.setdefault("maintenance", bool(m.get("runner")))
+        if m.get("maint_thresholds"):    # the run used a maintenance configuration other than the default one
+            kw.setdefault("maintenance_thresholds", dict((nm, c) for nm, c in m["maint_thresholds"]))
     return BatchedPlantEnv(n, **kw)
 
 
@@ -211,9 +213,10 @@ def test_long_run_stays_on_the_oracle(oracle_lib):
 
 
 def test_hip_maintenance_matches_oracle_on_random_batch(oracle_lib):
-    """Automatic oil_top_off maintenance on a ragged batch: oil levels scattered around the
-    58 % threshold, shortened cooldowns so that orders re-trigger, every maint.* and pump.* column
-    compared with the oracle after every step; plus the counting identities of the rule."""
+    """Automatic maintenance on a ragged batch: oil levels scattered around the 58 % threshold, wear /
+    contamination / NPSH scattered around theirs so that every orchestrator branch and most handlers occur somewhere
+    in the batch, shortened cooldowns so that orders re-trigger; every maint.*, mpump.* and pump.* column compared with
+    the oracle after every step; plus the counting identities of the queue."""
     n, T = 333, 90
     rng = np.random.default_rng(99)
     mp = {"maint_oil_level_cooldown_hours": 1.0, "maint_work_order_cooldown": 24.0, "maint_start_delay_hours": 0.1,
@@ -224,10 +227,16 @@ def test_hip_maintenance_matches_oracle_on_random_batch(oracle_lib):
         setattr(P, k, v)
     ora = oracle_lib.OraclePlants(n, P)
     for k in range(4):
-        v = rng.uniform(57.0, 59.5, n)
-        env.set_field("pump.oil_level", v, instance=k); ora.set("pump.oil_level", v, instance=k)
+        for name, lo, hi, frac in (("pump.oil_level", 57.0, 59.5, 1.0), ("pump.oil_contamination", 14.0, 16.0, 0.3),
+                                   ("pump.wear_impeller", 7.0, 9.0, 0.2), ("pump.wear_motor_bearings", 7.5, 9.5, 0.2),
+                                   ("pump.wear_pump_bearings", 5.5, 7.5, 0.2), ("pump.wear_thrust_bearing", 3.5, 5.5, 0.2),
+                                   ("pump.wear_mechanical_seals", 15.0, 17.0, 0.2), ("pump.npsh_available", 16.0, 20.0, 0.3),
+                                   ("pump.cavitation_damage", 7.0, 9.0, 0.2), ("pump.antioxidant_level", 2.0, 40.0, 0.2)):
+            base = ora.get(name, instance=k)
+            v = np.where(rng.random(n) < frac, rng.uniform(lo, hi, n), base)
+            env.set_field(name, v, instance=k); ora.set(name, v, instance=k)
     z = rng.standard_normal((T, n))
-    cols = [c for c in env_cols() if c[2].startswith(("maint", "pump"))]
+    cols = [c for c in env_cols() if c[2].startswith(("maint", "mpump", "pump"))]
     for t in range(T):
         ora.step(setpoint=np.full(n, 90.0), noise_z=z[t])
         env.step(power_setpoint=np.full(n, 90.0), noise_z=z[t])
@@ -240,7 +249,10 @@ def test_hip_maintenance_matches_oracle_on_random_batch(oracle_lib):
                 np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg="%s step %d" % (label, t))
     created = env.get_field("maint.work_orders_created").cpu().numpy()
     done_ = env.get_field("maint.maintenance_actions_performed").cpu().numpy()
-    open_ = sum((env.get_field("maint.wo_order", k=k).cpu().numpy() > 0).astype(np.int64) for k in range(4))
+    open_ = sum((env.get_field("mpump.wo_order", instance=k, k=a).cpu().numpy() > 0).astype(np.int64) for k in range(4) for a in range(18))
+    executed = np.stack([env.get_field("maint.executed", k=a).cpu().numpy() for a in range(18)])
+    assert np.array_equal(executed.sum(axis=0), done_)
+    assert (executed.sum(axis=1) > 0).sum() >= 8, "the batch reaches most action types: %s" % executed.sum(axis=1)
     assert created.max() > 4, "cooldowns were shortened so that pumps re-trigger"
     assert np.array_equal(created, done_ + open_)          # every order is either executed or still open
     assert done_.max() <= (T * 5.0) / 15.0 + 1             # at most one execution per 15-min check

@@ -14,6 +14,9 @@ def _configure(npo, g):
     P.hs_noise_enabled = 1 if m.get("noise") else 0
     P.hs_noise_std_percent = m.get("noise_std_percent", 0.1)
     P.maint_enabled = 1 if m.get("runner") else 0  # fixtures made through the data-gen runner have auto-maintenance on
+    # the maintenance thresholds the run used, when they are not the default configuration's
+    from nuclear_sim_amd import _lib
+    npo.set_maint_table(_lib.maint_table_from_thresholds(dict((n, c) for n, c in m["maint_thresholds"])) if m.get("maint_thresholds") else None)
     return P
 
 
