@@ -113,8 +113,10 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   *out = nullptr;
   if (storage != NPB_STORAGE_F64 && storage != NPB_STORAGE_F32) return fail(nullptr, NPB_EINVAL, "npb_create: storage must be NPB_STORAGE_F64 or NPB_STORAGE_F32");
   const size_t real_bytes = storage == NPB_STORAGE_F32 ? sizeof(float) : sizeof(double);
-  /* the step kernel addresses a column as (one 64-bit base) + (32-bit byte offset), nuclear_sim_amd/csrc/npd_stage.h */
-  if ((((size_t)n_plants + 63) / 64 * 64) * arena_columns(storage) * real_bytes >= ((size_t)1 << 32))
+  /* the step kernel addresses a column as (one 64-bit base) + (32-bit byte offset), nuclear_sim_amd/csrc/npd_stage.h;
+   * the maintenance sections behind its columns are addressed with 64-bit arithmetic by their own kernel */
+  const size_t step_columns = storage == NPB_STORAGE_F32 ? (size_t)NPB_MPUMP_COL32_BASE : (size_t)NPB_MPUMP_COL64_BASE;
+  if ((((size_t)n_plants + 63) / 64 * 64) * step_columns * real_bytes >= ((size_t)1 << 32))
     return fail(nullptr, NPB_EINVAL, "npb_create: more than 4 GiB of real-valued state per handle (about one million fp64 plants); use several handles");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);

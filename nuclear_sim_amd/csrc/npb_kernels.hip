@@ -21,6 +21,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "npd_common.h"
 /* diagnostic build only (-DNPB_STAMPS, tools/phase_stamps.py): lane 0 of every wave records s_memtime
  * at phase boundaries so the kernel's time can be attributed to phases on the GPU */
@@ -669,6 +670,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   NPD_WAIT_ACC_STORE();
 }
 
+#include "npd_step2.h"
+
 /* get_observation() without stepping (after reset / set_field): sim.py:290-333 */
 __global__ __launch_bounds__(NPB_WAVE) void npb_observe_kernel(int mode, int n_plants, size_t N, const npd_real_t *__restrict__ f64c,
                                                                double *__restrict__ obs_out) {
@@ -905,8 +908,15 @@ extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t n
                                 const double *noise_z, const double *cw_temp, double *obs, double *reward, uint8_t *done,
                                 uint32_t *trip_flags, double *info, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
-                     noise_z, cw_temp, obs, reward, done, trip_flags, info);
+  /* two kernels, one result: the two-wave kernel (npd_step2.h) for the full plant; the one-wave kernel for the
+   * primary + steam-generator mode and on request (NPB_STEP_KERNEL=1, for A/B measurements) */
+  static const int variant = [] { const char *e = getenv("NPB_STEP_KERNEL"); return e ? atoi(e) : 2; }();
+  if (variant == 2 && P->mode == NPB_MODE_FULL)
+    hipLaunchKernelGGL(npb_step2_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
+                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info);
+  else
+    hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
+                       noise_z, cw_temp, obs, reward, done, trip_flags, info);
 }
 extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, const npb_maint_table_t *T, size_t npad, void *arena, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);

@@ -177,10 +177,12 @@ typedef struct npd_sg_result_t {
   double heat_transfer_rate, steam_flow_rate, thermal_efficiency;
 } npd_sg_result_t;
 
-/* SteamGenerator.update_state  steam_generator.py:664-848 */
-NPD_FN void npd_sg_update(npb_sg_t *g, const npb_params_t *P, double primary_temp_in, double primary_temp_out,
-                          double primary_flow, double steam_flow_out, double feedwater_flow_in,
-                          double feedwater_temp, double dt, npd_sg_result_t *res) {
+/* SteamGenerator.update_state  steam_generator.py:664-848, in two parts.  Part 1 -- heat transfer, tube-wall
+ * temperature, TSP and tube-interior fouling -- needs the primary-side conditions only; part 2 -- flow restrictions and
+ * the secondary-side dynamics -- is where the actual feedwater flow first enters (:744-760).  The two-wave step
+ * kernel runs part 1 while the feedwater pumps are still being updated; everyone else calls them back to back. */
+NPD_FN double npd_sg_part1(npb_sg_t *g, const npb_params_t *P, double primary_temp_in, double primary_temp_out,
+                          double primary_flow, double dt) {
   /* ---- calculate_heat_transfer :150-314 */
   double sat_temp = npd_sg_tsat(g->secondary_pressure);
   double delta_t1 = primary_temp_in - sat_temp;
@@ -228,7 +230,11 @@ NPD_FN void npd_sg_update(npb_sg_t *g, const npb_params_t *P, double primary_tem
   double avg_velocity = primary_flow / (1000.0 * total_flow_area);
   npd_tsp_update(g, P, g->secondary_temperature, avg_velocity, dt / 3600.0);
   npd_scale_update(g, (primary_temp_in + primary_temp_out) / 2.0, avg_velocity, dt);
+  return heat_transfer;
+}
 
+NPD_FN void npd_sg_part2(npb_sg_t *g, const npb_params_t *P, double heat_transfer, double steam_flow_out, double feedwater_flow_in,
+                         double feedwater_temp, double dt, npd_sg_result_t *res) {
   /* _apply_tsp_flow_restrictions :516-547 */
   double flow_capacity_factor = 1.0 / sqrt(g->tsp_pressure_drop_ratio);
   double actual_steam_flow = npd_pymin(steam_flow_out, P->sg_design_steam_flow_per_sg * flow_capacity_factor);
@@ -291,6 +297,13 @@ NPD_FN void npd_sg_update(npb_sg_t *g, const npb_params_t *P, double primary_tem
   res->heat_transfer_rate = heat_transfer;
   res->steam_flow_rate = actual_steam_flow;
   res->thermal_efficiency = heat_transfer / P->sg_design_thermal_power_per_sg;
+}
+
+NPD_FN void npd_sg_update(npb_sg_t *g, const npb_params_t *P, double primary_temp_in, double primary_temp_out,
+                          double primary_flow, double steam_flow_out, double feedwater_flow_in,
+                          double feedwater_temp, double dt, npd_sg_result_t *res) {
+  const double heat_transfer = npd_sg_part1(g, P, primary_temp_in, primary_temp_out, primary_flow, dt);
+  npd_sg_part2(g, P, heat_transfer, steam_flow_out, feedwater_flow_in, feedwater_temp, dt, res);
 }
 
 typedef struct npd_sgsys_result_t {

@@ -400,14 +400,12 @@ typedef struct npd_turbine_result_t {
   int trip_active;
 } npd_turbine_result_t;
 
-NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double steam_pressure,
-                               double steam_temperature, double steam_flow,
-                               const double *sg_pressures, int sg_system_availability, double load_demand,
-                               double condenser_pressure, double dt, npd_turbine_result_t *res) {
-  /* ================= lubrication wrapper (pre-step, previous step's bearing state) =============
-   * update_with_lubrication  turbine_bearing_lubrication.py:715-784: called with keyword arguments
-   * only, so every rotor quantity takes its default and the load factor is turbine.load_demand
-   * as left by the PREVIOUS step (:744-746). */
+/* ================= lubrication wrapper (pre-step, previous step's bearing state) =============
+ * update_with_lubrication  turbine_bearing_lubrication.py:715-784: called with keyword arguments
+ * only, so every rotor quantity takes its default and the load factor is turbine.load_demand
+ * as left by the PREVIOUS step (:744-746).  Reads rotor_speed, bearing_load, bearing_metal_temp and load_demand
+ * as the previous step left them; writes the lub_* members only. */
+NPD_FN void npd_turbine_lube(npb_turb_t *t, double dt) {
   double lub_load_factor = t->load_demand;
   double friction_heat[4], b_load_factor[4], b_speed_factor, b_temperature[4];
   b_speed_factor = t->rotor_speed / 3600.0;
@@ -471,15 +469,12 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
     t->lub_wear[i] += (wear_rate * lubrication_wear_factor) * dt;
   }
 
-  NPD_STAMP(12);
-  /* ================= EnhancedTurbinePhysics.update_state  enhanced_physics.py:694-890 ========= */
-  t->load_demand = load_demand;
-  double pressure_stability_factor = npd_pressure_stability_factor(sg_pressures);
-  npd_stagesys_out_t ss;
-  npd_stage_system_update(st, (const double *)0, steam_pressure, steam_temperature, steam_flow, load_demand,
-                          pressure_stability_factor, dt, &ss);
-  NPD_STAMP(15);
-  double stage_power_mw = ss.total_power;
+}
+
+/* RotorDynamicsModel.update_state  rotor_dynamics.py:956-1070 (rotor, thermal effects, four bearings, vibration
+ * response); returns the hottest bearing metal temperature and the total vibration displacement for the protection */
+NPD_FN void npd_turbine_rotor(npb_turb_t *t, double stage_power_mw, double steam_temperature, double load_demand, double dt,
+                              double *max_bearing_metal_out, double *total_displacement_out) {
   double applied_torque = stage_power_mw * 1e6 / (2 * NPD_PI * 3600 / 60);
 
   /* ---- RotorDynamicsModel.update_state  rotor_dynamics.py:956-1070 */
@@ -555,8 +550,13 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
   double total_displacement = sqrt(npd_sq(displacement_1x) + npd_sq(displacement_2x) + npd_sq(displacement_3x));
   t->vibration_displacement = total_displacement;
 
-  /* MetalTemperatureTracker.update_temperatures ran per stage inside the stage pass (npd_stage_post) */
-  double max_stress = ss.max_thermal_stress;
+  *max_bearing_metal_out = max_bearing_metal; *total_displacement_out = total_displacement;
+}
+
+/* TurbineProtectionSystem.check_trip_conditions  enhanced_physics.py:348-436 and the power it leaves (:760-800) */
+NPD_FN void npd_turbine_protect(npb_turb_t *t, double stage_power_mw, double max_stress, double max_bearing_metal, double total_displacement,
+                                int sg_system_availability, double condenser_pressure, double dt) {
+  double dt_seconds = dt * 3600.0;
 
   /* ---- TurbineProtectionSystem.check_trip_conditions  enhanced_physics.py:348-436 */
   int trips = 0, latched = t->trip_latched_mask;
@@ -575,6 +575,27 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
   double sg_availability_factor = sg_system_availability ? 1.0 : 0.5;
   t->total_power_output = stage_power_mw * (power_reduction * sg_availability_factor);
 
+}
+
+NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double steam_pressure,
+                               double steam_temperature, double steam_flow,
+                               const double *sg_pressures, int sg_system_availability, double load_demand,
+                               double condenser_pressure, double dt, npd_turbine_result_t *res) {
+  npd_turbine_lube(t, dt);
+
+  NPD_STAMP(12);
+  /* ================= EnhancedTurbinePhysics.update_state  enhanced_physics.py:694-890 ========= */
+  t->load_demand = load_demand;
+  double pressure_stability_factor = npd_pressure_stability_factor(sg_pressures);
+  npd_stagesys_out_t ss;
+  npd_stage_system_update(st, (const double *)0, steam_pressure, steam_temperature, steam_flow, load_demand,
+                          pressure_stability_factor, dt, &ss);
+  NPD_STAMP(15);
+  double stage_power_mw = ss.total_power;
+  double max_bearing_metal, total_displacement;
+  npd_turbine_rotor(t, stage_power_mw, steam_temperature, load_demand, dt, &max_bearing_metal, &total_displacement);
+  /* MetalTemperatureTracker.update_temperatures ran per stage inside the stage pass (npd_stage_post) */
+  npd_turbine_protect(t, stage_power_mw, ss.max_thermal_stress, max_bearing_metal, total_displacement, sg_system_availability, condenser_pressure, dt);
   res->electrical_power_gross = t->total_power_output;
   res->mechanical_power = t->total_power_output / 0.985;
   res->electrical_power_net = t->total_power_output * 0.98;
