@@ -137,6 +137,12 @@ NPB_API int npb_step(NpbHandle *h, const int32_t *action, const double *magnitud
              const double *noise_z, const double *cooling_water_temp, double *obs, double *reward, uint8_t *done,
              uint32_t *trip_flags, double *info, void *stream);
 
+/* Which of the two step kernels npb_step launches (same device functions in the same per-plant order: identical int32
+ * columns and flags, reals equal to the last bit or two; this is a measurement / A-B aid):
+ * 0 = by batch size (default; also the environment variable NPB_STEP_KERNEL at handle creation), 1 = one wavefront per
+ * 64 plants with an LDS-DMA staging pipeline, 2 = two wavefronts per 64 plants that own different subsystems. */
+NPB_API int npb_set_step_kernel(NpbHandle *h, int variant);
+
 /* NuclearPlantSimulator.get_observation (sim.py:290-333) */
 NPB_API int npb_observe(NpbHandle *h, double *obs, void *stream);
 

@@ -115,6 +115,7 @@ def load():
     L.npb_num_plants.argtypes = [vp]
     L.npb_set_params.argtypes = [vp, ctypes.POINTER(NpbParams)]
     L.npb_reset.argtypes = [vp, vp, vp]
+    L.npb_set_step_kernel.argtypes = [vp, ci]
     L.npb_set_maintenance_table.argtypes = [vp, ctypes.POINTER(NpbMaintTable)]
     L.npb_default_maintenance_table.argtypes = [ctypes.POINTER(NpbMaintTable)]
     L.npb_reset_reference.argtypes = [vp, vp, ci, vp]

@@ -20,6 +20,7 @@ struct NpbHandle {
   size_t real_bytes;   /* 8 | 4 */
   void *f64;           /* the arena: [NPB_TOTAL_COL64][pitch] 8-byte columns, or [NPB_TOTAL_COL32][pitch] 4-byte ones */
   double *convert;     /* one staging column (pitch doubles) used by get/set_field with host buffers */
+  int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel (npb_set_step_kernel) */
   npb_maint_table_t maint_table;   /* thresholds of the automatic maintenance (include/npb_maint.h) */
   int *plan_dev;       /* npb_gather_fields: {column, sub, kind} per requested field, and the request it was built for */
   std::vector<int> plan_key;
@@ -128,6 +129,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   NpbHandle *h = new NpbHandle();
   if (params) h->params = *params; else npb_params_default(&h->params);
   npb_maint_table_default(&h->maint_table);
+  { const char *e = getenv("NPB_STEP_KERNEL"); h->step_kernel = e ? atoi(e) : 0; if (h->step_kernel < 0 || h->step_kernel > 2) h->step_kernel = 0; }
   h->n_plants = n_plants; h->device = device;
   h->pitch = ((size_t)n_plants + 63) / 64 * 64;
   h->storage = storage; h->real_bytes = real_bytes;
@@ -166,6 +168,12 @@ int npb_destroy(NpbHandle *h) {
 int npb_set_params(NpbHandle *h, const npb_params_t *params) {
   if (!h || !params) return NPB_EINVAL;
   h->params = *params;
+  return NPB_OK;
+}
+
+int npb_set_step_kernel(NpbHandle *h, int variant) {
+  if (!h || variant < 0 || variant > 2) return NPB_EINVAL;
+  h->step_kernel = variant;
   return NPB_OK;
 }
 
@@ -285,7 +293,7 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
   NPB_USE_DEVICE(h);
   const bool narrow = h->storage == NPB_STORAGE_F32;
   (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, action, magnitude, power_setpoint,
-                                                 noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, (hipStream_t)stream);
+                                                 noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, h->step_kernel, (hipStream_t)stream);
   if (h->params.maint_enabled) {
     npb_maint_table_t table = h->maint_table;   /* the two oil_level params of ABI version 1 override their table row */
     table.threshold[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_threshold;

@@ -906,11 +906,15 @@ extern "C" void NPB_LAUNCHER(field_set)(void *arena, size_t npad, int col, int s
 extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad, void *arena,
                                 const int32_t *action, const double *magnitude, const double *setpoint,
                                 const double *noise_z, const double *cw_temp, double *obs, double *reward, uint8_t *done,
-                                uint32_t *trip_flags, double *info, hipStream_t stream) {
+                                uint32_t *trip_flags, double *info, int variant, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  /* two kernels, one result: the two-wave kernel (npd_step2.h) for the full plant; the one-wave kernel for the
-   * primary + steam-generator mode and on request (NPB_STEP_KERNEL=1, for A/B measurements) */
-  static const int variant = [] { const char *e = getenv("NPB_STEP_KERNEL"); return e ? atoi(e) : 2; }();
+  /* two kernels, one result (the same device functions in the same order per plant; tests/test_gpu_parity.py,
+   * test_the_two_step_kernels_agree).  The two-wave kernel
+   * (npd_step2.h) fills the chip from half the batch and has the shorter critical path; once the one-wave kernel has a
+   * wave for every SIMD (> ~57 k plants) its LDS-DMA pipeline wins (measured crossover).
+   * variant: 0 = by batch size, 1 = one wave per 64 plants, 2 = two waves.  The primary + steam-generator mode
+   * always takes the one-wave kernel. */
+  if (variant == 0) variant = npad <= 57344 ? 2 : 1;
   if (variant == 2 && P->mode == NPB_MODE_FULL)
     hipLaunchKernelGGL(npb_step2_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
                        setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info);

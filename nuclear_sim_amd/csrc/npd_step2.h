@@ -34,6 +34,9 @@
 #define NPD_STEP2_H
 
 #define NPD2_THREADS 128
+#ifndef NPD2_OCCUPANCY
+#define NPD2_OCCUPANCY __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 #define NPD2_SLOTS 80                         /* exchange slots of 64 doubles: 40 KB per group, 4 groups per CU */
 #define NPD2_SYNC_() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #ifdef NPB_STAMPS
@@ -285,7 +288,7 @@ __device__ __forceinline__ void npd2_stage_post(const npd_stage_t &st, const npd
   }
 }
 
-__global__ __launch_bounds__(NPD2_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void npb_step2_kernel(
+__global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(
     npb_params_t P, int n_plants, size_t N, npd_real_t *__restrict__ f64,
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
     const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,

@@ -163,6 +163,10 @@ class BatchedPlantEnv:
         return env
 
     # ------------------------------------------------------------------ helpers
+    def set_step_kernel(self, variant: int) -> None:
+        """0 = by batch size (default), 1 = one-wave kernel, 2 = two-wave kernel; same results to the last bit or two (include/npb.h)"""
+        _lib.check(self.L.npb_set_step_kernel(self._h, int(variant)), self._h)
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.L.npb_destroy(self._h)
