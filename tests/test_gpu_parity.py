@@ -387,6 +387,34 @@ def test_the_two_step_kernels_agree(heat_source, storage):
     assert (i1 != 0).any()
 
 
+def test_results_do_not_depend_on_how_the_batch_is_split_into_handles():
+    """contiguous shards by global plant id give results independent of the number of GPUs.  One 200-plant
+    episode as ONE handle and as TWO handles (100 + 100: neither a multiple of the wave size, so plants sit in
+    different lanes and waves): every column and every output bit-identical for the same global plant."""
+    import torch
+    n, T = 200, 30
+    rng = np.random.default_rng(21)
+    oil = rng.uniform(56.0, 100.0, (4, n)); rods = rng.uniform(80, 100, n)
+    z = rng.standard_normal((T, n)); sp = rng.uniform(60, 100, (T, n)); acts = rng.choice([0, 1, 3, 8, 8], size=(T, n)).astype(np.int32)
+
+    def episode(lo, hi):
+        env = _env(n=hi - lo, dt=5.0, noise_enabled=True, maintenance=True)
+        env.set_step_kernel(2)
+        for k in range(4):
+            env.set_field("pump.oil_level", oil[k, lo:hi], instance=k)
+        env.set_field("prim.control_rod_position", rods[lo:hi])
+        for t in range(T):
+            obs, rew, done, info = env.step(action=acts[t, lo:hi], magnitude=np.ones(hi - lo), power_setpoint=sp[t, lo:hi], noise_z=z[t, lo:hi])
+        f, i = _host_state(env)
+        return f, i, obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), info["trip_flags"].cpu().numpy().copy()
+
+    whole = episode(0, n)
+    parts = [episode(0, 100), episode(100, n)]
+    for j in range(5):
+        joined = np.concatenate([p_[j] for p_ in parts], axis=1 if j < 2 else 0)
+        assert np.array_equal(whole[j], joined, equal_nan=True), j
+
+
 def test_lane_independence_and_determinism():
     """Plants are independent: perturbing one plant's state and inputs must leave every other plant's state and
     outputs bit-identical (also across the wave-level decisions: store elision ballots, the turbine stage pass's

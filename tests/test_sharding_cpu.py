@@ -50,3 +50,56 @@ def test_gather_and_reduce_world2():
     expect = np.arange(n_global, dtype=np.float64)[:, None] * 100.0 + np.arange(22, dtype=np.float64)[None, :]
     assert np.array_equal(full, expect)
     assert cnt.tolist() == [n_global, 3, 0, 10]
+
+
+def _episode_inputs(n_global, T):
+    """per-plant inputs as a function of the GLOBAL plant id only (what bench.py / tools/config4.py do)"""
+    gid = np.arange(n_global)
+    sp = 90.0 + 10.0 * np.sin(2.0 * np.pi * np.arange(T)[:, None] / (600.0 + 60.0 * (gid % 16))[None, :])
+    z = np.stack([np.random.RandomState(42 + int(i)).standard_normal(T) for i in gid], axis=1)
+    oil = 57.0 + (gid % 7) * 0.5          # some pumps cross the 58 % maintenance threshold
+    return sp, z, oil
+
+
+def _stepping_worker(rank, world, port, n_global, T, q):
+    """One rank of a sharded episode: steps ITS plants (the CPU oracle stands in for the GPU stepper here -- this test is
+    about the host logic: shard ranges, inputs by global id, the episode-end collectives), then gathers."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import npo
+    lo, hi = shard_range(n_global, rank, world)
+    sp, z, oil = _episode_inputs(n_global, T)
+    P = npo.Params(); P.hs_noise_enabled = 1; P.maint_enabled = 1; P.dt = 5.0
+    ora = npo.OraclePlants(hi - lo, P)
+    ora.set("pump.oil_level", oil[lo:hi], instance=0)
+    for t in range(T):
+        obs, rew, done, flags, info = ora.step(setpoint=sp[t, lo:hi], noise_z=z[t, lo:hi])
+    full = gather_observations(torch.from_numpy(obs), n_global)
+    events = sum(ora.get("maint.maintenance_actions_performed", plant=i) for i in range(hi - lo))
+    cnt = reduce_counters(torch.tensor([int((flags & 1).astype(bool).sum()), events], dtype=torch.int64))
+    if rank == 0:
+        q.put((full.numpy(), cnt.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_episode_does_not_depend_on_the_world_size():
+    """'results independent of G'.  The same 37-plant episode (ragged shards) stepped by one rank and by two:
+    the gathered observation block and the reduced counters must be identical."""
+    n_global, T = 37, 12
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 31500 + (os.getpid() % 2000) + world
+        procs = [ctx.Process(target=_stepping_worker, args=(r, world, port, n_global, T, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results[world] = q.get(timeout=300)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    assert np.array_equal(results[1][0], results[2][0])
+    assert results[1][1].tolist() == results[2][1].tolist()
+    assert results[1][1][1] > 0, "some plants had a maintenance event"
