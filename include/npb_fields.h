@@ -81,7 +81,7 @@
   F(thermal_power_mw,      "primary_physics.thermal_power_mw") \
   F(total_reactivity_pcm,  "primary_physics.total_reactivity_pcm") \
   I(scram_status,          "primary_physics.state.scram_status") \
-  I(has_heat_removal_factor, "")
+  I(has_heat_removal_factor, "=float(hasattr(root, '_last_heat_removal_factor'))")
 
 /* ---- one U-tube steam generator (x3)
  * reference: steam_generator/steam_generator.py:87-112, tsp_fouling_model.py:126-147,175-190,
@@ -155,7 +155,7 @@
   I(status,             "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.status") \
   I(available,          "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.available") \
   I(trip_active,        "secondary_physics.feedwater_system.pump_system.pumps['FWP-{j}'].state.trip_active") \
-  I(trip_reason,        "")
+  I(trip_reason,        "=H.pump_trip_reason(root, {i})")
 
 /* ---- feedwater system level: three-element control, shared cavitation monitor, protection timers
  * reference: feedwater/level_control.py:39-44,137-150, performance_monitoring.py:91-113,
@@ -216,7 +216,7 @@
   F(vibration_displacement, "secondary_physics.turbine.rotor_dynamics.vibration_monitor.displacement_x") \
   F(lub_effectiveness,    "secondary_physics.turbine.bearing_lubrication_system.lubrication_effectiveness") \
   I(trip_active,          "secondary_physics.turbine.protection_system.trip_active") \
-  I(trip_latched_mask,    "")
+  I(trip_latched_mask,    "=H.turbine_trip_mask(root)")
 
 /* ---- turbine, per-stage and metal-temperature arrays: visited one stage at a time, so the kernel
  * streams them straight from / to their SoA columns instead of holding them in registers */
@@ -266,7 +266,7 @@
   I(controller_enabled,     "secondary_physics.ph_control_system.controller.state.controller_enabled") \
   I(ammonia_supply_available, "secondary_physics.ph_control_system.controller.state.ammonia_supply_available") \
   I(morpholine_supply_available, "secondary_physics.ph_control_system.controller.state.morpholine_supply_available") \
-  I(has_pending_effects,    "")
+  I(has_pending_effects,    "=float('ph_control' in getattr(root.secondary_physics.water_chemistry, '_pending_chemistry_effects', {}))")
 
 /* ---- condenser: tube degradation, 3-species fouling, vacuum system with 2 steam-jet ejectors
  * reference: condenser/physics.py:55-71,151-165,540-559, vacuum_system.py:40-52,270-300,
@@ -318,7 +318,7 @@
   F(sg_avg_pressure,          "secondary_physics.steam_generator_system.average_steam_pressure") \
   F(sg_avg_temperature,       "secondary_physics.steam_generator_system.average_steam_temperature") \
   F(sg_avg_quality,           "secondary_physics.steam_generator_system.average_steam_quality") \
-  I(has_previous_sg_conditions, "") \
+  I(has_previous_sg_conditions, "=float(hasattr(root.secondary_physics, '_previous_sg_conditions'))") \
   I(sg_system_availability,   "secondary_physics.steam_generator_system.system_availability")
 
 /* ---- automatic maintenance of the feedwater pumps: what a run observes of the reference's control

@@ -286,6 +286,10 @@ class BatchedPlantEnv:
         m = self._col(magnitude, torch.float64)
         sp = self._col(power_setpoint, torch.float64)
         cw = self._col(cooling_water_temp, torch.float64)
+        if noise_z is None and self._noise is None and self.params.hs_noise_enabled:
+            # ConstantHeatSource(noise_enabled=True, noise_seed=None) draws from an unseeded generator
+            # (constant_heat_source.py:58-62): one fresh, unseeded stream per plant
+            self._noise = HeatSourceNoise(np.random.SeedSequence().generate_state(self.n, dtype=np.uint32), device=self.device)
         if noise_z is None and self._noise is not None:
             noise_z = self._noise.next()
         z = self._col(noise_z, torch.float64)
@@ -392,13 +396,17 @@ class NuclearPlantSimulator:
     against the reference -- ``sim.primary_physics.heat_source.set_power_setpoint(p); sim.step(action=...)``
     (maintenance_scenario_runner.py:383-411, 651-671) -- run unchanged on one lane of the HIP stepper.
 
-    Differences, all explicit: ``enable_state_management=True`` turns on what the path needs of it (the automatic
-    oil_top_off maintenance rule), not the pandas state log; ``secondary_config`` is honoured for the
+    Differences, all explicit: ``enable_state_management=True`` (the reference's default, sim.py:31) turns on what the
+    path needs of it -- the automatic maintenance of the feedwater pumps, with the priority delays of the configuration's
+    ``maintenance_system.maintenance_mode`` (aggressive / ultra_aggressive: none; anything else: 1 h / 4 h / 24 h,
+    sim.py:97-128, auto_maintenance.py:187-198) and the feedwater thresholds of
+    ``maintenance_system.component_configs.feedwater.thresholds`` when the configuration has them -- not the pandas state
+    log; ``secondary_config`` is honoured for the
     initial-condition keys nuclear_sim_amd.scenarios can map (others are listed in ``ignored_initial_conditions``);
     ``reset()`` follows the reference's own reset (default configuration; pinned by tests/golden/r1_*.npz)."""
 
     def __init__(self, dt: float = 1.0, heat_source=None, enable_secondary: bool = True,
-                 enable_state_management: bool = False, max_state_rows: int = 100000, secondary_config=None,
+                 enable_state_management: bool = True, max_state_rows: int = 100000, secondary_config=None,
                  secondary_config_file: Optional[str] = None, device: int = 0):
         if not enable_secondary:
             raise NotImplementedError("the HIP stepper always runs the secondary side")
@@ -415,12 +423,17 @@ class NuclearPlantSimulator:
         params = {"rated_power_mw": float(heat_source.rated_power_mw)}
         if constant:
             params["hs_noise_filter_tau"] = float(heat_source.noise_filter_time_constant)
+        maint_cfg = (secondary_config or {}).get("maintenance_system", {}) if isinstance(secondary_config, dict) else {}
+        if maint_cfg.get("maintenance_mode") not in ("aggressive", "ultra_aggressive") and enable_state_management and secondary_config is not None:
+            params.update(maint_start_delay_hours=1.0, maint_medium_delay_hours=4.0, maint_low_delay_hours=24.0)
+        thresholds = ((maint_cfg.get("component_configs") or {}).get("feedwater") or {}).get("thresholds")
         self._env = BatchedPlantEnv(1, dt=dt, heat_source="constant" if constant else "reactor",
                                     noise_enabled=bool(constant and heat_source.noise_enabled),
                                     noise_std_percent=float(heat_source.noise_std_percent) if constant else 0.1,
                                     noise_seeds=[heat_source.noise_seed] if (constant and heat_source.noise_enabled and
                                                                              heat_source.noise_seed is not None) else None,
-                                    device=device, maintenance=enable_state_management, params=params)
+                                    device=device, maintenance=enable_state_management, params=params,
+                                    maintenance_thresholds=thresholds)
         # the reference's object tree, as far as it is plant state: attribute paths resolve against the schema
         self.primary_physics = _PathProxy(self._env, "primary_physics",
                                           extras={"heat_source": heat_source, "rated_power_mw": heat_source.rated_power_mw})

@@ -104,6 +104,32 @@ class H:
     def last_trigger(root, pump, k):
         return root.maintenance_system.recent_work_order_triggers.get("FWP-%d:%s" % (pump + 1, H.ACTIONS[k]), -1.0)
 
+    # ---- trip reasons: the reference keeps strings; the schema keeps a code / a bit mask
+    PUMP_TRIP_CODES = (("Low Flow", 1), ("NPSH Violation", 2), ("Low Suction Pressure", 3), ("High Discharge Pressure", 4),
+                       ("Steam Generator High Level", 5), ("Severe Cavitation", 6), ("Cavitation Damage Limit", 7),
+                       ("Critical NPSH Violation", 8), ("Lubrication: Very Low Oil Level", 10), ("Lubrication: Low Oil Level", 11),
+                       ("Lubrication: Oil System Overfill", 12), ("Excessive Wear", 13), ("Lubrication: Excessive Seal Leakage", 14),
+                       ("Lubrication: Combined Wear Limit", 15), ("Lubrication: Performance Degradation", 16))
+    TURBINE_TRIP_BITS = {"Overspeed": 1, "High Vibration": 2, "High Bearing Temperature": 4, "Thrust Bearing Displacement": 8,
+                         "Low Vacuum": 16, "High Thermal Stress": 32}
+
+    @staticmethod
+    def pump_trip_reason(root, pump):
+        """FeedwaterPumpState.trip_reason (pump_models.py:261-267, pump_system.py:277-359) -> NPD_TRIP_* code (npd_feedwater.h)"""
+        r = root.secondary_physics.feedwater_system.pump_system.pumps["FWP-%d" % (pump + 1)].state.trip_reason or ""
+        if not r:
+            return 0.0
+        for text, code in H.PUMP_TRIP_CODES:
+            if (r.startswith(text) if not text.startswith("Excessive Wear") else r.endswith("Excessive Wear")):
+                return float(code)
+        raise ValueError("unmapped pump trip reason %r" % r)
+
+    @staticmethod
+    def turbine_trip_mask(root):
+        """TurbineProtectionSystem.trip_reasons (turbine/enhanced_physics.py:348-436: appended once, never removed until a
+        reset) -> bit mask in the order of the six checks"""
+        return float(sum(H.TURBINE_TRIP_BITS[r] for r in root.secondary_physics.turbine.protection_system.trip_reasons))
+
     @staticmethod
     def executed(root, k):
         n = 0

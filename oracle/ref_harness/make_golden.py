@@ -121,6 +121,52 @@ def scenarios():
              [(W % (2, "pump_bearings"), 6.0)])):
         S.append(dict(name="m13" + tag, steps=14, dt=5.0, noise=True, noise_seed=42, every=1, thresholds_override=override, init_pokes=pokes,
                       runner=dict(action="oil_top_off", duration_hours=2.0)))
+    # C1-C5: branches no other fixture visits (tests/test_fixture_coverage.py lists what varies where)
+    FP = "secondary_physics.feedwater_system.pump_system.pumps['FWP-%d']"
+    SGP = "secondary_physics.steam_generator_system.steam_generators[%d].tsp_fouling.deposits.%s_thickness[%d]"
+    # C1: the pump state machine's transient states: FWP-3 sent into coast-down (STOPPING -> STOPPED), later into start-up
+    # (STARTING -> RUNNING); both are what stop_pump() / start_pump() set (pump_models.py:148-164)
+    S.append(dict(name="c1_pump_stopping_starting", steps=60, noise=True, noise_seed=9, every=1,
+                  pokes={10: [(FP % 3 + ".state.status", "=PumpStatus.STOPPING")], 35: [(FP % 3 + ".state.status", "=PumpStatus.STARTING")],
+                         45: [(FP % 4 + ".state.status", "=PumpStatus.STARTING")]}))
+    # C2: TSP deposits thick enough for the fouling model's shutdown protection (tsp_fouling_model.py:654-724)
+    S.append(dict(name="c2_tsp_shutdown", steps=40, noise=True, noise_seed=9, every=2,
+                  init_pokes=[(SGP % (0, sp, k), v) for sp, v in (("magnetite", 4.0), ("copper", 2.0), ("silica", 2.5)) for k in range(7)]
+                             + [(SGP % (1, "magnetite", k), 3.5) for k in range(3)]      # SG 2: uneven over the levels (flow maldistribution)
+                             + [(SGP % (2, sp, k), v) for sp, v in (("magnetite", 4.1), ("copper", 2.0), ("silica", 2.0)) for k in range(7)]))
+    # C3: NPSH collapse on one pump: pump trip by NPSH, then the system protection's low-low NPSH timer and trip
+    # (protection_system.py:59-125), critical NPSH (< 4 m) on another
+    S.append(dict(name="c3_npsh_collapse", steps=50, noise=True, noise_seed=9, every=1,
+                  pokes={12: [(FP % 1 + ".state.npsh_available", 0.05)], 30: [(FP % 2 + ".state.npsh_available", 3.0)],
+                         # the shared NPSHProtection is visited once per pump, in order, and a healthy pump clears the latch
+                         # again: only the LAST pump's collapse is left standing after a step
+                         40: [(FP % 4 + ".state.npsh_available", 0.05)]}))
+    # C4: turbine protection: a thermal bow large enough for the vibration trip, on top of the thermal-expansion trip every
+    # dt = 1 run reaches (turbine/enhanced_physics.py:348-436); latched reasons recorded as a bit mask
+    S.append(dict(name="c4_turbine_vibration_trip", steps=50, noise=True, noise_seed=9, every=1,
+                  pokes={8: [("secondary_physics.turbine.rotor_dynamics.thermal_bow", 2.0)]}))
+    # C5: NaN poked into the primary state THROUGH THE REFERENCE: check_for_nan_values resets five fields
+    # (thermal_hydraulics.py:247-270); what the NaN did to the step it entered is part of the fixture
+    S.append(dict(name="c5_nan_reset", steps=40, heat_source="reactor", equilibrium=(100.0, 95.0), every=1,
+                  pokes={10: [("primary_physics.state.fuel_temperature", "=nan")], 25: [("primary_physics.state.coolant_pressure", "=nan")]}))
+    # C6: the remaining reachable pump trip reasons, three pumps at a time (a tripped pump is put back to RUNNING by hand, as
+    # reset_trip() + start would).  Unreachable by construction: low flow (a RUNNING pump's flow is floored at 5 % of rated =
+    # the trip value, pump_system.py:205-216 vs pump_models.py:251-259), high discharge pressure (the system condition is the
+    # constant 7.4 MPa), oil overfill and seal leakage (both clamped below their trip values by the lubrication update).
+    LW = FP + ".lubrication_system.component_wear['%s']"
+    back = lambda j: [(FP % j + ".state.status", "=PumpStatus.RUNNING"), (FP % j + ".state.trip_active", False), (FP % j + ".state.available", True)]
+    S.append(dict(name="c6_pump_trip_reasons", steps=60, noise=True, noise_seed=9, every=1, pokes={
+        5: [(FP % 1 + ".state.suction_pressure", 0.15),                                   # Low Suction Pressure
+            (FP % 2 + ".state.cavitation_damage", 10.5),                                  # Cavitation Damage Limit
+            (FP % 3 + ".lubrication_system.oil_level", 4.0)],                             # Lubrication: Very Low Oil Level
+        20: back(1) + back(2) + back(3) + [(FP % 1 + ".state.suction_pressure", 0.5), (FP % 2 + ".state.cavitation_damage", 0.0),
+                                           (FP % 3 + ".lubrication_system.oil_level", 100.0)],
+        25: [(FP % 1 + ".state.cavitation_intensity", 0.8),                               # Severe Cavitation
+             (LW % (2, "impeller"), 26.0),                                                # Lubrication: Impeller Excessive Wear
+             (LW % (3, "motor_bearings"), 14.0), (LW % (3, "pump_bearings"), 14.0), (LW % (3, "thrust_bearing"), 14.0)],   # Combined Wear Limit
+        40: back(1) + back(2) + back(3) + [(LW % (2, "impeller"), 0.0), (LW % (3, "motor_bearings"), 0.0), (LW % (3, "pump_bearings"), 0.0),
+                                           (LW % (3, "thrust_bearing"), 0.0)],
+        45: [(LW % (1, "motor_bearings"), 55.0), (LW % (1, "pump_bearings"), 45.0), (LW % (1, "thrust_bearing"), 35.0)]}))   # (component wear first: 13)
     # R1-R3: NuclearPlantSimulator.reset() (sim.py:546-581) in the middle of a run -- the reference's reset is not a
     # re-construction (parts of the history survive, start_at_steady_state force-sets the secondary side and advances the
     # steam generators once), so the state it leaves and the trajectory after it are pinned here
@@ -151,14 +197,15 @@ def main(only=None):
         every = sc.get("every", 1)
         steps = sorted(set(list(range(0, T + 1, every)) + [T] + [t + 1 for t in sc.get("pokes", {})] + list(sc.get("pokes", {}).keys())
                            + [t for t in sc.get("resets", {})] + [t + 1 for t in sc.get("resets", {})]))
-        meta = {k: v for k, v in sc.items() if not callable(v) and k not in ("pokes", "resets", "_maint_thresholds")}
+        meta = {k: v for k, v in sc.items() if not callable(v) and k not in ("pokes", "resets", "_maint_thresholds", "init_pokes")}
         if sc.get("_maint_thresholds"):
             meta["maint_thresholds"] = sc["_maint_thresholds"]   # the FWP thresholds dict the run used, in its order
         meta["resets"] = {str(k): bool(v) for k, v in sc.get("resets", {}).items()}
-        meta["pokes"] = {str(k): [[p, float(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
+        meta["pokes"] = {str(k): [[p, trace.poke_number(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
+        meta["init_pokes"] = [[p, trace.poke_number(v)] for p, v in sc.get("init_pokes", [])]
         # pokes expressed in schema labels so tests can replay them without the reference
         path_to_label = {c[3]: (c[0], c[1], c[2]) for c in cols}
-        meta["pokes_schema"] = {str(k): [[p, float(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
+        meta["pokes_schema"] = {str(k): [[p, trace.poke_number(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
         np.savez_compressed(os.path.join(OUT, sc["name"] + ".npz"),
                             action=ref["action"], magnitude=ref["magnitude"], setpoint=ref["setpoint"],
                             cooling=ref["cooling"], noise_z=ref["noise_z"], obs=ref["obs"], reward=ref["reward"],

@@ -41,6 +41,22 @@ def _val(sim, path):
         return np.nan
 
 
+def poke_value(v):
+    """a poke's value: a number, or "=<expr>" evaluated with the reference's enums in scope (e.g. "=PumpStatus.STOPPING")"""
+    if isinstance(v, str) and v.startswith("="):
+        from systems.primary.coolant.pump_models import PumpStatus
+        return eval(v[1:], {"PumpStatus": PumpStatus, "nan": float("nan"), "inf": float("inf")})
+    return v
+
+
+def poke_number(v):
+    """the same value as the number a schema column holds (enums by declaration index, as _val reads them)"""
+    v = poke_value(v)
+    if isinstance(v, enum.Enum):
+        return float(v.value) if isinstance(v.value, (int, float)) else float(list(type(v)).index(v))
+    return float(v)
+
+
 def run_reference(sc, columns):
     """columns: SCHEMA.columns(). Returns dict of arrays."""
     refsim.setup()
@@ -69,7 +85,7 @@ def run_reference(sc, columns):
         sim.primary_physics.state = st
         sim.state = st
     for path, v in sc.get("init_pokes", []):
-        exec("sim.%s = v" % path, {"sim": sim, "v": v})
+        exec("sim.%s = v" % path, {"sim": sim, "v": poke_value(v)})
     T = sc["steps"]
     paths = [c[3] for c in columns]
     state = np.full((T + 1, len(paths)), np.nan)
@@ -86,7 +102,7 @@ def run_reference(sc, columns):
     reset_steps, reset_modes, reset_obs, reset_state = [], [], [], []
     for t in range(T):
         for path, v in sc.get("pokes", {}).get(t, []):
-            exec("sim.%s = v" % path, {"sim": sim, "v": v})
+            exec("sim.%s = v" % path, {"sim": sim, "v": poke_value(v)})
         if t in resets:
             with refsim.quiet():
                 ob = sim.reset(start_at_steady_state=bool(resets[t]))

@@ -302,7 +302,8 @@ def test_single_plant_facade_runs_the_data_gen_loop():
     ic["pump_oil_levels"] = [58.3, 58.1, 98.0, 57.0]
     cfg = {"secondary_system": {"feedwater": {"initial_conditions": ic},
                                 "steam_generator": {"initial_conditions": scenarios.ACTION_TEST_TEMPLATE["steam_generator"]},
-                                "turbine": {"initial_conditions": scenarios.ACTION_TEST_TEMPLATE["turbine"]}}}
+                                "turbine": {"initial_conditions": scenarios.ACTION_TEST_TEMPLATE["turbine"]}},
+           "maintenance_system": {"maintenance_mode": "aggressive"}}     # as the composer's action-test configuration has it
     hs = ConstantHeatSource(rated_power_mw=3000.0, noise_enabled=True, noise_std_percent=0.1, noise_seed=42)
     sim = NuclearPlantSimulator(heat_source=hs, dt=5.0, enable_secondary=True, enable_state_management=True, secondary_config=cfg)
     assert not sim.ignored_initial_conditions
@@ -328,7 +329,7 @@ def test_facade_reset_follows_the_reference(name):
     g = Golden(name)
     hs = ConstantHeatSource(rated_power_mw=3000.0, noise_enabled=True, noise_std_percent=0.1, noise_seed=g.meta["noise_seed"])
     cfg = {"secondary_system": g.meta["secondary"]} if g.meta.get("secondary") else None
-    sim = NuclearPlantSimulator(heat_source=hs, dt=1.0, secondary_config=cfg)
+    sim = NuclearPlantSimulator(heat_source=hs, dt=1.0, secondary_config=cfg, enable_state_management=False)   # as the fixture's run
     assert not sim.ignored_initial_conditions
     for t in range(g.T):
         if t in g.resets:
