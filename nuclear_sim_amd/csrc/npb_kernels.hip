@@ -530,7 +530,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   const int sg_system_availability = sg_effective >= (NPB_NUM_SG - 1);
 
   double electrical_power = 0.0, thermal_efficiency = 0.0, condenser_pressure = 0.007;
-  double total_system_heat_rejection = 0.0;
+  double total_system_heat_rejection = 0.0, turbine_gross_power = 0.0;
   if (full) {
     NPD_STAMP(11);
     /* ================= phase 3: turbine (dt in hours, load demand in PERCENT, :564-569) ========== */
@@ -583,6 +583,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     NPD_STAMP(20);
     /* ================= electrical-power gates (:750-932) ================= */
     double turbine_electrical_power = tr.electrical_power_net;
+    turbine_gross_power = tr.electrical_power_gross;
     total_system_heat_rejection = (primary_thermal_power - turbine_electrical_power) * 1e6;
     double power_reduction_factor = 1.0;
     if (fw_total_flow < 300.0) power_reduction_factor = 0.0;
@@ -664,6 +665,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     info[NPB_INFO_CONDENSER_PRESSURE] = isfinite(condenser_pressure) ? condenser_pressure : 0.007;
     info[NPB_INFO_CONDENSER_HEAT_REJECTION] = isfinite(total_system_heat_rejection) ? total_system_heat_rejection : 0.0;
     info[NPB_INFO_FEEDWATER_FLOW] = fw_total_flow;
+    info[NPB_INFO_SG_HEAT_TRANSFER] = sg_total_thermal; info[NPB_INFO_TURBINE_POWER] = turbine_gross_power;
+    info[NPB_INFO_FEEDWATER_POWER] = fw_total_power; info[NPB_INFO_PRIMARY_THERMAL_POWER] = primary_thermal_power;
     npd_store_rows<NPB_INFO_DIM>(info, info_out, lds, block_base, (size_t)n_plants);
   }
   NPD_STAMP(22);

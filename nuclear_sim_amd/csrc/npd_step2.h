@@ -76,7 +76,7 @@ enum {
   /* tail scalars for reward / info (reuses X_PSELF ...) */
   X_TAIL = 0,
   /* transposes */
-  X_OBS = 20, X_INFO = 46
+  X_OBS = 22, X_INFO = 46
 };
 static_assert(X_PUMP + 4 * X_PUMP_N <= X_SGCARRY && X_SGCARRY + 6 <= X_FLAG2 && X_OBS + NPB_OBS_PAD <= X_INFO && X_INFO + NPB_OBS_PAD <= X_MAXSTRESS, "exchange slot plan");
 
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(
     XW(X_TAIL + 8, thermal_power_info); XW(X_TAIL + 9, reactivity_info); XW(X_TAIL + 10, time_info);
     XW(X_TAIL + 11, sg_total_thermal); XW(X_TAIL + 12, sg_avg_temperature); XW(X_TAIL + 13, sg_avg_quality);
     XW(X_TAIL + 14, (double)(sg_system_availability | (fw_available << 1))); XW(X_TAIL + 15, prev_feedwater_temp); XW(X_TAIL + 16, cw_old);
-    XW(X_TAIL + 17, operating_hours);
+    XW(X_TAIL + 17, operating_hours); XW(X_TAIL + 18, t.total_power_output); XW(X_TAIL + 19, fw_total_power); XW(X_TAIL + 20, primary_thermal_power);
     NPD2_SYNCJ(11);                                                                                     /* #9 */
     /* ---- observation, done, trip flags: the primary part (sim.py:290-333) from the primary section as stored in phase 0
      * (carried members: the stored value is the value; power_level, an output member, was kept) */
@@ -828,6 +828,8 @@ __global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(
       info[NPB_INFO_CONDENSER_PRESSURE] = isfinite(condenser_pressure) ? condenser_pressure : 0.007;
       info[NPB_INFO_CONDENSER_HEAT_REJECTION] = isfinite(heat_rejection) ? heat_rejection : 0.0;
       info[NPB_INFO_FEEDWATER_FLOW] = fw_total_flow_t;
+      info[NPB_INFO_SG_HEAT_TRANSFER] = XR(X_TAIL + 11); info[NPB_INFO_TURBINE_POWER] = XR(X_TAIL + 18);
+      info[NPB_INFO_FEEDWATER_POWER] = XR(X_TAIL + 19); info[NPB_INFO_PRIMARY_THERMAL_POWER] = XR(X_TAIL + 20);
       npd2_store_rows<NPB_INFO_DIM>(info, info_out, xch + X_INFO * NPB_WAVE, lane, block_base, (size_t)n_plants);
     }
   }

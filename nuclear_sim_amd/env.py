@@ -42,7 +42,8 @@ class ControlAction(enum.Enum):
 
 
 INFO_COLUMNS = ("thermal_power", "reactivity", "electrical_power", "thermal_efficiency", "steam_flow",
-                "steam_pressure", "condenser_pressure", "condenser_heat_rejection", "time", "feedwater_flow")
+                "steam_pressure", "condenser_pressure", "condenser_heat_rejection", "time", "feedwater_flow",
+                "sg_heat_transfer", "turbine_power", "feedwater_power", "primary_thermal_power")
 
 
 class HeatSourceNoise:
@@ -147,7 +148,7 @@ class BatchedPlantEnv:
             self._reward = torch.zeros(self.n, dtype=torch.float64, device=self.device)
             self._done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
             self._flags = torch.zeros(self.n, dtype=torch.int32, device=self.device)
-            self._info = torch.zeros((self.n, 10), dtype=torch.float64, device=self.device)
+            self._info = torch.zeros((self.n, len(INFO_COLUMNS)), dtype=torch.float64, device=self.device)
         self._noise = None
         if noise_enabled and noise_seeds is not None:
             self._noise = HeatSourceNoise(noise_seeds, device=self.device)
@@ -280,6 +281,18 @@ class BatchedPlantEnv:
         _lib.check(self.L.npb_observe(self._h, self._p(self._obs), self._stream()), self._h)
         return self._obs
 
+    def secondary_result(self) -> Dict[str, torch.Tensor]:
+        """info["secondary_system"] of the reference for every plant, as columns, for the step just taken (one gather launch)"""
+        if getattr(self, "_sec_plan", None) is None:
+            ks = [SCHEMA.slot(name) for name in SECONDARY_RESULT_MEMBERS]
+            self._sec_plan = ((ctypes.c_int * len(ks))(*[0 if kd == "f64" else 1 for kd, _ in ks]), (ctypes.c_int * len(ks))(*[sl for _, sl in ks]))
+            self._sec_buf = torch.empty((len(ks), self.n), dtype=torch.float64, device=self.device)
+        _lib.check(self.L.npb_gather_fields(self._h, len(SECONDARY_RESULT_MEMBERS), self._sec_plan[0], self._sec_plan[1],
+                                            ctypes.c_void_p(self._sec_buf.data_ptr()), self._stream()), self._h)
+        members = {name: self._sec_buf[j] for j, name in enumerate(SECONDARY_RESULT_MEMBERS)}
+        info = {name: self._info[:, j] for j, name in enumerate(INFO_COLUMNS)}
+        return secondary_result(info, members)
+
     def step(self, action=None, magnitude=None, power_setpoint=None, cooling_water_temp=None, noise_z=None):
         self._keep = []
         a = self._col(None if action is None else action, torch.int32)
@@ -302,6 +315,81 @@ class BatchedPlantEnv:
         if self.params.maint_enabled:  # bit-exact counterpart of AutoMaintenanceSystem.maintenance_actions_performed
             info["maintenance_event_count"] = self.get_field("maint.maintenance_actions_performed")
         return self._obs, self._reward, self._done, info
+
+
+def secondary_result(info: Dict[str, torch.Tensor], members: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The scalar keys of the reference's info["secondary_system"] (SecondaryReactorPhysics.update_system's result dict,
+    secondary/__init__.py:922-1010) as columns, including its heat-flow and chemistry-flow tracker outputs
+    (heat_flow_tracker.py:248-351, chemistry_flow_tracker.py:472-666; consumed at secondary/__init__.py:979-994).
+    ``info`` = the step's fp64 info columns, ``members`` = the state members named in SECONDARY_RESULT_MEMBERS.
+    The trackers are bookkeeping on top of quantities the step already has: the heat-flow state is closed-form in the SG
+    heat transfer, the turbine power and the feedwater pump power (secondary/__init__.py:679-744); the chemistry-flow tracker
+    looks its providers' states up under ChemicalSpecies names that none of them uses ("ph", "iron" ... vs
+    "water_chemistry_ph" ...), so every lookup takes its default and its seven outputs are constants."""
+    f = {}
+    total_heat_transfer = info["sg_heat_transfer"]; turbine_gross = info["turbine_power"]; fw_power = info["feedwater_power"]
+    electrical = info["electrical_power"]
+    zero = torch.zeros_like(electrical); one = torch.ones_like(electrical)
+    f["electrical_power_mw"] = members["sec.electrical_power_output"]
+    f["thermal_efficiency"] = members["sec.thermal_efficiency"]
+    f["heat_rate_kj_kwh"] = torch.where(electrical > 0, (total_heat_transfer / 1000.0) / (electrical * 1000.0) * 3600.0, zero)
+    f["total_steam_flow"] = info["steam_flow"]; f["total_heat_transfer"] = total_heat_transfer; f["sg_total_heat_transfer"] = total_heat_transfer
+    f["total_feedwater_flow"] = info["feedwater_flow"]; f["feedwater_total_flow"] = info["feedwater_flow"]
+    f["sg_avg_pressure"] = info["steam_pressure"]
+    # reported (not used by the turbine) as max(SG average, saturation temperature at the average pressure)
+    # secondary/__init__.py:551-552 with _saturation_temperature :1455-1491
+    pr = info["steam_pressure"] / 0.101325
+    sat = 1.0 / (1.0 / (100.0 + 273.15) - (0.4615 / 2257.0) * torch.log(pr.clamp_min(1e-300))) - 273.15
+    sat = torch.where(info["steam_pressure"] <= 0.001, torch.full_like(sat, 10.0), sat.clamp(10.0, 374.0))
+    f["sg_avg_temperature"] = torch.maximum(members["sec.sg_avg_temperature"], sat); f["sg_avg_steam_quality"] = members["sec.sg_avg_quality"]
+    mechanical = turbine_gross / 0.985
+    f["turbine_mechanical_power"] = mechanical; f["turbine_electrical_power_gross"] = turbine_gross
+    f["turbine_electrical_power_net"] = turbine_gross * 0.98
+    f["turbine_steam_rate"] = torch.where(turbine_gross > 0, info["steam_flow"] / (turbine_gross * 1000) * 3600, zero)
+    f["condenser_heat_rejection"] = members["cond.heat_rejection_rate"]; f["condenser_pressure"] = info["condenser_pressure"]
+    f["condenser_vacuum_efficiency"] = members["cond.vacuum_system_efficiency"]
+    f["total_system_heat_rejection"] = info["condenser_heat_rejection"]
+    f["feedwater_total_power"] = fw_power
+    mask = members["fw.running_mask"].to(torch.int64)
+    f["feedwater_num_running_pumps"] = ((mask & 1) + ((mask >> 1) & 1) + ((mask >> 2) & 1) + ((mask >> 3) & 1)).to(torch.float64)
+    f["feedwater_system_available"] = members["fw.system_availability"]
+    # ---- HeatFlowTracker: component flows secondary/__init__.py:686-736, system state heat_flow_tracker.py:248-322
+    sg_in = total_heat_transfer / 1e6; sg_out = total_heat_transfer * 0.98 / 1e6; sg_loss = total_heat_transfer * 0.02 / 1e6
+    turb_loss = mechanical * 0.05
+    fw_loss = fw_power * 0.1
+    total_losses = (sg_loss + turb_loss + fw_loss)
+    required_rejection = sg_in - mechanical - total_losses
+    cond_loss = required_rejection * 0.01
+    gen_out = mechanical * 0.985; gen_loss = mechanical - gen_out
+    aux = gen_out * 0.02; net = gen_out - aux
+    total_in = (sg_in + fw_power)
+    total_out = (net + required_rejection + sg_loss + turb_loss + cond_loss + fw_loss + gen_loss + 0.0)
+    err = total_in - total_out
+    pct = torch.where(total_in > 0, (err / total_in) * 100.0, zero)
+    f["heat_flow_energy_balance_error"] = err; f["heat_flow_energy_balance_percent"] = pct
+    f["heat_flow_balance_ok"] = (pct.abs() < (0.01 * 100)).to(torch.float64)
+    f["heat_flow_condenser_heat_rejection"] = required_rejection; f["heat_flow_net_electrical_output"] = net
+    f["heat_flow_overall_efficiency"] = torch.where(total_in > 0, net / total_in, zero)
+    # ---- ChemistryFlowTracker: every provider lookup falls through to its default (see the docstring)
+    f["chemistry_flow_balance_error"] = zero; f["chemistry_flow_balance_ok"] = one; f["chemistry_flow_ph"] = one * 9.2
+    f["chemistry_flow_iron_concentration"] = one * 0.1; f["chemistry_flow_tsp_fouling_rate"] = zero
+    f["chemistry_flow_treatment_efficiency"] = one; f["chemistry_flow_stability"] = one * 0.5
+    # ---- shared WaterChemistry and the pH controller
+    f["water_chemistry_ph"] = members["chem.ph"]; f["water_chemistry_iron_concentration"] = one * 0.1
+    f["water_chemistry_aggressiveness"] = members["chem.water_aggressiveness"]
+    f["water_chemistry_treatment_efficiency"] = members["chem.treatment_efficiency"]
+    f["ph_control_output"] = members["ph.controller_output"]; f["ph_control_ammonia_dose"] = members["ph.pending_ammonia_dose"]
+    f["ph_control_error"] = members["ph.previous_error"]
+    f["load_demand"] = members["sec.load_demand"]; f["feedwater_temperature"] = one * 227.0
+    f["cooling_water_inlet_temp"] = members["sec.cooling_water_temperature"]; f["cooling_water_outlet_temp"] = members["cond.cooling_water_outlet_temp"]
+    return f
+
+
+SECONDARY_RESULT_MEMBERS = ("sec.electrical_power_output", "sec.thermal_efficiency", "sec.sg_avg_temperature", "sec.sg_avg_quality",
+                            "cond.heat_rejection_rate", "cond.vacuum_system_efficiency", "fw.running_mask", "fw.system_availability",
+                            "chem.ph", "chem.water_aggressiveness", "chem.treatment_efficiency", "ph.controller_output",
+                            "ph.pending_ammonia_dose", "ph.previous_error", "sec.load_demand", "sec.cooling_water_temperature",
+                            "cond.cooling_water_outlet_temp")
 
 
 class ConstantHeatSource:
@@ -500,23 +588,10 @@ class NuclearPlantSimulator:
         return {"observation": o, "reward": float(rew[0].item()), "done": bool(done[0].item()), "info": inf}
 
     def _secondary_result(self) -> Dict[str, float]:
-        """The scalars of the reference's info["secondary_system"] (secondary/__init__.py:930-1010) that are plant state:
-        which key is which member was established on a reference run, series for series (state_names.json)."""
-        if getattr(self, "_sec_keys", None) is None:
-            import json as _json
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "state_names.json")) as fh:
-                keys = _json.load(fh)["secondary_result_keys"]
-            labels = {c[2]: (c[0], c[1]) for c in SCHEMA.columns()}
-            self._sec_keys = [(k, labels[lab]) for k, lab in sorted(keys.items())]
-            nf = len(self._sec_keys)
-            self._sec_kinds = (ctypes.c_int * nf)(*[0 if kd == "f64" else 1 for _k, (kd, _s) in self._sec_keys])
-            self._sec_slots = (ctypes.c_int * nf)(*[sl for _k, (_kd, sl) in self._sec_keys])
-            self._sec_buf = torch.empty((nf, 1), dtype=torch.float64, device=self._env.device)
-        env = self._env
-        _lib.check(env.L.npb_gather_fields(env._h, len(self._sec_keys), self._sec_kinds, self._sec_slots,
-                                           ctypes.c_void_p(self._sec_buf.data_ptr()), env._stream()), env._h)
-        vals = self._sec_buf[:, 0].cpu().numpy()
-        return {k: float(v) for (k, _), v in zip(self._sec_keys, vals)}
+        """info["secondary_system"]: every scalar key of the reference's result dict (secondary/__init__.py:922-1010) that is a
+        function of what the step produces -- 50 of its 56 scalars; turbine_efficiency, turbine_hp_power, turbine_lp_power,
+        condenser_cooling_water_temp_rise, condenser_thermal_performance and feedwater_auto_control are not carried."""
+        return {k: float(v[0].item()) for k, v in self._env.secondary_result().items()}
 
     def reset(self, start_at_steady_state: bool = True):
         """sim.py:546-581: the reference's reset (not a re-construction); the configured feedwater initial conditions

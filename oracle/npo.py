@@ -178,7 +178,7 @@ class OraclePlants:
         a = col(action, np.int32); m = col(magnitude, np.float64); sp = col(setpoint, np.float64)
         z = col(noise_z, np.float64); cw = col(cw_temp, np.float64)
         obs = np.zeros((n, 22)); rew = np.zeros(n); done = np.zeros(n, dtype=np.uint8)
-        flags = np.zeros(n, dtype=np.uint32); info = np.zeros((n, 10))
+        flags = np.zeros(n, dtype=np.uint32); info = np.zeros((n, 14))
         self.L.npo_step_batch(_ptr(self._buf), n, self.params.ptr, _ptr(a), _ptr(m), _ptr(sp), _ptr(z), _ptr(cw),
                               _ptr(obs), _ptr(rew), _ptr(done), _ptr(flags), _ptr(info))
         return obs, rew, done, flags, info

@@ -21,6 +21,7 @@ typedef struct npo_secondary_result_t {
   double electrical_power_mw, thermal_efficiency, total_steam_flow, sg_avg_pressure;
   double condenser_pressure, total_system_heat_rejection;
   double feedwater_total_flow, feedwater_total_power;
+  double sg_total_heat_transfer, turbine_power_output, primary_thermal_power;
   int feedwater_system_available;
   uint32_t trip_flags;
 } npo_secondary_result_t;
@@ -79,6 +80,8 @@ NPO_FN void npo_secondary_update(npo_plant_t *pl, const npb_params_t *P, const n
     r->condenser_pressure = 0.007;
     r->feedwater_total_flow = sgr.total_steam_flow;
     r->feedwater_system_available = 1;
+    r->sg_total_heat_transfer = sgr.total_thermal_power;
+    for (int i = 0; i < NPB_NUM_SG; i++) r->primary_thermal_power += c->thermal_power[i];
     return;
   }
   /* ---- STEP 1: feedwater system first, fed with the PREVIOUS step's SG conditions (:442-491) */
@@ -171,6 +174,8 @@ NPO_FN void npo_secondary_tail(npo_plant_t *pl, const npb_params_t *P, const npo
   r->feedwater_total_flow = fwr->total_flow_rate;
   r->feedwater_total_power = fwr->total_power_consumption;
   r->feedwater_system_available = fwr->system_availability;
+  r->sg_total_heat_transfer = sgr->total_thermal_power; r->turbine_power_output = tr.electrical_power_gross;
+  r->primary_thermal_power = primary_thermal_power;
   r->trip_flags = (fwr->pump_trip_mask << 8) | (pl->fw.system_trip_active ? NPB_TRIP_FW_SYSTEM : 0) |
                   (tr.trip_active ? NPB_TRIP_TURBINE : 0);
 }

@@ -115,6 +115,8 @@ NPO_FN void npo_step(npo_plant_t *pl, const npb_params_t *P, const npo_inputs_t 
   out->info[NPB_INFO_CONDENSER_HEAT_REJECTION] = npo_finite_or(r.total_system_heat_rejection, 0.0);
   out->info[NPB_INFO_TIME] = s->sim_time;
   out->info[NPB_INFO_FEEDWATER_FLOW] = r.feedwater_total_flow;
+  out->info[NPB_INFO_SG_HEAT_TRANSFER] = r.sg_total_heat_transfer; out->info[NPB_INFO_TURBINE_POWER] = r.turbine_power_output;
+  out->info[NPB_INFO_FEEDWATER_POWER] = r.feedwater_total_power; out->info[NPB_INFO_PRIMARY_THERMAL_POWER] = r.primary_thermal_power;
 
   /* maintenance_system.update + state_manager.collect_states  sim.py:208-223; nothing they touch
    * feeds the observation, reward or info built above */

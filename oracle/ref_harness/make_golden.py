@@ -211,7 +211,7 @@ def main(only=None):
                             cooling=ref["cooling"], noise_z=ref["noise_z"], obs=ref["obs"], reward=ref["reward"],
                             done=ref["done"], info=ref["info"], state_steps=np.array(steps),
                             reset_steps=ref["reset_steps"], reset_modes=ref["reset_modes"], reset_obs=ref["reset_obs"],
-                            reset_state=ref["reset_state"],
+                            reset_state=ref["reset_state"], sec_keys=ref["sec_keys"], sec=ref["sec"],
                             state=ref["state"][steps], labels=labels, kinds=kinds, paths=paths, meta=json.dumps(meta))
         print(sc["name"], "steps", T, "dones", int(ref["done"].sum()), "elec", float(ref["obs"][-1, 12] * 1100))
 

@@ -98,6 +98,7 @@ def run_reference(sc, columns):
     if sc.get("noise", False):
         z[:] = np.random.RandomState(sc.get("noise_seed", 42)).standard_normal(T)
     actions = sc.get("actions")
+    sec_keys, sec_rows = None, []
     resets = sc.get("resets", {})
     reset_steps, reset_modes, reset_obs, reset_state = [], [], [], []
     for t in range(T):
@@ -135,9 +136,14 @@ def run_reference(sc, columns):
                    i.get("steam_pressure", np.nan), i.get("condenser_pressure", np.nan),
                    i.get("condenser_heat_rejection", np.nan), i["time"],
                    i["secondary_system"]["feedwater_total_flow"] if "secondary_system" in i else np.nan]
+        ss = i.get("secondary_system", {})
+        if sec_keys is None:   # every scalar key of SecondaryReactorPhysics.update_system's result (secondary/__init__.py:922-1010)
+            sec_keys = [k for k, v in ss.items() if isinstance(v, (bool, int, float, np.floating, np.integer, np.bool_))]
+        sec_rows.append([float(ss[k]) for k in sec_keys])
         state[t + 1] = [_val(sim, p) for p in paths]
     return dict(state=state, obs=obs, reward=rew, done=done, info=info,
                 action=act, magnitude=mag, setpoint=sp, cooling=cw, noise_z=z,
+                sec_keys=np.array(sec_keys or []), sec=np.array(sec_rows, dtype=np.float64).reshape(T, len(sec_keys or [])),
                 reset_steps=np.array(reset_steps, dtype=np.int64), reset_modes=np.array(reset_modes, dtype=np.int64),
                 reset_obs=np.array(reset_obs, dtype=np.float64).reshape(len(reset_steps), 22),
                 reset_state=np.array(reset_state, dtype=np.float64).reshape(len(reset_steps), len(paths))), sim

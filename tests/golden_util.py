@@ -43,6 +43,9 @@ class Golden:
                 st[:, j] = raw[:, idx[c[3]]]
         self.state = st
         self.cols = cols
+        # the scalar keys of info["secondary_system"] per step (fixtures made before they were recorded have none)
+        self.sec_keys = [str(k) for k in z["sec_keys"]] if "sec_keys" in z.files else []
+        self.sec = z["sec"] if "sec" in z.files else None
         # NuclearPlantSimulator.reset() calls recorded in the run: {step: (start_at_steady_state, obs, state row)}
         self.resets = {}
         if "reset_steps" in z.files:

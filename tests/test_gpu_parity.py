@@ -94,6 +94,17 @@ def test_hip_replays_golden(name):
             fs, is_ = _host_state(env)
             compare_state(g, fs[:, 0], is_[:, 0], g.state[sampled[t + 1]], "after step %d" % t)
             compare_state(g, fs[:, n - 1], is_[:, n - 1], g.state[sampled[t + 1]], "after step %d (lane 63)" % t)
+        if g.sec is not None and t % 7 == 0:
+            # the scalar keys of the reference's info["secondary_system"], heat-flow / chemistry-flow tracker outputs included
+            res = env.secondary_result()
+            checked = 0
+            for k, col in res.items():
+                if k in g.sec_keys:
+                    want = g.sec[t, g.sec_keys.index(k)]
+                    # energy_balance_error is a ~1e-3 difference of ~3000 MW sums: absolute floor 1e-9 MW
+                    np.testing.assert_allclose(col[0].item(), want, rtol=RTOL, atol=1e-9, err_msg="%s secondary_system[%s] step %d" % (name, k, t))
+                    checked += 1
+            assert checked >= 45, checked
 
 
 @pytest.mark.parametrize("heat_source,mode", [("constant", "full"), ("reactor", "full"), ("reactor", "primary_sg")])
