@@ -232,6 +232,48 @@ def make_ic_fixture(action="oil_top_off", seeds=tuple(range(12))):
     print("ic_%s: %d seeds" % (action, len(seeds)))
 
 
+def _ic_rows(job):
+    """worker of make_ic_check: (action, subsystem, seeds) -> rows of initial states, one per seed"""
+    from . import refsim
+    a, sub, seeds = job
+    cols = SCHEMA.columns()
+    out = []
+    for sd in seeds:
+        try:
+            _runner, sim = refsim.make_runner_sim(action=a, duration_hours=2.0, randomization_seed=sd)
+        except Exception as e:
+            out.append((a, sub, sd, None, type(e).__name__)); continue
+        out.append((a, sub, sd, [trace._val(sim, c[3]) for c in cols], ""))
+    return out
+
+
+def make_ic_check(seeds=(11, 12, 13, 14, 15, 16, 17, 18), procs=8):
+    """tests/golden/ic_all_actions_check.npz: for every action of the composer's map, the reference constructor's initial state
+    for EIGHT MORE randomisation seeds -- seeds that nuclear_sim_amd/action_state_deltas.json (made from ic_all_actions.npz,
+    catalog entry + seed 0) has never seen.  An independent check of the table and of the claim that the composer's
+    randomisation of turbine / condenser / generic actions never reaches plant state."""
+    import multiprocessing as mp
+    from . import refsim
+    refsim.setup()
+    from data_gen.config_engine.composers.comprehensive_composer import ComprehensiveComposer
+    with refsim.quiet():
+        amap = dict(ComprehensiveComposer().action_subsystem_map)
+    jobs = [(a, sub, tuple(seeds)) for a, sub in amap.items()]
+    with mp.get_context("fork").Pool(procs) as pool:
+        results = pool.map(_ic_rows, jobs, chunksize=2)
+    cols = SCHEMA.columns()
+    rows, names, subs, seed_of, failed = [], [], [], [], []
+    for res in results:
+        for a, sub, sd, row, err in res:
+            if row is None:
+                failed.append("%s|%s|%s" % (a, sd, err)); continue
+            rows.append(row); names.append(a); subs.append(sub); seed_of.append(sd)
+    np.savez_compressed(os.path.join(OUT, "ic_all_actions_check.npz"), state=np.array(rows), actions=np.array(names), subsystems=np.array(subs),
+                        seeds=np.array(seed_of), failed=np.array(failed), labels=np.array([c[2] for c in cols]),
+                        kinds=np.array([c[0] for c in cols]), paths=np.array([c[3] for c in cols]))
+    print("ic_all_actions_check: %d rows, %d failed" % (len(rows), len(failed)))
+
+
 def make_ic_all_actions(seeds=(0,)):
     """tests/golden/ic_all_actions.npz: for EVERY action of the composer's action -> subsystem map (all four subsystems
     and the generic ones), the initial state of the simulator the runner builds for the catalog entry and for the
@@ -292,6 +334,8 @@ def make_maint_table():
 if __name__ == "__main__":
     if sys.argv[1:] == ["maint_table"]:
         make_maint_table()
+    elif sys.argv[1:] == ["ic_check"]:
+        make_ic_check()
     elif sys.argv[1:] == ["ic"]:
         make_ic_fixture()
     elif sys.argv[1:] == ["ic_actions"]:

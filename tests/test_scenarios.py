@@ -114,6 +114,34 @@ def test_every_action_of_the_composers_map(oracle_lib):
         _check(_apply(oracle_lib, f, 1), st[row:row + 1], cols)
 
 
+def test_action_table_against_seeds_it_was_never_built_from(oracle_lib):
+    """nuclear_sim_amd/action_state_deltas.json was made from ic_all_actions.npz (catalog entry + seed 0), which the test above
+    reads again.  This one is the independent check: tests/golden/ic_all_actions_check.npz holds the reference constructor's
+    state for EIGHT OTHER seeds of every action (oracle/ref_harness/make_golden.py ic_check).  It pins (a) the table
+    itself, (b) the claim that the composer's randomisation of turbine / condenser / generic actions never reaches plant
+    state -- every one of those seeds must give the state the table gives -- and (c) the restated randomisers (feedwater
+    scenario tables / jitter, steam-generator jitter) on seeds no other fixture uses."""
+    z = np.load(os.path.join(GOLDEN_DIR, "ic_all_actions_check.npz"), allow_pickle=False)
+    cols = SCHEMA.columns()
+    idx = {str(p): j for j, p in enumerate(z["paths"]) if str(p)}
+    st = np.full((z["state"].shape[0], len(cols)), np.nan)
+    for j, c in enumerate(cols):
+        if c[3] in idx:
+            st[:, j] = z["state"][:, idx[c[3]]]
+    acts = [str(a) for a in z["actions"]]; seeds = [int(s) for s in z["seeds"]]
+    eff = float(oracle_lib.OraclePlants(1, oracle_lib.Params()).get("pump.lubrication_effectiveness"))
+    assert set(acts) == set(scenarios.ALL_ACTIONS)
+    per_action = {}
+    for row, (a, sd) in enumerate(zip(acts, seeds)):
+        per_action.setdefault(a, []).append((sd, row))
+    assert min(len(v) for v in per_action.values()) >= 8
+    for a, lst in per_action.items():
+        sds = [sd for sd, _ in lst]; rows = [r for _, r in lst]
+        assert not set(sds) & {0}, "seeds the table was built from"
+        o = _apply(oracle_lib, scenarios.action_test_fields(a, sds, eff, randomize=True), len(sds))
+        _check(o, st[rows], cols)
+
+
 def test_unknown_action_is_refused():
     with pytest.raises(NotImplementedError):
         scenarios.action_test_fields("rotor_inspection", [0], 0.9, randomize=False)   # the reference's own composition raises
