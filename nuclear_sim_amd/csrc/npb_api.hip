@@ -20,6 +20,7 @@ struct NpbHandle {
   size_t real_bytes;   /* 8 | 4 */
   void *f64;           /* the arena: [NPB_TOTAL_COL64][pitch] 8-byte columns, or [NPB_TOTAL_COL32][pitch] 4-byte ones */
   double *convert;     /* one staging column (pitch doubles) used by get/set_field with host buffers */
+  unsigned *maint_flags; /* NPB_NUM_PUMPS words per wave of plants: the maintenance screen's verdict (behind the staging column) */
   int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel (npb_set_step_kernel) */
   npb_maint_table_t maint_table;   /* thresholds of the automatic maintenance (include/npb_maint.h) */
   int *plan_dev;       /* npb_gather_fields: {column, sub, kind} per requested field, and the request it was built for */
@@ -135,13 +136,14 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   h->storage = storage; h->real_bytes = real_bytes;
   h->f64 = nullptr; h->convert = nullptr; h->plan_dev = nullptr;
   e = hipMalloc(&h->f64, arena_columns(storage) * h->pitch * real_bytes);
-  if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double) + h->pitch / 64 * NPB_NUM_PUMPS * sizeof(unsigned));
   if (e != hipSuccess) {
     if (h->f64) (void)hipFree(h->f64);
     delete h;
     if (caller_device >= 0) (void)hipSetDevice(caller_device);
     return fail(nullptr, NPB_ENOMEM, "npb_create: hipMalloc of the state arena failed", e);
   }
+  h->maint_flags = (unsigned *)(h->convert + h->pitch);
   (storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, n_plants, h->pitch, h->f64, nullptr, nullptr);
   e = hipDeviceSynchronize();
   if (caller_device >= 0 && caller_device != device) (void)hipSetDevice(caller_device); /* the caller's current device is left as it was */
@@ -298,7 +300,7 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
     npb_maint_table_t table = h->maint_table;   /* the two oil_level params of ABI version 1 override their table row */
     table.threshold[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_threshold;
     table.cooldown_hours[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_cooldown_hours;
-    (narrow ? npb32_launch_maint : npb_launch_maint)(&h->params, &table, h->pitch, h->f64, (hipStream_t)stream);
+    (narrow ? npb32_launch_maint : npb_launch_maint)(&h->params, &table, h->pitch, h->f64, h->maint_flags, (hipStream_t)stream);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_step: kernel launch failed", e);

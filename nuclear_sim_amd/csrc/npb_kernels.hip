@@ -776,17 +776,85 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_reset_kernel(npb_params_t P, siz
 }
 
 /* automatic maintenance after a step (params.maint_enabled): AutoMaintenanceSystem.update, then the state manager's
- * threshold scan with work-order creation (npd_maintenance.h), for the four feedwater pumps.  HBM-bound and small:
- * every step it reads, per pump, the 16 last-violation stamps and the ~15 pump members thresholds look at (~1 KB
- * per plant); the work-order arrays are read only at a check with open orders and at a violation, and everything
- * is written only where it changed. */
+ * threshold scan with work-order creation (npd_maintenance.h), for the four feedwater pumps.  Two launches:
+ *   npb_maint_screen_kernel  what nearly every step of nearly every plant ends with: nothing to do.  HBM-bound and
+ *     small -- per plant sim_time, three members of the maintenance section, and per pump the 15 members thresholds
+ *     look at and the 16 last-violation stamps, 128 independent loads (~1 KB) issued at once and evaluated without a
+ *     branch, one wave per (64 plants, pump).  It moves last_check_time where a check fell due with no order open, and
+ *     writes one flag word per wave: some plant has a check falling on open orders, or a fresh violation on this pump.
+ *   npb_maint_kernel         the full rule, for the 64 plants of a flagged wave only: work orders, the orchestrator,
+ *     the thirteen handlers.  Rare, so it is written for clarity, not for registers.
+ * Kept apart so that the register and scalar pressure of the rule (every threshold row and most of npb_params_t live
+ * in SGPRs) does not shape the code of the screen. */
 #define NPD_MP_COL(inst, member, k) (NPD_SEC_COL(MPUMP, inst) + NPB_F64_SLOT(npb_mpump_t, member) + (k))
 #define NPD_MP_LOAD(inst, member, count) do { _Pragma("unroll") for (int q__ = 0; q__ < (count); q__++) \
     mp.member[q__] = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(inst, member, q__)); } while (0)
 #define NPD_MP_STORE(inst, member, count) do { _Pragma("unroll") for (int q__ = 0; q__ < (count); q__++) \
     *(npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(inst, member, q__)) = (npd_real_t)mp.member[q__]; } while (0)
-__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, npb_maint_table_t T, size_t N, npd_real_t *__restrict__ f64) {
-  const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
+/* the screen's view of the table: scan membership folded into the comparison masks on the host side of the launch */
+struct npd_maint_screen_t {
+  double threshold[NPB_MAINT_NPARAM];
+  double cooldown_minutes[NPB_MAINT_NPARAM];
+  uint32_t want_gt, want_lt, want_eq, want_near, want_far;    /* bit q: row q fires on value > / < / == threshold, |value - threshold| < / >= 0.001 */
+};
+__global__ __launch_bounds__(NPB_WAVE) void npb_maint_screen_kernel(npd_maint_screen_t S, double check_interval_minutes, size_t N,
+                                                                    npd_real_t *__restrict__ f64, unsigned *__restrict__ wave_flags) {
+  /* one wave per (64 plants, pump): four times the waves of a launch that is far from filling the chip */
+  const int k = blockIdx.x % NPB_NUM_PUMPS;
+  const size_t p = (size_t)(blockIdx.x / NPB_NUM_PUMPS) * NPB_WAVE + threadIdx.x;
+  const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
+  npb_pump_t pm;      /* only the members npd_maint_values reads are loaded */
+#define NPD_PM(member) pm.member = NPD_F64_COL(PUMP, npb_pump_t, member, k)
+  NPD_PM(oil_level); NPD_PM(oil_contamination); NPD_PM(lubrication_effectiveness); NPD_PM(wear_impeller); NPD_PM(cavitation_damage);
+  NPD_PM(cavitation_intensity); NPD_PM(npsh_available); NPD_PM(wear_motor_bearings); NPD_PM(wear_pump_bearings); NPD_PM(wear_thrust_bearing);
+  NPD_PM(wear_mechanical_seals); NPD_PM(vibration_level); NPD_PM(oil_temperature); NPD_PM(motor_temperature); NPD_PM(seal_leakage_rate);
+#undef NPD_PM
+  double values[NPB_MAINT_NPARAM], stamp[NPB_MAINT_NPARAM];
+  npd_maint_values(&pm, values);
+#pragma unroll
+  for (int q = 0; q < NPB_MAINT_NPARAM; q++) stamp[q] = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q));
+  bool work = false;
+  if (k == 0) {
+    /* AutoMaintenanceSystem.update as far as it needs no order: a check that falls due with nothing open only moves
+     * last_check_time; one that finds open orders is left, untouched, to the full rule */
+    const double last_check_time = NPD_F64_COL(MAINT, npb_maint_t, last_check_time, 0);
+    const int created = NPD_I32_COL(MAINT, npb_maint_t, work_orders_created, 0);
+    const int performed = NPD_I32_COL(MAINT, npb_maint_t, maintenance_actions_performed, 0);
+    const bool due = !(last_check_time > 0.0 && t - last_check_time < check_interval_minutes);    /* npd_maint_check_due */
+    work = due & (created > performed);
+    if (due & !work) *(npd_real_t *)npd_gaddr(f64, N, p, NPD_SEC_COL(MAINT, 0) + NPB_F64_SLOT(npb_maint_t, last_check_time)) = (npd_real_t)t;
+  }
+#pragma unroll
+  for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
+    const double v = values[q], thr = S.threshold[q], lv = stamp[q];
+    const bool cooling = (lv >= 0.0) & (t - lv < S.cooldown_minutes[q]);        /* _is_threshold_in_cooldown */
+    const bool near_eq = fabs(v - thr) < 0.001;                                  /* _check_threshold_condition */
+    const bool hit = (((S.want_gt >> q) & 1u) != 0) & (v > thr) | (((S.want_lt >> q) & 1u) != 0) & (v < thr) | (((S.want_eq >> q) & 1u) != 0) & (v == thr) |
+                     (((S.want_near >> q) & 1u) != 0) & near_eq | (((S.want_far >> q) & 1u) != 0) & !near_eq;
+    work |= hit & !cooling;
+  }
+  const bool wave_has_work = __any(work) != 0;
+  if (threadIdx.x == 0) wave_flags[blockIdx.x] = wave_has_work ? 1u : 0u;
+}
+
+/* a fixed, small grid: each group walks the waves of plants it owns and works on the flagged ones */
+__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, npb_maint_table_t T, size_t N, npd_real_t *__restrict__ f64,
+                                                             const unsigned *__restrict__ wave_flags) {
+  const unsigned n_waves = (unsigned)(N / NPB_WAVE);
+  /* nothing flagged among this group's waves -- the usual case -- and it is gone before the rule's constants (most of P
+   * and T, which the compiler gathers into registers ahead of the loop) are even fetched */
+  unsigned mine = 0;
+#pragma unroll 1
+  for (unsigned w = blockIdx.x; w < n_waves; w += gridDim.x) {
+    const uint4 flagged = *(const uint4 *)(wave_flags + (size_t)w * NPB_NUM_PUMPS);
+    mine |= flagged.x | flagged.y | flagged.z | flagged.w;
+  }
+  if (!mine) return;
+#pragma unroll 1
+  for (unsigned w = blockIdx.x; w < n_waves; w += gridDim.x) {
+  const uint4 flagged = *(const uint4 *)(wave_flags + (size_t)w * NPB_NUM_PUMPS);
+  if (!(flagged.x | flagged.y | flagged.z | flagged.w)) continue;
+  const size_t p = (size_t)w * NPB_WAVE + threadIdx.x;
   const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
   npb_maint_t m;
   NPD_LOAD(MAINT, npb_maint_t, m, 0);
@@ -817,30 +885,21 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, npb
       }
     }
   }
-  /* ---- StateManager.collect_states: threshold scan, one orchestrated event per pump */
+  /* ---- StateManager.collect_states: threshold scan, one orchestrated event per pump (after the work above, as the
+   * reference orders it) */
 #pragma unroll 1
   for (int k = 0; k < NPB_NUM_PUMPS; k++) {
     npb_pump_t pm;
     NPD_LOAD(PUMP, npb_pump_t, pm, k);
     npb_mpump_t mp;
-    NPD_MP_LOAD(k, last_violation_time, NPB_MAINT_NPARAM);
-    /* would any threshold fire?  (the cheap pre-test: the work-order arrays are needed only then) */
-    double values[NPB_MAINT_NPARAM];
-    npd_maint_values(&pm, values);
-    bool any = false;
-#pragma unroll
-    for (int q = 0; q < NPB_MAINT_NPARAM; q++)
-      any = any || (T.rank[q] >= 0 && !(mp.last_violation_time[q] >= 0.0 && t - mp.last_violation_time[q] < T.cooldown_hours[q] * 60) &&
-                    npd_maint_violates(values[q], T.threshold[q], T.comparison[q]));
-    if (!any) continue;
-    NPD_MP_LOAD(k, wo_order, NPB_MAINT_NACT); NPD_MP_LOAD(k, wo_planned_start, NPB_MAINT_NACT);
-    NPD_MP_LOAD(k, last_trigger_time, NPB_MAINT_NACT);
-    mp.wo_bearing = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, wo_bearing, 0));
-    npd_maint_scan_pump(&mp, &m, &P, &T, &pm, t);
-    dirty = 1;
-    NPD_STORE(MPUMP, npb_mpump_t, mp, k);
+    NPD_LOAD(MPUMP, npb_mpump_t, mp, k);
+    if (npd_maint_scan_pump(&mp, &m, &P, &T, &pm, t)) {
+      dirty = 1;
+      NPD_STORE(MPUMP, npb_mpump_t, mp, k);
+    }
   }
   if (dirty) NPD_STORE(MAINT, npb_maint_t, m, 0);
+  }
 }
 
 #ifndef NPB_BUILD_F32
@@ -925,9 +984,24 @@ extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t n
     hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, cw_temp, obs, reward, done, trip_flags, info);
 }
-extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, const npb_maint_table_t *T, size_t npad, void *arena, hipStream_t stream) {
-  dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_maint_kernel, grid, block, 0, stream, *P, *T, npad, (npd_real_t *)arena);
+extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, const npb_maint_table_t *T, size_t npad, void *arena, unsigned *wave_flags, hipStream_t stream) {
+  dim3 block(NPB_WAVE);
+  npd_maint_screen_t S = {};
+  for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
+    S.threshold[q] = T->threshold[q];
+    S.cooldown_minutes[q] = T->cooldown_hours[q] * 60;
+    if (T->rank[q] < 0) continue;             /* not in the scan: no mask bit, never fires */
+    const int c = T->comparison[q];
+    const uint32_t bit = 1u << q;
+    if (c == NPB_CMP_GREATER_THAN || c == NPB_CMP_GREATER_EQUAL) S.want_gt |= bit;
+    if (c == NPB_CMP_LESS_THAN || c == NPB_CMP_LESS_EQUAL) S.want_lt |= bit;
+    if (c == NPB_CMP_GREATER_EQUAL || c == NPB_CMP_LESS_EQUAL) S.want_eq |= bit;
+    if (c == NPB_CMP_EQUALS) S.want_near |= bit;
+    if (c != NPB_CMP_GREATER_THAN && c != NPB_CMP_GREATER_EQUAL && c != NPB_CMP_LESS_THAN && c != NPB_CMP_LESS_EQUAL && c != NPB_CMP_EQUALS) S.want_far |= bit;
+  }
+  const unsigned n_waves = (unsigned)(npad / NPB_WAVE);
+  hipLaunchKernelGGL(npb_maint_screen_kernel, dim3(n_waves * NPB_NUM_PUMPS), block, 0, stream, S, P->maint_check_interval_hours * 60, npad, (npd_real_t *)arena, wave_flags);
+  hipLaunchKernelGGL(npb_maint_kernel, dim3(n_waves < 256u ? n_waves : 256u), block, 0, stream, *P, *T, npad, (npd_real_t *)arena, (const unsigned *)wave_flags);
 }
 extern "C" void NPB_LAUNCHER(observe)(int mode, int n_plants, size_t npad, const void *arena, double *obs, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);

@@ -795,7 +795,8 @@ def test_facade_reads_and_pokes_through_reference_attribute_paths():
     assert pump.state.trip_active == 1 and (int(r["info"]["trip_flags"]) >> 8) & 1
     sec = r["info"]["secondary_system"]     # the reference's result keys that are plant state, under the reference's names
     assert sec["electrical_power_mw"] == sim._env.get_field("sec.electrical_power_output")[0].item() == r["info"]["electrical_power"]
-    assert sec["feedwater_total_flow"] == sim._env.get_field("fw.total_flow_rate")[0].item() and len(sec) >= 15
+    # (the result carries the fp64 value the step computed; the fw.total_flow_rate column keeps it as a float output)
+    assert sec["feedwater_total_flow"] == pytest.approx(sim._env.get_field("fw.total_flow_rate")[0].item(), rel=1e-6) and len(sec) >= 15
     sim.secondary_physics._previous_sg_conditions['levels'][0] = 16.2       # the other S7 poke, dict-and-index syntax
     assert sim.secondary_physics._previous_sg_conditions['levels'][0] == 16.2
     with pytest.raises(AttributeError):

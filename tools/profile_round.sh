@@ -5,7 +5,7 @@
 set -e
 OUT=$(realpath -m "$1"); REPO=$(pwd); mkdir -p "$OUT"
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/bench.py" --steps 100 --warmup 5 --no-cpu-baseline --maintenance > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/bench.py" --steps 100 --warmup 5 --no-cpu-baseline --plants-per-gpu ${NPB_PROFILE_PLANTS:-65536} > "$OUT/stats.log" 2>&1
 echo "stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 "$REPO/tools/profile_traffic.py" > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 "$REPO/tools/profile_traffic.py" > "$OUT/write.log" 2>&1

@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-N = 65536
+N = int(os.environ.get("NPB_PROFILE_PLANTS", "65536"))   # which step kernel runs follows from the batch size (npb_set_step_kernel)
 K = 10
 
 
@@ -60,12 +60,12 @@ def summarize(out):
     total = 0.0
     for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         avg, cnt = counter_per_kernel(os.path.join(out, sub), counter)
-        touch = avg.get("npb_touch_kernel"); step = avg.get("npb_step_kernel")
+        touch = avg.get("npb_touch_kernel"); step = avg.get("npb_step_kernel", avg.get("npb_step2_kernel"))
         if touch is None or step is None:
             res[counter] = "missing"; continue
         raw_unit_bytes = 1024.0  # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
         scale = known / (touch * raw_unit_bytes)
-        res[counter] = {"touch_raw_kib": touch, "step_raw_kib": step, "launches": cnt.get("npb_step_kernel"),
+        res[counter] = {"touch_raw_kib": touch, "step_raw_kib": step, "launches": cnt.get("npb_step_kernel", cnt.get("npb_step2_kernel")),
                         "calibration_scale": scale, "step_bytes_calibrated": step * raw_unit_bytes * scale}
         total += step * raw_unit_bytes * scale
     res["step_hbm_bytes_per_launch"] = total
@@ -79,11 +79,11 @@ def summarize(out):
 def summarize_sq(out):
     """Per-launch averages of every counter found under OUT (one sub-directory per --pmc pass), for
     npb_step_kernel; SQ counters are summed over the chip, so they are also shown per wave (1 024 waves)."""
-    waves = N // 64
+    waves = N // 64   # groups of 64 plants: one wave each (npb_step_kernel) or two (npb_step2_kernel)
     res = {}
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if not row["Kernel_Name"].startswith("npb_step_kernel"):
+            if not row["Kernel_Name"].startswith(("npb_step_kernel", "npb_step2_kernel")):
                 continue
             res.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     print("%-28s %16s %14s" % ("counter", "per launch", "per wave"))
