@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPB_VERSION 120 /* 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
+#define NPB_VERSION 130 /* 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
 #ifndef NPB_API
 #define NPB_API __attribute__((visibility("default")))
 #endif
@@ -43,6 +43,14 @@ enum {
    * (secondary/__init__.py:679-744, 922-1010; nuclear_sim_amd/env.py secondary_result): total steam-generator heat transfer
    * [W], turbine gross electrical power [MW], feedwater pump power [MW], primary thermal power over the three loops [MW] */
   NPB_INFO_SG_HEAT_TRANSFER, NPB_INFO_TURBINE_POWER, NPB_INFO_FEEDWATER_POWER, NPB_INFO_PRIMARY_THERMAL_POWER
+};
+/* info["reactivity_components"] (sim.py:205; reactivity_model.py:77-125, pcm, the dict's insertion order).  Only the
+ * reactor heat source has them, and only a caller that sets params.info_reactivity_components gets them: the info
+ * buffer handed to npb_step must then hold a second block behind the first, [n_plants][NPB_INFO_DIM] followed by
+ * [n_plants][NPB_INFO_NRHO]. */
+enum {
+  NPB_RHO_CONTROL_RODS = 0, NPB_RHO_BORON, NPB_RHO_DOPPLER, NPB_RHO_MODERATOR_TEMP, NPB_RHO_MODERATOR_VOID, NPB_RHO_PRESSURE,
+  NPB_RHO_XENON, NPB_RHO_SAMARIUM, NPB_RHO_FUEL_DEPLETION, NPB_RHO_BURNABLE_POISONS, NPB_INFO_NRHO
 };
 /* trip_flags bits */
 enum {

@@ -64,12 +64,14 @@ typedef struct npb_params_t {
   double dt;               /* NuclearPlantSimulator(dt=...)  sim.py:33 */
   int heat_source;         /* NPB_HEAT_CONSTANT | NPB_HEAT_REACTOR */
   int hs_noise_enabled;    /* ConstantHeatSource(noise_enabled=...) */
-  int mode;                /* NPB_MODE_FULL | NPB_MODE_PRIMARY_SG */
-  int maint_enabled;       /* 1: run the oil_top_off maintenance rule after every step (maint.* columns) */
+  int mode;                /* NPB_MODE_FULL | NPB_MODE_PRIMARY_SG | NPB_MODE_PRIMARY */
+  int maint_enabled;       /* 1: run the automatic maintenance of the feedwater pumps after every step (maint.*, mpump.* columns) */
+  int info_reactivity_components; /* 1: under NPB_HEAT_REACTOR the step also writes info["reactivity_components"] (npb.h NPB_RHO_*) */
 } npb_params_t;
 
 enum { NPB_HEAT_CONSTANT = 0, NPB_HEAT_REACTOR = 1 };
-enum { NPB_MODE_FULL = 0, NPB_MODE_PRIMARY_SG = 1 };
+/* NPB_MODE_PRIMARY: NuclearPlantSimulator(enable_secondary=False), sim.py:155,309,333 -- primary side only, 12 observations */
+enum { NPB_MODE_FULL = 0, NPB_MODE_PRIMARY_SG = 1, NPB_MODE_PRIMARY = 2 };
 
 static inline void npb_params_default(npb_params_t *p) {
 #define NPB__P(name, dflt, path) p->name = (dflt);
@@ -80,6 +82,7 @@ static inline void npb_params_default(npb_params_t *p) {
   p->hs_noise_enabled = 0;
   p->mode = NPB_MODE_FULL;
   p->maint_enabled = 0;
+  p->info_reactivity_components = 0;
 }
 
 #endif /* NPB_PARAMS_H */

@@ -17,7 +17,10 @@ LIB_PATH = os.environ.get("NPB_LIB", os.path.join(_HERE, "libnpb.so"))
 NPB_KIND_F64, NPB_KIND_I32 = 0, 1
 HEAT_CONSTANT, HEAT_REACTOR = 0, 1
 STORAGE_F64, STORAGE_F32 = 0, 1
-MODE_FULL, MODE_PRIMARY_SG = 0, 1
+MODE_FULL, MODE_PRIMARY_SG, MODE_PRIMARY = 0, 1, 2
+INFO_NRHO = 10   # include/npb.h NPB_INFO_NRHO
+REACTIVITY_COMPONENTS = ("control_rods", "boron", "doppler", "moderator_temp", "moderator_void", "pressure", "xenon", "samarium",
+                         "fuel_depletion", "burnable_poisons")   # reactivity_model.py:87-121, NPB_RHO_*
 
 
 class NpbError(RuntimeError):
@@ -27,7 +30,7 @@ class NpbError(RuntimeError):
 def _make_params_struct():
     fields = [(name, ctypes.c_double) for name, _d, _p in PARAMS]
     fields += [("dt", ctypes.c_double), ("heat_source", ctypes.c_int), ("hs_noise_enabled", ctypes.c_int),
-               ("mode", ctypes.c_int), ("maint_enabled", ctypes.c_int)]
+               ("mode", ctypes.c_int), ("maint_enabled", ctypes.c_int), ("info_reactivity_components", ctypes.c_int)]
     return type("NpbParams", (ctypes.Structure,), {"_fields_": fields})
 
 

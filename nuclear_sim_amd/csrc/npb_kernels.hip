@@ -302,6 +302,71 @@ __device__ __forceinline__ void npd_obs_primary(const npb_prim_t &s, double *obs
   obs[11] = (double)(s.scram_status != 0);
 }
 
+/* info["reactivity_components"] (sim.py:205): the second block of the info buffer, only for a caller that asked
+ * (params.info_reactivity_components) under the reactor heat source -- include/npb.h NPB_RHO_* */
+__device__ __forceinline__ void npd_store_reactivity_components(const npb_params_t &P, const double *rho, double *__restrict__ info_out,
+                                                                int n_plants, size_t p) {
+  if (P.info_reactivity_components && P.heat_source == NPB_HEAT_REACTOR && info_out && p < (size_t)n_plants) {
+    double *out = info_out + (size_t)n_plants * NPB_INFO_DIM + p * NPB_INFO_NRHO;
+#pragma unroll
+    for (int k = 0; k < NPB_INFO_NRHO; k++) out[k] = rho[k];
+  }
+}
+
+/* NuclearPlantSimulator(enable_secondary=False).step  sim.py:141-151,186-206,253-258: the primary side alone (no coupling,
+ * no secondary update, no feedback), twelve observations (the other ten columns of the obs row are written as 0), the
+ * base reward, and NaN in the info columns whose keys the reference's dict then lacks.  A small kernel of its own: nothing
+ * here is worth the staging pipeline. */
+__global__ __launch_bounds__(NPB_WAVE) void npb_step_primary_kernel(
+    npb_params_t P, int n_plants, size_t N, npd_real_t *__restrict__ f64,
+    const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
+    const double *__restrict__ noise_z, double *__restrict__ obs_out, double *__restrict__ reward_out,
+    uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out, double *__restrict__ info_out) {
+  __shared__ double lds[NPB_WAVE * NPB_OBS_PAD];
+  const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
+  const size_t p = block_base + threadIdx.x;
+  const bool live = p < (size_t)n_plants;
+  npd_inputs_t in;
+  in.action = (live && action) ? action[p] : 8;
+  in.magnitude = (live && magnitude) ? magnitude[p] : 1.0;
+  in.power_setpoint = (live && setpoint) ? setpoint[p] : NAN;
+  in.noise_z = (live && noise_z) ? noise_z[p] : 0.0;
+  in.cooling_water_temp = NAN;
+  npb_prim_t s;
+  NPD_LOAD(PRIM, npb_prim_t, s, 0);
+  if (!isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
+  int nan_reset;
+  double rho[NPB_INFO_NRHO];
+  const int scram_fired = npd_primary_update(&s, &P, &in, &nan_reset, rho);
+  npd_store_reactivity_components(P, rho, info_out, n_plants, p);
+  s.sim_time += P.dt;
+  NPD_STORE(PRIM, npb_prim_t, s, 0);
+  double obs[NPB_OBS_DIM], info[NPB_INFO_DIM];
+  npd_obs_primary(s, obs);
+#pragma unroll
+  for (int k = 12; k < NPB_OBS_DIM; k++) obs[k] = 0.0;
+  /* calculate_reward(None)  sim.py:503-519 */
+  double power_reward = -fabs(s.power_level - 100) / 100;
+  double temp_penalty = 0, pressure_penalty = 0;
+  if (s.fuel_temperature > 800) temp_penalty = -(s.fuel_temperature - 800) / 100;
+  if (s.coolant_pressure > 16) pressure_penalty = -(s.coolant_pressure - 16);
+  double scram_penalty = s.scram_status ? -100 : 0;
+  if (live) {
+    if (reward_out) reward_out[p] = power_reward + temp_penalty + pressure_penalty + scram_penalty;
+    if (done_out) done_out[p] = (uint8_t)scram_fired;
+    if (trip_out) trip_out[p] = (s.scram_status ? NPB_TRIP_SCRAM : 0u) | (scram_fired ? NPB_TRIP_SCRAM_FIRED : 0u) | (nan_reset ? NPB_TRIP_NAN_RESET : 0u);
+  }
+  if (obs_out) npd_store_rows<NPB_OBS_DIM>(obs, obs_out, lds, block_base, (size_t)n_plants);
+  if (info_out) {
+#pragma unroll
+    for (int k = 0; k < NPB_INFO_DIM; k++) info[k] = NAN;
+    info[NPB_INFO_THERMAL_POWER] = s.thermal_power_mw;
+    info[NPB_INFO_REACTIVITY_PCM] = s.total_reactivity_pcm;
+    info[NPB_INFO_TIME] = s.sim_time;
+    npd_store_rows<NPB_INFO_DIM>(info, info_out, lds, block_base, (size_t)n_plants);
+  }
+}
+
 __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     npb_params_t P, int n_plants, size_t N, npd_real_t *__restrict__ f64,
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
@@ -376,7 +441,9 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
   /* ================= phase 0: primary side + coupling (sim.py:141-161) ================= */
   {
     if (!isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
-    scram_fired = npd_primary_update(&s, &P, &in, &nan_reset);
+    double rho[NPB_INFO_NRHO];
+    scram_fired = npd_primary_update(&s, &P, &in, &nan_reset, rho);
+    npd_store_reactivity_components(P, rho, info_out, n_plants, p);
     npd_primary_to_secondary(&s, &c);
     s.sim_time += dt;
     load_demand = s.power_level; /* sim.py:161: the caller's load_demand is overwritten */
@@ -686,6 +753,12 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_observe_kernel(int mode, int n_p
   npb_prim_t s;
   NPD_LOAD(PRIM, npb_prim_t, s, 0);
   npd_obs_primary(s, obs);
+  if (mode == NPB_MODE_PRIMARY) {   /* sim.py:333: twelve values */
+#pragma unroll
+    for (int k = 12; k < NPB_OBS_DIM; k++) obs[k] = 0.0;
+    npd_store_rows<NPB_OBS_DIM>(obs, obs_out, lds, block_base, (size_t)n_plants);
+    return;
+  }
   obs[12] = NPD_F64_COL(SEC, npb_sec_t, electrical_power_output, 0) / 1100;
   obs[13] = NPD_F64_COL(SEC, npb_sec_t, thermal_efficiency, 0) / 0.35;
   obs[14] = NPD_F64_COL(SEC, npb_sec_t, total_steam_flow, 0) / 1665;
@@ -976,6 +1049,11 @@ extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t n
    * wave for every SIMD (> ~57 k plants) its LDS-DMA pipeline wins (measured crossover).
    * variant: 0 = by batch size, 1 = one wave per 64 plants, 2 = two waves.  The primary + steam-generator mode
    * always takes the one-wave kernel. */
+  if (P->mode == NPB_MODE_PRIMARY) {
+    hipLaunchKernelGGL(npb_step_primary_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
+                       noise_z, obs, reward, done, trip_flags, info);
+    return;
+  }
   if (variant == 0) variant = npad <= 57344 ? 2 : 1;
   if (variant == 2 && P->mode == NPB_MODE_FULL)
     hipLaunchKernelGGL(npb_step2_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,

@@ -51,7 +51,7 @@ NPD_FN void npd_update_fission_products(npb_prim_t *s, double flux, double dt) {
 
 /* ReactivityModel.calculate_total_reactivity  reactivity_model.py:77-125, terms :127-311.
  * Python's sum() over the dict adds in insertion order starting from int 0. */
-NPD_FN double npd_total_reactivity_pcm(const npb_prim_t *s) {
+NPD_FN double npd_total_reactivity_pcm(const npb_prim_t *s, double *components) {
   double pos_norm = npd_clip(s->control_rod_position / 100.0, 0.0, 1.0);
   double rods = 3000.0 * (pos_norm - 0.5);
   double boron = -10.0 * s->boron_concentration;
@@ -66,17 +66,23 @@ NPD_FN double npd_total_reactivity_pcm(const npb_prim_t *s) {
   double total = 0.0;
   total += rods; total += boron; total += doppler; total += mod_temp; total += mod_void;
   total += pressure; total += xenon; total += samarium; total += depletion; total += bp;
+  if (components) {   /* info["reactivity_components"], in the dict's order (NPB_RHO_* of include/npb.h) */
+    components[NPB_RHO_CONTROL_RODS] = rods; components[NPB_RHO_BORON] = boron; components[NPB_RHO_DOPPLER] = doppler;
+    components[NPB_RHO_MODERATOR_TEMP] = mod_temp; components[NPB_RHO_MODERATOR_VOID] = mod_void; components[NPB_RHO_PRESSURE] = pressure;
+    components[NPB_RHO_XENON] = xenon; components[NPB_RHO_SAMARIUM] = samarium; components[NPB_RHO_FUEL_DEPLETION] = depletion;
+    components[NPB_RHO_BURNABLE_POISONS] = bp;
+  }
   return total;
 }
 
 /* ReactorHeatSource.update  heat_sources/reactor_heat_source.py:40-107 with
  * PointKineticsModel  physics/point_kinetics.py:26-131 */
 NPD_FN void npd_reactor_heat_source(npb_prim_t *s, const npb_params_t *P, double dt,
-                                    double *thermal_power_mw, double *power_percent, double *total_pcm) {
+                                    double *thermal_power_mw, double *power_percent, double *total_pcm, double *components) {
   const double BETA = 0.0065, LAMBDA_PROMPT = 1e-5;
   const double LAMBDA[6] = {0.077, 0.311, 1.40, 3.87, 1.40, 0.195};
   npd_update_fission_products(s, s->neutron_flux, dt);
-  double total = npd_total_reactivity_pcm(s);
+  double total = npd_total_reactivity_pcm(s, components);
   double reactivity = total / 100000.0;
   if (s->scram_status) reactivity = -0.5;
   /* solve_point_kinetics */
@@ -151,7 +157,7 @@ NPD_FN double npd_core_ua(double coolant_flow_rate) {
 
 /* PrimaryReactorPhysics.update_system  systems/primary/__init__.py:178-287.
  * Returns scram_activated (True only on the firing step). nan_reset reports :247. */
-NPD_FN int npd_primary_update(npb_prim_t *s, const npb_params_t *P, const npd_inputs_t *in, int *nan_reset) {
+NPD_FN int npd_primary_update(npb_prim_t *s, const npb_params_t *P, const npd_inputs_t *in, int *nan_reset, double *components) {
   const double dt = P->dt;
   const double FUEL_MASS = 200000.0, FUEL_HEAT_CAPACITY = 1500.0, COOLANT_HEAT_CAPACITY = 5200.0;
   (void)COOLANT_HEAT_CAPACITY;
@@ -159,7 +165,7 @@ NPD_FN int npd_primary_update(npb_prim_t *s, const npb_params_t *P, const npd_in
 
   double thermal_power_mw, power_percent, total_pcm = 0.0;
   if (P->heat_source == NPB_HEAT_REACTOR) {
-    npd_reactor_heat_source(s, P, dt, &thermal_power_mw, &power_percent, &total_pcm);
+    npd_reactor_heat_source(s, P, dt, &thermal_power_mw, &power_percent, &total_pcm, components);
     s->total_reactivity_pcm = total_pcm;
     s->reactivity = total_pcm / 100000.0; /* __init__.py:220 overwrites heat source's value */
   } else {

@@ -342,7 +342,9 @@ __global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(
       }
       const npb_prim_t s_old = s;
       if (!isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
-      scram_fired = npd_primary_update(&s, &P, &in, &nan_reset);
+      double rho[NPB_INFO_NRHO];
+      scram_fired = npd_primary_update(&s, &P, &in, &nan_reset, rho);
+      npd_store_reactivity_components(P, rho, info_out, n_plants, p);
       npd_coupling_t c;
       npd_primary_to_secondary(&s, &c);
       /* the per-loop conditions go to LDS: wave B's steam generators read them there, and so does this wave later

@@ -115,7 +115,7 @@ class BatchedPlantEnv:
     def __init__(self, n_envs: int, dt: float = 1.0, heat_source: str = "constant", noise_enabled: bool = False,
                  noise_std_percent: float = 0.1, noise_seeds: Optional[Sequence[int]] = None,
                  mode: str = "full", device: int = 0, params: Optional[dict] = None, maintenance: bool = False,
-                 storage: str = "f64", maintenance_thresholds: Optional[dict] = None):
+                 storage: str = "f64", maintenance_thresholds: Optional[dict] = None, reactivity_components: bool = False):
         if not torch.cuda.is_available():
             raise _lib.NpbError("BatchedPlantEnv needs a HIP device (torch.cuda.is_available() is False); "
                                 "there is no CPU fallback")
@@ -127,7 +127,13 @@ class BatchedPlantEnv:
         p.heat_source = {"constant": _lib.HEAT_CONSTANT, "reactor": _lib.HEAT_REACTOR}[heat_source]
         p.hs_noise_enabled = int(bool(noise_enabled))
         p.hs_noise_std_percent = float(noise_std_percent)
-        p.mode = {"full": _lib.MODE_FULL, "primary_sg": _lib.MODE_PRIMARY_SG}[mode]
+        # "primary": NuclearPlantSimulator(enable_secondary=False) -- the primary side alone, obs[:, :12] (sim.py:155,333)
+        p.mode = {"full": _lib.MODE_FULL, "primary_sg": _lib.MODE_PRIMARY_SG, "primary": _lib.MODE_PRIMARY}[mode]
+        self.mode = mode
+        # info["reactivity_components"] (sim.py:205) exists under the reactor heat source only; asked for, the step writes the
+        # ten terms behind the info columns (include/npb.h NPB_RHO_*)
+        self._with_rho = bool(reactivity_components) and heat_source == "reactor"
+        p.info_reactivity_components = int(self._with_rho)
         # automatic oil_top_off maintenance after every step, as the data-gen runner's simulator has it
         # (maintenance_scenario_runner.py:210-244); thresholds/cadence via params["maint_*"]
         p.maint_enabled = int(bool(maintenance))
@@ -148,7 +154,9 @@ class BatchedPlantEnv:
             self._reward = torch.zeros(self.n, dtype=torch.float64, device=self.device)
             self._done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
             self._flags = torch.zeros(self.n, dtype=torch.int32, device=self.device)
-            self._info = torch.zeros((self.n, len(INFO_COLUMNS)), dtype=torch.float64, device=self.device)
+            self._info_buf = torch.zeros(self.n * (len(INFO_COLUMNS) + (_lib.INFO_NRHO if self._with_rho else 0)), dtype=torch.float64, device=self.device)
+            self._info = self._info_buf[: self.n * len(INFO_COLUMNS)].view(self.n, len(INFO_COLUMNS))
+            self._rho = self._info_buf[self.n * len(INFO_COLUMNS):].view(self.n, -1) if self._with_rho else None
         self._noise = None
         if noise_enabled and noise_seeds is not None:
             self._noise = HeatSourceNoise(noise_seeds, device=self.device)
@@ -308,8 +316,10 @@ class BatchedPlantEnv:
         z = self._col(noise_z, torch.float64)
         _lib.check(self.L.npb_step(self._h, self._p(a), self._p(m), self._p(sp), self._p(z), self._p(cw),
                                    self._p(self._obs), self._p(self._reward), self._p(self._done), self._p(self._flags),
-                                   self._p(self._info), self._stream()), self._h)
+                                   self._p(self._info_buf), self._stream()), self._h)
         info = {name: self._info[:, j] for j, name in enumerate(INFO_COLUMNS)}
+        if self._with_rho:
+            info["reactivity_components"] = {name: self._rho[:, j] for j, name in enumerate(_lib.REACTIVITY_COMPONENTS)}
         info["trip_flags"] = self._flags
         info["scram_activated"] = self._done
         if self.params.maint_enabled:  # bit-exact counterpart of AutoMaintenanceSystem.maintenance_actions_performed
@@ -496,18 +506,24 @@ class NuclearPlantSimulator:
     def __init__(self, dt: float = 1.0, heat_source=None, enable_secondary: bool = True,
                  enable_state_management: bool = True, max_state_rows: int = 100000, secondary_config=None,
                  secondary_config_file: Optional[str] = None, device: int = 0):
-        if not enable_secondary:
-            raise NotImplementedError("the HIP stepper always runs the secondary side")
-        if secondary_config_file is not None:
-            raise NotImplementedError("pass secondary_config as a dict (YAML loading is out of scope)")
+        if secondary_config is None and secondary_config_file is not None and enable_secondary:
+            secondary_config = self._load_config_file(secondary_config_file)
         if heat_source is None or heat_source == "reactor":
             heat_source = ReactorHeatSource()            # sim.py:41-44: the default heat source is the reactor model
         elif heat_source == "constant":
             heat_source = ConstantHeatSource(noise_std_percent=0.1)
         constant = isinstance(heat_source, ConstantHeatSource)
         self.dt = dt
-        self.enable_secondary = True
+        self.enable_secondary = bool(enable_secondary)
         self.enable_state_management = enable_state_management
+        # StateManager's clock (state_manager.py:51-52,82-109): a random start date drawn from the `random` module, advanced
+        # by dt minutes per step, never put back by reset(); without state management info["datetime"] is None
+        self._datetime = None
+        if enable_state_management:
+            import datetime as _dt
+            import random as _random
+            self._datetime = _dt.datetime(_random.randint(2020, 2030), _random.randint(1, 12), _random.randint(1, 28),
+                                          _random.randint(0, 23), _random.randint(0, 59), 0)
         params = {"rated_power_mw": float(heat_source.rated_power_mw)}
         if constant:
             params["hs_noise_filter_tau"] = float(heat_source.noise_filter_time_constant)
@@ -520,14 +536,15 @@ class NuclearPlantSimulator:
                                     noise_std_percent=float(heat_source.noise_std_percent) if constant else 0.1,
                                     noise_seeds=[heat_source.noise_seed] if (constant and heat_source.noise_enabled and
                                                                              heat_source.noise_seed is not None) else None,
-                                    device=device, maintenance=enable_state_management, params=params,
-                                    maintenance_thresholds=thresholds)
+                                    device=device, maintenance=bool(enable_state_management and enable_secondary), params=params,
+                                    maintenance_thresholds=thresholds, mode="full" if enable_secondary else "primary",
+                                    reactivity_components=not constant)
         # the reference's object tree, as far as it is plant state: attribute paths resolve against the schema
         self.primary_physics = _PathProxy(self._env, "primary_physics",
                                           extras={"heat_source": heat_source, "rated_power_mw": heat_source.rated_power_mw})
-        self.secondary_physics = _PathProxy(self._env, "secondary_physics")
+        self.secondary_physics = _PathProxy(self._env, "secondary_physics") if enable_secondary else None
         self.ignored_initial_conditions = []
-        if secondary_config is not None:
+        if secondary_config is not None and enable_secondary:
             self._apply_secondary_config(secondary_config)
         self.load_demand = 100.0
         self.cooling_water_temp = 25.0
@@ -581,11 +598,33 @@ class NuclearPlantSimulator:
                                               power_setpoint=None if sp is None else [sp],
                                               cooling_water_temp=None if cooling_water_temp is None else [cooling_water_temp])
         o = obs[0].cpu().numpy().copy()
+        rho = info.pop("reactivity_components", None)
         inf = {k: (v[0].item()) for k, v in info.items()}
         inf["scram_activated"] = bool(inf["scram_activated"])
-        inf["datetime"] = None
-        inf["secondary_system"] = self._secondary_result()
+        # sim.py:205: the reactor model's ten terms in pcm; ConstantHeatSource has none (primary/__init__.py:225)
+        inf["reactivity_components"] = {} if rho is None else {k: float(v[0].item()) for k, v in rho.items()}
+        if self._datetime is not None:
+            import datetime as _dt
+            self._datetime += _dt.timedelta(minutes=self.dt)
+        inf["datetime"] = self._datetime.isoformat() if self._datetime is not None else None
+        if not self.enable_secondary:   # sim.py:199-206,225: without a secondary side the dict has the primary keys only
+            inf = {k: inf[k] for k in ("time", "datetime", "thermal_power", "scram_activated", "reactivity", "reactivity_components", "trip_flags")}
+            o = o[:12]
+        else:
+            inf["secondary_system"] = self._secondary_result()
         return {"observation": o, "reward": float(rew[0].item()), "done": bool(done[0].item()), "info": inf}
+
+    @staticmethod
+    def _load_config_file(path: str) -> dict:
+        """SecondaryReactorPhysics(config_file=...)  secondary/__init__.py:181-205: a YAML file, its ``secondary_system``
+        section when it has one; the comprehensive configuration's ``maintenance_system`` section rides along"""
+        import yaml
+        with open(path, "r") as fh:
+            data = yaml.safe_load(fh)
+        cfg = dict(data.get("secondary_system", data))
+        if "maintenance_system" in data and "maintenance_system" not in cfg:
+            cfg["maintenance_system"] = data["maintenance_system"]
+        return cfg
 
     def _secondary_result(self) -> Dict[str, float]:
         """info["secondary_system"]: every scalar key of the reference's result dict (secondary/__init__.py:922-1010) that is a
@@ -608,10 +647,10 @@ class NuclearPlantSimulator:
             self.primary_physics.heat_source.power_setpoint_percent = 100.0
         self.load_demand = 100.0
         self.cooling_water_temp = 25.0
-        return obs[0].cpu().numpy().copy()
+        return obs[0].cpu().numpy().copy()[: 22 if self.enable_secondary else 12]
 
     def get_observation(self) -> np.ndarray:
-        return self._env.get_observation()[0].cpu().numpy().copy()
+        return self._env.get_observation()[0].cpu().numpy().copy()[: 22 if self.enable_secondary else 12]
 
 
 class NuclearPlantEnv:
@@ -620,7 +659,7 @@ class NuclearPlantEnv:
     def __init__(self, **kw):
         self.sim = NuclearPlantSimulator(**kw)
         self.action_space_size = len(ControlAction)
-        self.observation_space_size = 22
+        self.observation_space_size = 22 if self.sim.enable_secondary else 12   # sim.py:917-918
 
     def render(self):
         return None

@@ -54,7 +54,7 @@ class Params:
         self._buf = np.zeros(L.npo_params_size(), dtype=np.uint8)
         L.npo_params_default(_ptr(self._buf))
         nd = len(self._names)
-        assert self._buf.size == nd * 8 + 8 + 4 * 4, (self._buf.size, nd)
+        assert self._buf.size == (nd * 8 + 8 + 5 * 4 + 7) // 8 * 8, (self._buf.size, nd)
 
     def _dview(self):
         return self._buf[: (len(self._names) + 1) * 8].view(np.float64)
@@ -69,7 +69,7 @@ class Params:
             return float(self._dview()[self._names.index(k)])
         if k == "dt":
             return float(self._dview()[len(self._names)])
-        ints = ["heat_source", "hs_noise_enabled", "mode", "maint_enabled"]
+        ints = ["heat_source", "hs_noise_enabled", "mode", "maint_enabled", "info_reactivity_components"]
         if k in ints:
             return int(self._iview()[ints.index(k)])
         raise AttributeError(k)
@@ -81,8 +81,8 @@ class Params:
             self._dview()[self._names.index(k)] = v
         elif k == "dt":
             self._dview()[len(self._names)] = v
-        elif k in ("heat_source", "hs_noise_enabled", "mode", "maint_enabled"):
-            self._iview()[["heat_source", "hs_noise_enabled", "mode", "maint_enabled"].index(k)] = v
+        elif k in ("heat_source", "hs_noise_enabled", "mode", "maint_enabled", "info_reactivity_components"):
+            self._iview()[["heat_source", "hs_noise_enabled", "mode", "maint_enabled", "info_reactivity_components"].index(k)] = v
         else:
             raise AttributeError(k)
 
@@ -178,7 +178,11 @@ class OraclePlants:
         a = col(action, np.int32); m = col(magnitude, np.float64); sp = col(setpoint, np.float64)
         z = col(noise_z, np.float64); cw = col(cw_temp, np.float64)
         obs = np.zeros((n, 22)); rew = np.zeros(n); done = np.zeros(n, dtype=np.uint8)
-        flags = np.zeros(n, dtype=np.uint32); info = np.zeros((n, 14))
+        flags = np.zeros(n, dtype=np.uint32)
+        with_rho = bool(self.params.info_reactivity_components and self.params.heat_source == 1)
+        buf = np.zeros(n * (14 + (10 if with_rho else 0)))
         self.L.npo_step_batch(_ptr(self._buf), n, self.params.ptr, _ptr(a), _ptr(m), _ptr(sp), _ptr(z), _ptr(cw),
-                              _ptr(obs), _ptr(rew), _ptr(done), _ptr(flags), _ptr(info))
+                              _ptr(obs), _ptr(rew), _ptr(done), _ptr(flags), _ptr(buf))
+        info = buf[: n * 14].reshape(n, 14)
+        self.reactivity_components = buf[n * 14:].reshape(n, 10) if with_rho else None   # second block of the info buffer
         return obs, rew, done, flags, info

@@ -109,6 +109,8 @@ NPO_API void npo_step_batch(npo_plant_t *plants, int n, const npb_params_t *P,
     if (done) done[i] = o.done;
     if (trip_flags) trip_flags[i] = o.trip_flags;
     if (info) memcpy(info + (size_t)i * NPB_INFO_DIM, o.info, sizeof(o.info));
+    if (info && P->info_reactivity_components && P->heat_source == NPB_HEAT_REACTOR)   /* second block, as npb_step lays it out */
+      memcpy(info + (size_t)n * NPB_INFO_DIM + (size_t)i * NPB_INFO_NRHO, o.rho, sizeof(o.rho));
   }
 }
 NPO_API void npo_observe_batch(npo_plant_t *plants, int n, const npb_params_t *P, double *obs) {

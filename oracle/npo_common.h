@@ -49,6 +49,7 @@ typedef struct npo_outputs_t {
   double obs[NPB_OBS_DIM];
   double reward;
   double info[NPB_INFO_DIM];
+  double rho[NPB_INFO_NRHO];   /* reactivity components (reactor heat source only; NaN otherwise) */
   uint32_t trip_flags;
   uint8_t done;
 } npo_outputs_t;

@@ -33,6 +33,7 @@ NPO_FN void npo_observation(const npo_plant_t *pl, int mode, double *obs) {
   obs[9] = s->steam_valve_position / 100;
   obs[10] = s->power_level / 100;
   obs[11] = (double)(s->scram_status != 0);
+  if (mode == NPB_MODE_PRIMARY) { for (int k = 12; k < NPB_OBS_DIM; k++) obs[k] = 0.0; return; }   /* sim.py:333: twelve values */
   obs[12] = sec->electrical_power_output / 1100;
   obs[13] = sec->thermal_efficiency / 0.35;
   obs[14] = sec->total_steam_flow / 1665;
@@ -78,7 +79,21 @@ NPO_FN void npo_step(npo_plant_t *pl, const npb_params_t *P, const npo_inputs_t 
   if (!isnan(in->cooling_water_temp)) pl->sec.cooling_water_temperature = in->cooling_water_temp; /* sim.py:138-139 */
 
   int nan_reset = 0;
-  int scram_fired = npo_primary_update(s, P, in, &nan_reset);
+  for (int k = 0; k < NPB_INFO_NRHO; k++) out->rho[k] = NAN;
+  int scram_fired = npo_primary_update(s, P, in, &nan_reset, out->rho);
+
+  if (P->mode == NPB_MODE_PRIMARY) {   /* enable_secondary=False: sim.py:155 skips coupling, secondary update and feedback */
+    s->sim_time += P->dt;
+    npo_observation(pl, P->mode, out->obs);
+    out->reward = npo_reward(pl, 0);
+    out->done = (uint8_t)scram_fired;
+    out->trip_flags = (s->scram_status ? NPB_TRIP_SCRAM : 0) | (scram_fired ? NPB_TRIP_SCRAM_FIRED : 0) | (nan_reset ? NPB_TRIP_NAN_RESET : 0);
+    for (int k = 0; k < NPB_INFO_DIM; k++) out->info[k] = NAN;   /* the secondary keys are absent from the reference's dict */
+    out->info[NPB_INFO_THERMAL_POWER] = s->thermal_power_mw;
+    out->info[NPB_INFO_REACTIVITY_PCM] = s->total_reactivity_pcm;
+    out->info[NPB_INFO_TIME] = s->sim_time;
+    return;
+  }
 
   npo_coupling_t c;
   npo_primary_to_secondary(s, &c);

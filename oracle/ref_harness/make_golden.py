@@ -180,6 +180,15 @@ def scenarios():
                   secondary={"feedwater": {"initial_conditions": {"pump_oil_levels": [59.4, 62.0, 64.0, 90.0], "pump_oil_contamination": 8.0,
                                                                    "seal_face_wear": [12.0, 0.1, 0.1, 0.1], "motor_bearing_wear": [1.0, 0.1, 0.1, 0.0],
                                                                    "motor_temperature": [71.0, 72.0, 73.0, 74.0]}}}))
+    # K1: info["reactivity_components"] (sim.py:205) of the reactor model, through rod / boron actions and a scram
+    S.append(dict(name="k1_reactivity_components", steps=160, heat_source="reactor", equilibrium=(100.0, 95.0), every=4,
+                  actions=lambda t: (int(acts[t]), float(mags[t])),
+                  pokes={110: [("primary_physics.state.neutron_flux", 1.6e13)]}))
+    # P1/P2: NuclearPlantSimulator(enable_secondary=False): the primary side alone, 12 observations, base reward
+    S.append(dict(name="p1_primary_only_reactor", steps=120, heat_source="reactor", equilibrium=(100.0, 95.0), every=3, enable_secondary=False,
+                  actions=lambda t: (int(acts[t]), float(mags[t])), resets={70: True}))
+    S.append(dict(name="p2_primary_only_constant", steps=80, noise=True, noise_seed=21, every=2, enable_secondary=False,
+                  setpoints=lambda t: 100.0 - 0.5 * t if t < 40 else None))
     return S
 
 
@@ -211,7 +220,7 @@ def main(only=None):
                             cooling=ref["cooling"], noise_z=ref["noise_z"], obs=ref["obs"], reward=ref["reward"],
                             done=ref["done"], info=ref["info"], state_steps=np.array(steps),
                             reset_steps=ref["reset_steps"], reset_modes=ref["reset_modes"], reset_obs=ref["reset_obs"],
-                            reset_state=ref["reset_state"], sec_keys=ref["sec_keys"], sec=ref["sec"],
+                            reset_state=ref["reset_state"], sec_keys=ref["sec_keys"], sec=ref["sec"], rc_keys=ref["rc_keys"], rc=ref["rc"],
                             state=ref["state"][steps], labels=labels, kinds=kinds, paths=paths, meta=json.dumps(meta))
         print(sc["name"], "steps", T, "dones", int(ref["done"].sum()), "elec", float(ref["obs"][-1, 12] * 1100))
 

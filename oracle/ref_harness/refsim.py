@@ -115,7 +115,7 @@ def quiet():
 
 
 def make_sim(dt=1.0, heat_source="constant", noise=False, noise_std_percent=0.1,
-             noise_seed=42, secondary=None, state_management=False):
+             noise_seed=42, secondary=None, state_management=False, enable_secondary=True):
     """Construct a reference NuclearPlantSimulator."""
     setup()
     with quiet():
@@ -129,7 +129,7 @@ def make_sim(dt=1.0, heat_source="constant", noise=False, noise_std_percent=0.1,
             hs = ReactorHeatSource(3000.0)
         cfg = {"secondary_system": secondary or {}}
         sim = NuclearPlantSimulator(dt=dt, heat_source=hs, secondary_config=cfg,
-                                    enable_state_management=state_management)
+                                    enable_state_management=state_management, enable_secondary=enable_secondary)
     return sim
 
 

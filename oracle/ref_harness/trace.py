@@ -5,6 +5,8 @@ Harness-only (needs /root/reference; see refsim.py).
 Scenario dict keys:
   name, steps, dt, heat_source ("constant"|"reactor"), noise (bool), noise_seed,
   noise_std_percent, secondary (IC override dict for SecondarySystemConfig.from_dict),
+  enable_secondary: False -> NuclearPlantSimulator(enable_secondary=False): 12 observations (recorded in obs[:, :12], the
+          rest 0), no secondary keys in info (recorded as NaN),
   equilibrium: (power, rods) -> start ReactorState from create_equilibrium_state,
   actions: {step: (action_id, magnitude)} or callable(step)->(action, magnitude),
   setpoints: callable(step)->percent or None,
@@ -67,7 +69,8 @@ def run_reference(sc, columns):
     else:
       sim = refsim.make_sim(dt=sc.get("dt", 1.0), heat_source=sc.get("heat_source", "constant"),
                           noise=sc.get("noise", False), noise_std_percent=sc.get("noise_std_percent", 0.1),
-                          noise_seed=sc.get("noise_seed", 42), secondary=sc.get("secondary"))
+                          noise_seed=sc.get("noise_seed", 42), secondary=sc.get("secondary"),
+                          enable_secondary=sc.get("enable_secondary", True))
     from systems.primary import ControlAction
     if sc.get("thresholds_override"):
         # edit the live maintenance thresholds of every feedwater pump (what another maintenance configuration would load)
@@ -99,6 +102,7 @@ def run_reference(sc, columns):
         z[:] = np.random.RandomState(sc.get("noise_seed", 42)).standard_normal(T)
     actions = sc.get("actions")
     sec_keys, sec_rows = None, []
+    rc_keys, rc_rows = None, []     # info["reactivity_components"] (sim.py:205), in the dict's own order
     resets = sc.get("resets", {})
     reset_steps, reset_modes, reset_obs, reset_state = [], [], [], []
     for t in range(T):
@@ -107,7 +111,7 @@ def run_reference(sc, columns):
         if t in resets:
             with refsim.quiet():
                 ob = sim.reset(start_at_steady_state=bool(resets[t]))
-            reset_steps.append(t); reset_modes.append(int(bool(resets[t]))); reset_obs.append(np.asarray(ob, dtype=np.float64))
+            reset_steps.append(t); reset_modes.append(int(bool(resets[t]))); reset_obs.append(np.concatenate([np.asarray(ob, dtype=np.float64), np.zeros(22 - len(ob))]))
             reset_state.append([_val(sim, p) for p in paths])
         if actions is not None:
             a = actions(t) if callable(actions) else actions.get(t)
@@ -129,13 +133,17 @@ def run_reference(sc, columns):
                 cw[t] = v; kw["cooling_water_temp"] = v
         with refsim.quiet():
             r = sim.step(ControlAction(int(act[t])), magnitude=float(mag[t]), **kw)
-        obs[t] = r["observation"]; rew[t] = r["reward"]; done[t] = bool(r["done"])
+        obs[t, :len(r["observation"])] = r["observation"]; rew[t] = r["reward"]; done[t] = bool(r["done"])
         i = r["info"]
         info[t] = [i["thermal_power"], i["reactivity"], i.get("electrical_power", np.nan),
                    i.get("thermal_efficiency", np.nan), i.get("steam_flow", np.nan),
                    i.get("steam_pressure", np.nan), i.get("condenser_pressure", np.nan),
                    i.get("condenser_heat_rejection", np.nan), i["time"],
                    i["secondary_system"]["feedwater_total_flow"] if "secondary_system" in i else np.nan]
+        rc = i.get("reactivity_components") or {}
+        if rc_keys is None:
+            rc_keys = list(rc.keys())
+        rc_rows.append([float(rc[k]) for k in rc_keys])
         ss = i.get("secondary_system", {})
         if sec_keys is None:   # every scalar key of SecondaryReactorPhysics.update_system's result (secondary/__init__.py:922-1010)
             sec_keys = [k for k, v in ss.items() if isinstance(v, (bool, int, float, np.floating, np.integer, np.bool_))]
@@ -143,6 +151,7 @@ def run_reference(sc, columns):
         state[t + 1] = [_val(sim, p) for p in paths]
     return dict(state=state, obs=obs, reward=rew, done=done, info=info,
                 action=act, magnitude=mag, setpoint=sp, cooling=cw, noise_z=z,
+                rc_keys=np.array(rc_keys or []), rc=np.array(rc_rows, dtype=np.float64).reshape(T, len(rc_keys or [])),
                 sec_keys=np.array(sec_keys or []), sec=np.array(sec_rows, dtype=np.float64).reshape(T, len(sec_keys or [])),
                 reset_steps=np.array(reset_steps, dtype=np.int64), reset_modes=np.array(reset_modes, dtype=np.int64),
                 reset_obs=np.array(reset_obs, dtype=np.float64).reshape(len(reset_steps), 22),

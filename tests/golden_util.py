@@ -46,6 +46,9 @@ class Golden:
         # the scalar keys of info["secondary_system"] per step (fixtures made before they were recorded have none)
         self.sec_keys = [str(k) for k in z["sec_keys"]] if "sec_keys" in z.files else []
         self.sec = z["sec"] if "sec" in z.files else None
+        # info["reactivity_components"] per step, in the reference dict's own order (reactor heat source; newer fixtures)
+        self.rc_keys = [str(k) for k in z["rc_keys"]] if "rc_keys" in z.files else []
+        self.rc = z["rc"] if "rc_keys" in z.files and len(z["rc_keys"]) else None
         # NuclearPlantSimulator.reset() calls recorded in the run: {step: (start_at_steady_state, obs, state row)}
         self.resets = {}
         if "reset_steps" in z.files:

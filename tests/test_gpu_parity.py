@@ -18,6 +18,8 @@ def _env(g=None, n=1, **kw):
         kw.setdefault("noise_enabled", bool(m.get("noise")))
         kw.setdefault("noise_std_percent", m.get("noise_std_percent", 0.1))
         kw.setdefault("maintenance", bool(m.get("runner")))
+        kw.setdefault("mode", "full" if m.get("enable_secondary", True) else "primary")   # NuclearPlantSimulator(enable_secondary=False)
+        kw.setdefault("reactivity_components", g.rc is not None)
         if m.get("maint_thresholds"):    # the run used a maintenance configuration other than the default one
             kw.setdefault("maintenance_thresholds", dict((nm, c) for nm, c in m["maint_thresholds"]))
     return BatchedPlantEnv(n, **kw)
@@ -90,11 +92,17 @@ def test_hip_replays_golden(name):
             np.testing.assert_allclose(obs[lane], g.obs[t], rtol=RTOL, atol=1e-12, err_msg="%s obs step %d" % (name, t))
             np.testing.assert_allclose(rew[lane], g.reward[t], rtol=RTOL, atol=1e-9, err_msg="%s reward step %d" % (name, t))
             assert int(done[lane]) == int(g.done[t]), "%s done step %d" % (name, t)
+        if g.rc is not None:    # info["reactivity_components"] (sim.py:205), the ten terms of the reactor model in the dict's order
+            rho = info["reactivity_components"]
+            assert list(rho) == g.rc_keys
+            for j, k in enumerate(g.rc_keys):
+                for lane in (0, n - 1):
+                    np.testing.assert_allclose(rho[k][lane].item(), g.rc[t, j], rtol=RTOL, atol=1e-9, err_msg="%s reactivity_components[%s] step %d" % (name, k, t))
         if t + 1 in sampled:
             fs, is_ = _host_state(env)
             compare_state(g, fs[:, 0], is_[:, 0], g.state[sampled[t + 1]], "after step %d" % t)
             compare_state(g, fs[:, n - 1], is_[:, n - 1], g.state[sampled[t + 1]], "after step %d (lane 63)" % t)
-        if g.sec is not None and t % 7 == 0:
+        if g.sec is not None and g.sec.shape[1] and t % 7 == 0:
             # the scalar keys of the reference's info["secondary_system"], heat-flow / chemistry-flow tracker outputs included
             res = env.secondary_result()
             checked = 0
@@ -930,3 +938,48 @@ def test_set_params_takes_effect_at_the_next_step(oracle_lib):
         obs = env.step(noise_z=z)[0].cpu().numpy()
         np.testing.assert_allclose(obs, o_obs, rtol=RTOL, atol=1e-12, err_msg="step %d" % t)
     assert abs(env.get_field("prim.sim_time")[0].item() - (6 * 1.0 + 6 * 0.25)) < 1e-12
+
+
+def test_facade_without_a_secondary_side_and_with_the_reactor_models_terms(tmp_path):
+    """NuclearPlantSimulator(enable_secondary=False) (sim.py:155,309,333): twelve observations, the primary keys of info
+    only; with the reactor heat source info["reactivity_components"] carries the model's ten terms and they add up to
+    info["reactivity"]; info["datetime"] advances by dt minutes per step from the state manager's random start date and
+    is None without state management; secondary_config_file is read as the reference reads it (YAML, its
+    secondary_system section)."""
+    import datetime
+    from nuclear_sim_amd.env import NuclearPlantSimulator, NuclearPlantEnv, ConstantHeatSource, ReactorHeatSource, ControlAction
+    g = Golden("p1_primary_only_reactor")
+    sim = NuclearPlantSimulator(dt=1.0, heat_source=ReactorHeatSource(), enable_secondary=False, enable_state_management=False)
+    assert sim.secondary_physics is None
+    f0, i0 = _host_state(sim._env)
+    f, i, fm, im = g.split_state(g.state[0])
+    f0[fm, :] = f[fm, None]; i0[im, :] = i[im, None]
+    sim._env.load_state_arrays(f0, i0)
+    for t in range(40):
+        r = sim.step(ControlAction(int(g.action[t])), magnitude=float(g.magnitude[t]))
+        assert r["observation"].shape == (12,)
+        np.testing.assert_allclose(r["observation"], g.obs[t, :12], rtol=RTOL, atol=1e-12)
+        np.testing.assert_allclose(r["reward"], g.reward[t], rtol=RTOL, atol=1e-9)
+        inf = r["info"]
+        assert "secondary_system" not in inf and "electrical_power" not in inf and inf["datetime"] is None
+        np.testing.assert_allclose([inf["thermal_power"], inf["reactivity"], inf["time"]], g.info[t, [0, 1, 8]], rtol=RTOL, atol=1e-9)
+        assert list(inf["reactivity_components"]) == g.rc_keys
+        np.testing.assert_allclose(list(inf["reactivity_components"].values()), g.rc[t], rtol=RTOL, atol=1e-9)
+        assert sum(inf["reactivity_components"].values()) == pytest.approx(inf["reactivity"], rel=1e-12, abs=1e-9)
+    assert sim.get_observation().shape == (12,) and NuclearPlantEnv(enable_secondary=False, heat_source="constant").observation_space_size == 12
+    # the state manager's clock
+    sim = NuclearPlantSimulator(dt=5.0, heat_source=ConstantHeatSource(noise_enabled=False))
+    a = datetime.datetime.fromisoformat(sim.step()["info"]["datetime"])
+    sim.reset()
+    r = sim.step()
+    b = datetime.datetime.fromisoformat(r["info"]["datetime"])
+    assert b - a == datetime.timedelta(minutes=5.0) and 2020 <= a.year <= 2030 and r["info"]["reactivity_components"] == {}
+    # a configuration file
+    import yaml
+    cfg = {"secondary_system": {"feedwater": {"initial_conditions": {"pump_oil_levels": [61.0, 62.0, 63.0, 64.0]}}},
+           "maintenance_system": {"maintenance_mode": "conservative"}}
+    path = tmp_path / "plant.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    sim = NuclearPlantSimulator(dt=1.0, heat_source=ConstantHeatSource(noise_enabled=False), secondary_config_file=str(path))
+    assert [sim._env.get_field("pump.oil_level", instance=k)[0].item() for k in range(4)] == [61.0, 62.0, 63.0, 64.0]
+    assert sim._env.params.maint_start_delay_hours == 1.0

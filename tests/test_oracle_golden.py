@@ -14,6 +14,8 @@ def _configure(npo, g):
     P.hs_noise_enabled = 1 if m.get("noise") else 0
     P.hs_noise_std_percent = m.get("noise_std_percent", 0.1)
     P.maint_enabled = 1 if m.get("runner") else 0  # fixtures made through the data-gen runner have auto-maintenance on
+    P.mode = 0 if m.get("enable_secondary", True) else 2     # NuclearPlantSimulator(enable_secondary=False)
+    P.info_reactivity_components = 1 if g.rc is not None else 0
     # the maintenance thresholds the run used, when they are not the default configuration's
     from nuclear_sim_amd import _lib
     npo.set_maint_table(_lib.maint_table_from_thresholds(dict((n, c) for n, c in m["maint_thresholds"])) if m.get("maint_thresholds") else None)
@@ -74,6 +76,10 @@ def test_oracle_replays_golden(oracle_lib, name):
         assert int(done[0]) == int(g.done[t]), "%s done step %d" % (name, t)
         m = ~np.isnan(g.info[t])
         np.testing.assert_allclose(info[0][:g.info.shape[1]][m], g.info[t][m], rtol=RTOL, atol=1e-9, err_msg="%s info step %d" % (name, t))
+        if g.rc is not None:   # info["reactivity_components"], key order = include/npb.h NPB_RHO_*
+            from nuclear_sim_amd import _lib
+            assert tuple(g.rc_keys) == _lib.REACTIVITY_COMPONENTS
+            np.testing.assert_allclose(o.reactivity_components[0], g.rc[t], rtol=RTOL, atol=1e-9, err_msg="%s reactivity components step %d" % (name, t))
         if t + 1 in sampled:
             fs, is_ = o.state()
             compare_state(g, fs, is_, g.state[sampled[t + 1]], "after step %d" % t)
