@@ -25,7 +25,7 @@
 
 /* ---- exp / log for this kernel.  The device library's fp64 exp / log / log10 cost ~50 / ~105 / ~115
  * instructions; a step evaluates a few hundred of them and, with one wave per SIMD, every instruction is
- * paid in full.  These versions cost ~25 / ~40 and stay within 4e-16 relative of libm (CPU mirror checked on
+ * paid in full.  These versions cost ~21 / ~34 (plus their literals) and stay within 4e-16 relative of libm (CPU mirror checked on
  * 4e6 points over 1e-13..1e13, tools/fastmath_check.c), far inside the 1e-6 parity budget.
  * Domain handling kept: log(0) = -inf, log(x<0) = NaN, log(inf) = inf, exp(-inf) = 0, exp(inf) = inf, NaN in ->
  * NaN out. */
@@ -38,38 +38,41 @@ NPD_FN double npd_rcp(double y) { /* 1 / y to working precision: hardware seed +
 NPD_FN double npd_log(double x) {
   double m = __builtin_amdgcn_frexp_mant(x); /* [0.5, 1) */
   int e = __builtin_amdgcn_frexp_exp(x);
-  const bool low = m < 0.70710678118654752440;
-  m = low ? m * 2.0 : m;
-  e = low ? e - 1 : e;
-  const double f = m - 1.0, g = 2.0 + f;
-  const double r = npd_rcp(g);
+  /* into [sqrt(1/2), sqrt(2)) by integer arithmetic on the high word: no compare, no select (each costs a lone wave ~20 cycles) */
+  const uint32_t hm = (uint32_t)__double2hiint(m);
+  const uint32_t low = (hm - 0x3fe6a09eu) >> 31;
+  m = __hiloint2double((int)(hm + (low << 20)), __double2loint(m));
+  e -= (int)low;
+  const double f = m - 1.0, g = m + 1.0;
+  double r = __builtin_amdgcn_rcp(g);                     /* seed + one Newton step; the quotient below is corrected once more */
+  r = __builtin_fma(__builtin_fma(-g, r, 1.0), r, r);
   double s = f * r;
   s = __builtin_fma(__builtin_fma(-g, s, f), r, s);
   const double z = s * s;
-  double p = 2.0 / 21.0; /* 2 atanh(s) = 2s + 2s^3/3 + ..., |s| <= 0.1716 */
-  p = __builtin_fma(p, z, 2.0 / 19.0); p = __builtin_fma(p, z, 2.0 / 17.0); p = __builtin_fma(p, z, 2.0 / 15.0);
-  p = __builtin_fma(p, z, 2.0 / 13.0); p = __builtin_fma(p, z, 2.0 / 11.0); p = __builtin_fma(p, z, 2.0 / 9.0);
-  p = __builtin_fma(p, z, 2.0 / 7.0); p = __builtin_fma(p, z, 2.0 / 5.0); p = __builtin_fma(p, z, 2.0 / 3.0);
+  double p = 0.14616878919029820754;  /* near-minimax for (2 atanh(s) - 2s) / s^3 in z = s^2, |s| <= 0.1716 (mpmath chebyfit, 3e-16) */
+  p = __builtin_fma(p, z, 0.15331686868638428253); p = __builtin_fma(p, z, 0.18182890170313970214); p = __builtin_fma(p, z, 0.22222211120449298486);
+  p = __builtin_fma(p, z, 0.28571428626063380364); p = __builtin_fma(p, z, 0.39999999999899310681); p = __builtin_fma(p, z, 0.66666666666666696929);
   const double lm = __builtin_fma(s * z, p, 2.0 * s);
   const double de = (double)e;
-  double res = __builtin_fma(de, 6.93147180369123816490e-01, __builtin_fma(de, 1.90821492927058770002e-10, lm));
-  res = (x == 0.0) ? -INFINITY : res;
-  res = (x < 0.0) ? NAN : res;
-  res = (x == INFINITY) ? INFINITY : res;
-  return res;
+  const double res = __builtin_fma(de, 6.93147180369123816490e-01, __builtin_fma(de, 1.90821492927058770002e-10, lm));
+  /* everything but a positive finite number (zero, negative, +inf, NaN): one class test, and the value the float unit's own
+   * logarithm gives for it: log(+-0) = -inf, log(x < 0) = NaN, log(inf) = inf, NaN -> NaN */
+  const double special = (double)__builtin_amdgcn_logf((float)x);
+  return __builtin_amdgcn_class(x, 0x27f) ? special : res;
 }
 NPD_FN double npd_exp(double x) {
-  double xc = (x < -800.0) ? -800.0 : x; /* NaN falls through both comparisons */
-  xc = (xc > 800.0) ? 800.0 : xc;
+  const double xc = __builtin_fmin(__builtin_fmax(x, -800.0), 800.0);   /* v_max / v_min: a NaN is put back at the end */
   const double n = __builtin_rint(xc * 1.44269504088896338700e+00);
   double r = __builtin_fma(-n, 6.93147180369123816490e-01, xc);
   r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
-  double p = 1.0 / 6227020800.0; /* Taylor to r^13, |r| <= 0.3466 */
-  p = __builtin_fma(p, r, 1.0 / 479001600.0); p = __builtin_fma(p, r, 1.0 / 39916800.0); p = __builtin_fma(p, r, 1.0 / 3628800.0);
-  p = __builtin_fma(p, r, 1.0 / 362880.0); p = __builtin_fma(p, r, 1.0 / 40320.0); p = __builtin_fma(p, r, 1.0 / 5040.0);
-  p = __builtin_fma(p, r, 1.0 / 720.0); p = __builtin_fma(p, r, 1.0 / 120.0); p = __builtin_fma(p, r, 1.0 / 24.0);
-  p = __builtin_fma(p, r, 1.0 / 6.0); p = __builtin_fma(p, r, 0.5); p = __builtin_fma(p, r, 1.0); p = __builtin_fma(p, r, 1.0);
-  return __builtin_amdgcn_ldexp(p, (int)n); /* overflow -> inf, underflow -> 0 */
+  double q = 2.5100385495510319077e-8;   /* near-minimax for (exp(r) - 1 - r) / r^2, |r| <= ln2 / 2 (mpmath chebyfit, 1e-16) */
+  q = __builtin_fma(q, r, 2.762008844540974816e-7); q = __builtin_fma(q, r, 2.7557268459997064772e-6); q = __builtin_fma(q, r, 0.000024801521295954375131);
+  q = __builtin_fma(q, r, 0.00019841269863053616878); q = __builtin_fma(q, r, 0.0013888888917213716901); q = __builtin_fma(q, r, 0.0083333333333300618325);
+  q = __builtin_fma(q, r, 0.041666666666624127873); q = __builtin_fma(q, r, 0.16666666666666667453); q = __builtin_fma(q, r, 0.50000000000000010221);
+  const double p = __builtin_fma(__builtin_fma(q, r, 1.0), r, 1.0);
+  const double res = __builtin_amdgcn_ldexp(p, (int)n); /* overflow -> inf, underflow -> 0 */
+  /* NaN in -> NaN out: only the high word needs the select */
+  return __hiloint2double(__builtin_isnan(x) ? 0x7ff80000 : __double2hiint(res), __double2loint(res));
 }
 NPD_FN double npd_log10(double x) { return npd_log(x) * 4.34294481903251827651e-01; }
 

@@ -3,39 +3,47 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <string.h>
 static double f_rcp(double y) { // mirror: v_rcp_f64 (~1e-8 rel?) + 2 Newton steps; emulate with float-precision seed
   double r = (double)(1.0f / (float)y);
   r = fma(fma(-y, r, 1.0), r, r);
   r = fma(fma(-y, r, 1.0), r, r);
   return r;
 }
+static double f_rcp1(double y) { // seed + ONE Newton step (the quotient that uses it is corrected once more)
+  double r = (double)(1.0f / (float)y);
+  return fma(fma(-y, r, 1.0), r, r);
+}
 static double f_log(double x) {
   int e; double m = frexp(x, &e);               // m in [0.5,1)
-  if (m < 0.70710678118654752440) { m *= 2.0; e -= 1; }
-  double f = m - 1.0;
-  double r = f_rcp(2.0 + f);
+  uint64_t bits; memcpy(&bits, &m, 8);
+  uint32_t hm = (uint32_t)(bits >> 32);
+  uint32_t low = (hm - 0x3fe6a09eu) >> 31;      // 1 when m < ~sqrt(1/2): integer arithmetic on the high word, no compare / select
+  bits += (uint64_t)(low << 20) << 32; memcpy(&m, &bits, 8);
+  e -= (int)low;
+  double f = m - 1.0, g = m + 1.0;
+  double r = f_rcp1(g);
   double s = f * r;
-  s = fma(fma(-(2.0 + f), s, f), r, s);          // one correction of the quotient
+  s = fma(fma(-g, s, f), r, s);                  // one correction of the quotient
   double z = s * s;
-  double p = 2.0 / 21.0;
-  p = fma(p, z, 2.0 / 19.0); p = fma(p, z, 2.0 / 17.0); p = fma(p, z, 2.0 / 15.0); p = fma(p, z, 2.0 / 13.0);
-  p = fma(p, z, 2.0 / 11.0); p = fma(p, z, 2.0 / 9.0); p = fma(p, z, 2.0 / 7.0); p = fma(p, z, 2.0 / 5.0);
-  p = fma(p, z, 2.0 / 3.0);
+  double p = 0.14616878919029820754;             // near-minimax for (log((1+s)/(1-s)) - 2s) / s^3 in z = s^2, |s| <= 0.1716
+  p = fma(p, z, 0.15331686868638428253); p = fma(p, z, 0.18182890170313970214); p = fma(p, z, 0.22222211120449298486);
+  p = fma(p, z, 0.28571428626063380364); p = fma(p, z, 0.39999999999899310681); p = fma(p, z, 0.66666666666666696929);
   double lm = fma(s * z, p, 2.0 * s);
   double de = (double)e;
   return fma(de, 6.93147180369123816490e-01, fma(de, 1.90821492927058770002e-10, lm));
 }
 static double f_exp(double x) {
-  double n = rint(x * 1.44269504088896338700e+00);
-  double r = fma(-n, 6.93147180369123816490e-01, x);
+  double xc = fmin(fmax(x, -800.0), 800.0);
+  double n = rint(xc * 1.44269504088896338700e+00);
+  double r = fma(-n, 6.93147180369123816490e-01, xc);
   r = fma(-n, 1.90821492927058770002e-10, r);
-  double p = 1.0 / 6227020800.0;                 // 1/13!
-  p = fma(p, r, 1.0 / 479001600.0); p = fma(p, r, 1.0 / 39916800.0); p = fma(p, r, 1.0 / 3628800.0);
-  p = fma(p, r, 1.0 / 362880.0); p = fma(p, r, 1.0 / 40320.0); p = fma(p, r, 1.0 / 5040.0); p = fma(p, r, 1.0 / 720.0);
-  p = fma(p, r, 1.0 / 120.0); p = fma(p, r, 1.0 / 24.0); p = fma(p, r, 1.0 / 6.0); p = fma(p, r, 0.5);
-  p = fma(p, r, 1.0); p = fma(p, r, 1.0);
-  double nn = n; if (nn > 2000) nn = 2000; if (nn < -2000) nn = -2000;
-  return ldexp(p, (int)nn);
+  double q = 2.5100385495510319077e-8;           // near-minimax for (exp(r) - 1 - r) / r^2, |r| <= ln2 / 2
+  q = fma(q, r, 2.762008844540974816e-7); q = fma(q, r, 2.7557268459997064772e-6); q = fma(q, r, 0.000024801521295954375131);
+  q = fma(q, r, 0.00019841269863053616878); q = fma(q, r, 0.0013888888917213716901); q = fma(q, r, 0.0083333333333300618325);
+  q = fma(q, r, 0.041666666666624127873); q = fma(q, r, 0.16666666666666667453); q = fma(q, r, 0.50000000000000010221);
+  double p = fma(fma(q, r, 1.0), r, 1.0);
+  return ldexp(p, (int)n);
 }
 int main() {
   double maxl = 0, maxe = 0, maxp = 0; srand(1);
