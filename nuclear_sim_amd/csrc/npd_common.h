@@ -74,6 +74,17 @@ NPD_FN double npd_exp(double x) {
   /* NaN in -> NaN out: only the high word needs the select */
   return __hiloint2double(__builtin_isnan(x) ? 0x7ff80000 : __double2hiint(res), __double2loint(res));
 }
+/* sqrt for the magnitudes of this path (exact zeros, and 1e-200 .. 1e200 otherwise): hardware rsq seed, one coupled
+ * Newton step and one residual correction (the device library's version spends 8 more instructions on rescaling
+ * operands outside that range); sqrt(+-0) = +-0, sqrt(inf) = inf, negative and NaN operands give NaN */
+NPD_FN double npd_sqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return __builtin_amdgcn_class(x, 0x260) ? x : g;
+}
 NPD_FN double npd_log10(double x) { return npd_log(x) * 4.34294481903251827651e-01; }
 
 /* x^c for x >= 0: exp(c * log(x)); npd_powc(0, c) = 0 for c > 0 is preserved (log(0) = -inf, exp(-inf) = 0) */

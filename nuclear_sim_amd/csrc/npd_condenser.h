@@ -151,9 +151,9 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
       if (suction < 0.003 || suction > 0.015) capacity = 0.0;         /* calculate_steam_jet_performance :96-190 */
       else if (motive_p < 0.8) capacity = 0.0;
       else {
-        double pressure_capacity_factor = sqrt(motive_p / 1.0);
+        double pressure_capacity_factor = npd_sqrt(motive_p / 1.0);
         double temp_ratio = (motive_steam_temperature + 273.15) / (180.0 + 273.15);
-        double temp_capacity_factor = npd_powc(temp_ratio, 0.25);
+        double temp_capacity_factor = npd_sqrt(npd_sqrt(temp_ratio));   /* ** 0.25 */
         double suction_pressure_ratio = suction / 0.007;
         double suction_capacity_factor = 1.0 / (1.0 + 0.5 * (suction_pressure_ratio - 1.0));
         double available_capacity = (25.0 * pressure_capacity_factor * temp_capacity_factor * suction_capacity_factor * overall);

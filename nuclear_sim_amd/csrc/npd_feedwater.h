@@ -102,7 +102,7 @@ NPD_FN void npd_pump_set_flow_demand(npb_pump_t *p, double flow_demand) {
   if (flow_demand > 0) {
     double effective_capacity = NPD_PUMP_RATED_FLOW * npd_pump_flow_factor(p);
     double speed_setpoint;
-    if (effective_capacity > 0) speed_setpoint = sqrt(flow_demand / effective_capacity) * 100.0;
+    if (effective_capacity > 0) speed_setpoint = npd_sqrt(flow_demand / effective_capacity) * 100.0;
     else speed_setpoint = 100.0;
     p->speed_setpoint = npd_clip(speed_setpoint, 0.0, 100.0);
   } else {
@@ -189,9 +189,8 @@ NPD_FN void npd_pump_update(npb_pump_t *p, const npd_pump_sysconds_t *sc, double
 
   /* update_component_wear  lubrication_base.py:354-401 with calculate_component_wear
    * pump_lubrication.py:275-396; wear levels are read live, so later components see earlier updates */
-  /* the four distinct bases of the wear-rate powers; every rate is then one exp of a sum of their logarithms */
-  const double l_electrical = npd_log(electrical_load_factor), l_speed = npd_log(speed_factor),
-               l_load = npd_log(load_factor), l_pressure = npd_log(pressure_factor);
+  /* the three distinct bases of the wear-rate powers with fractional exponents; every rate is then one exp of a sum of their logarithms */
+  const double l_electrical = npd_log(electrical_load_factor), l_speed = npd_log(speed_factor), l_load = npd_log(load_factor);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     const npd_lubcomp_t *c = &NPD_PUMP_COMP[i];
@@ -225,7 +224,7 @@ NPD_FN void npd_pump_update(npb_pump_t *p, const npd_pump_sysconds_t *sc, double
         double cavitation_seal_factor = 1.0 + cav * 5.0;
         double impeller_coupling = 1.0 + (impeller_wear / 100.0) * 0.15;
         double bearing_coupling = 1.0 + (max_bearing_wear / 100.0) * 0.2;
-        wear_rate = (c->base * npd_exp(c->load_exp * l_pressure) * 1.0 * cavitation_seal_factor * impeller_coupling * bearing_coupling);
+        wear_rate = (c->base * (pressure_factor * pressure_factor) * 1.0 * cavitation_seal_factor * impeller_coupling * bearing_coupling); /* load_exp = 2.0: the square itself */
       } break;
       default: {
         double bearing_coupling = 1.0 + (max_bearing_wear / 100.0) * 0.3;

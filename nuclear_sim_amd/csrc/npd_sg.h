@@ -49,7 +49,7 @@ NPD_FN double npd_tsp_average_thickness(const npb_sg_t *g) {
 
 /* TSPFoulingModel.calculate_heat_transfer_degradation  tsp_fouling_model.py:342-367 */
 NPD_FN double npd_tsp_ht_degradation(double ff) {
-  double mixing = npd_powc(ff, 1.5);
+  double mixing = ff * npd_sqrt(ff);   /* ff ** 1.5 */
   double maldist = ff * 0.3;
   double total = (mixing + maldist) * 0.6;
   return npd_pymin(total, 0.9);
@@ -87,7 +87,7 @@ NPD_FN void npd_tsp_update(npb_sg_t *g, const npb_params_t *P, double temperatur
   double temp_factor = npd_exp(-45000.0 / (8.314 * temp_kelvin));
   temp_factor = temp_factor / npd_exp(-45000.0 / (8.314 * 573.15));
   double ph_factor = 1.0 + 0.5 * fabs(P->sgchem_ph - 9.2);
-  double velocity_factor = sqrt(flow_velocity / 3.0);
+  double velocity_factor = npd_sqrt(flow_velocity / 3.0);
   velocity_factor = npd_clip(velocity_factor, 0.5, 2.0);
   double magnetite_rate = 2.5 * (1.0 + P->sgchem_iron * 1.5) * temp_factor * ph_factor * velocity_factor;
   double copper_rate = 0.8 * (1.0 + P->sgchem_copper * 2.0) * temp_factor * velocity_factor;
@@ -120,7 +120,7 @@ NPD_FN void npd_tsp_update(npb_sg_t *g, const npb_params_t *P, double temperatur
   mean /= NPB_NUM_TSP;
   double var = 0.0;
   for (int i = 0; i < NPB_NUM_TSP; i++) var += (levels[i] - mean) * (levels[i] - mean);
-  double stdv = sqrt(var / NPB_NUM_TSP);
+  double stdv = npd_sqrt(var / NPB_NUM_TSP);
   double maldistribution = npd_pymin(stdv / (mean + 0.01), 1.0);
   /* evaluate_shutdown_conditions */
   int shutdown = 0;
@@ -236,7 +236,7 @@ NPD_FN double npd_sg_part1(npb_sg_t *g, const npb_params_t *P, double primary_te
 NPD_FN void npd_sg_part2(npb_sg_t *g, const npb_params_t *P, double heat_transfer, double steam_flow_out, double feedwater_flow_in,
                          double feedwater_temp, double dt, npd_sg_result_t *res) {
   /* _apply_tsp_flow_restrictions :516-547 */
-  double flow_capacity_factor = 1.0 / sqrt(g->tsp_pressure_drop_ratio);
+  double flow_capacity_factor = 1.0 / npd_sqrt(g->tsp_pressure_drop_ratio);
   double actual_steam_flow = npd_pymin(steam_flow_out, P->sg_design_steam_flow_per_sg * flow_capacity_factor);
   double actual_feedwater_flow = npd_pymin(feedwater_flow_in, P->sg_design_feedwater_flow_per_sg * flow_capacity_factor);
   /* (_calculate_primary_flow_restriction :549-601 only feeds the result dict) */

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(
       for (int k = 0; k < 10; k++) {
         sat_a[k] = npd_tsat_antoine(p_self[k]);
         hg_a[k] = npd_hg_from_tsat(sat_a[k]);
-        tr_a[k] = sqrt(sqrt(p_self[k] / ((k == 0) ? sg_avg_pressure : p_self[k > 0 ? k - 1 : 0])));
+        tr_a[k] = npd_sqrt(npd_sqrt(p_self[k] / ((k == 0) ? sg_avg_pressure : p_self[k > 0 ? k - 1 : 0])));
       }
       NPD2_SYNCJ(8);                                                                                   /* #6 */
 #pragma unroll
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(
       for (int k = 10; k < 14; k++) {
         const double pk = XR(X_PSELF + k), pkm = XR(X_PSELF + k - 1);
         const double sat = npd_tsat_antoine(pk);
-        XW(X_SAT + k - 10, sat); XW(X_HG + k - 10, npd_hg_from_tsat(sat)); XW(X_TRATIO + k - 10, sqrt(sqrt(pk / pkm)));
+        XW(X_SAT + k - 10, sat); XW(X_HG + k - 10, npd_hg_from_tsat(sat)); XW(X_TRATIO + k - 10, npd_sqrt(npd_sqrt(pk / pkm)));
       }
 #pragma unroll
       for (int e = 0; e < 5; e++) XW(X_HGEXT + e, npd_hg_from_tsat(npd_tsat_antoine(XR(X_PEXT + e))));

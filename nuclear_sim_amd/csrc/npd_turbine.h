@@ -110,7 +110,7 @@ NPD_FN void npd_stage_expansion(int k, double actual_efficiency, double blade_co
   }
   double outlet_flow = inlet_flow - extraction_flow;
   double pr = self_outlet_pressure / inlet_pressure;
-  double outlet_temp_isentropic = (inlet_temperature + 273.15) * sqrt(sqrt(pr)) - 273.15;
+  double outlet_temp_isentropic = (inlet_temperature + 273.15) * npd_sqrt(npd_sqrt(pr)) - 273.15;
   double outlet_enthalpy_isentropic = npd_stage_steam_enthalpy(outlet_temp_isentropic, self_outlet_pressure);
   double quality_efficiency_factor = 1.0; /* steam_quality is the hard-coded 0.99 (:206) */
   double total_efficiency = (actual_efficiency * blade_condition_factor * fouling_factor * blade_wear_factor * quality_efficiency_factor);
@@ -318,7 +318,7 @@ NPD_FN void npd_stage_system_update(const npd_stage_t &st, const double *stg, do
   for (int k = 0; k < 14; k++) {
     sat_self[k] = npd_tsat_antoine(p_self[k]);
     hg_self[k] = npd_hg_from_tsat(sat_self[k]);
-    tratio[k] = sqrt(sqrt(p_self[k] / ((k == 0) ? inlet_pressure : p_self[k > 0 ? k - 1 : 0])));
+    tratio[k] = npd_sqrt(npd_sqrt(p_self[k] / ((k == 0) ? inlet_pressure : p_self[k > 0 ? k - 1 : 0])));
   }
 #pragma unroll
   for (int e = 0; e < 5; e++) hg_ext[e] = npd_hg_from_tsat(npd_tsat_antoine(p_ext[e]));
@@ -538,16 +538,16 @@ NPD_FN void npd_turbine_rotor(npb_turb_t *t, double stage_power_mw, double steam
   double vib_unbalance_force = npd_sq(t->rotor_speed / 60.0) * 0.1;
   double rotation_frequency = t->rotor_speed / 60.0;
   const double rotor_mass = 15000.0;
-  double natural_frequency = sqrt(avg_stiffness / rotor_mass) / (2 * NPD_PI);
+  double natural_frequency = npd_sqrt(avg_stiffness / rotor_mass) / (2 * NPD_PI);
   double frequency_ratio = rotation_frequency / natural_frequency;
-  double critical_damping = 2 * sqrt(avg_stiffness * rotor_mass);
+  double critical_damping = 2 * npd_sqrt(avg_stiffness * rotor_mass);
   double damping_ratio = avg_damping / critical_damping;
-  double denominator = sqrt(npd_sq(1 - npd_sq(frequency_ratio)) + npd_sq(2 * damping_ratio * frequency_ratio));
+  double denominator = npd_sqrt(npd_sq(1 - npd_sq(frequency_ratio)) + npd_sq(2 * damping_ratio * frequency_ratio));
   double unbalance_response = vib_unbalance_force / avg_stiffness / denominator;
   double thermal_response = t->thermal_bow * npd_sq(frequency_ratio) / denominator;
   double displacement_1x = (unbalance_response + thermal_response) * 39.37;
   double displacement_2x = displacement_1x * 0.1, displacement_3x = displacement_1x * 0.05;
-  double total_displacement = sqrt(npd_sq(displacement_1x) + npd_sq(displacement_2x) + npd_sq(displacement_3x));
+  double total_displacement = npd_sqrt(npd_sq(displacement_1x) + npd_sq(displacement_2x) + npd_sq(displacement_3x));
   t->vibration_displacement = total_displacement;
 
   *max_bearing_metal_out = max_bearing_metal; *total_displacement_out = total_displacement;
