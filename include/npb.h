@@ -152,7 +152,9 @@ NPB_API int npb_step(NpbHandle *h, const int32_t *action, const double *magnitud
 /* Which of the two step kernels npb_step launches (same device functions in the same per-plant order: identical int32
  * columns and flags, reals equal to the last bit or two; this is a measurement / A-B aid):
  * 0 = by batch size (default; also the environment variable NPB_STEP_KERNEL at handle creation), 1 = one wavefront per
- * 64 plants with an LDS-DMA staging pipeline, 2 = two wavefronts per 64 plants that own different subsystems. */
+ * 64 plants with an LDS-DMA staging pipeline, 2 = two wavefronts per 64 plants that own different subsystems (two builds of
+ * it: the whole register file up to 32 768 plants, where a SIMD holds one wave anyway, 256 registers above), 3 = the
+ * 256-register build at any size. */
 NPB_API int npb_set_step_kernel(NpbHandle *h, int variant);
 
 /* NuclearPlantSimulator.get_observation (sim.py:290-333) */

@@ -21,7 +21,7 @@ struct NpbHandle {
   void *f64;           /* the arena: [NPB_TOTAL_COL64][pitch] 8-byte columns, or [NPB_TOTAL_COL32][pitch] 4-byte ones */
   double *convert;     /* one staging column (pitch doubles) used by get/set_field with host buffers */
   unsigned *maint_flags; /* NPB_NUM_PUMPS words per wave of plants: the maintenance screen's verdict (behind the staging column) */
-  int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel (npb_set_step_kernel) */
+  int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel, 3 = its two-waves-per-SIMD build (npb_set_step_kernel) */
   npb_maint_table_t maint_table;   /* thresholds of the automatic maintenance (include/npb_maint.h) */
   int *plan_dev;       /* npb_gather_fields: {column, sub, kind} per requested field, and the request it was built for */
   std::vector<int> plan_key;
@@ -130,7 +130,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   NpbHandle *h = new NpbHandle();
   if (params) h->params = *params; else npb_params_default(&h->params);
   npb_maint_table_default(&h->maint_table);
-  { const char *e = getenv("NPB_STEP_KERNEL"); h->step_kernel = e ? atoi(e) : 0; if (h->step_kernel < 0 || h->step_kernel > 2) h->step_kernel = 0; }
+  { const char *e = getenv("NPB_STEP_KERNEL"); h->step_kernel = e ? atoi(e) : 0; if (h->step_kernel < 0 || h->step_kernel > 3) h->step_kernel = 0; }
   h->n_plants = n_plants; h->device = device;
   h->pitch = ((size_t)n_plants + 63) / 64 * 64;
   h->storage = storage; h->real_bytes = real_bytes;
@@ -174,7 +174,7 @@ int npb_set_params(NpbHandle *h, const npb_params_t *params) {
 }
 
 int npb_set_step_kernel(NpbHandle *h, int variant) {
-  if (!h || variant < 0 || variant > 2) return NPB_EINVAL;
+  if (!h || variant < 0 || variant > 3) return NPB_EINVAL;
   h->step_kernel = variant;
   return NPB_OK;
 }

@@ -288,8 +288,9 @@ __device__ __forceinline__ void npd2_stage_post(const npd_stage_t &st, const npd
   }
 }
 
-__global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(
-    npb_params_t P, int n_plants, size_t N, npd_real_t *__restrict__ f64,
+/* the body of both two-wave kernels (below): same code, compiled once per register budget */
+__device__ __forceinline__ void npd_step2_body(
+    const npb_params_t &P, int n_plants, size_t N, npd_real_t *__restrict__ f64,
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
     const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,
     double *__restrict__ reward_out, uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out,
@@ -839,5 +840,17 @@ __global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(
 #undef NPD_EXT_IDX
 #undef NPD_IS_EXT
 }
+
+#define NPD2_KERNEL_ARGS \
+    npb_params_t P, int n_plants, size_t N, npd_real_t *__restrict__ f64, const int32_t *__restrict__ action, \
+    const double *__restrict__ magnitude, const double *__restrict__ setpoint, const double *__restrict__ noise_z, \
+    const double *__restrict__ cw_temp, double *__restrict__ obs_out, double *__restrict__ reward_out, uint8_t *__restrict__ done_out, \
+    uint32_t *__restrict__ trip_out, double *__restrict__ info_out
+#define NPD2_KERNEL_PASS P, n_plants, N, f64, action, magnitude, setpoint, noise_z, cw_temp, obs_out, reward_out, done_out, trip_out, info_out
+/* two waves per SIMD (256 registers each, part of the state spilled): for batches between one and two waves per SIMD */
+__global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(NPD2_KERNEL_ARGS) { npd_step2_body(NPD2_KERNEL_PASS); }
+/* one wave per SIMD and the whole register file: up to 32 768 plants (1 024 waves) nothing is gained by leaving room for a
+ * second wave, and the spill code goes away */
+__global__ __launch_bounds__(NPD2_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void npb_step2_wide_kernel(NPD2_KERNEL_ARGS) { npd_step2_body(NPD2_KERNEL_PASS); }
 
 #endif

@@ -178,7 +178,8 @@ class BatchedPlantEnv:
 
     # ------------------------------------------------------------------ helpers
     def set_step_kernel(self, variant: int) -> None:
-        """0 = by batch size (default), 1 = one-wave kernel, 2 = two-wave kernel; same results to the last bit or two (include/npb.h)"""
+        """0 = by batch size (default), 1 = one-wave kernel, 2 = two-wave kernel, 3 = its 256-register build at any size; same
+        results to the last bit or two (include/npb.h)"""
         _lib.check(self.L.npb_set_step_kernel(self._h, int(variant)), self._h)
 
     def close(self):
