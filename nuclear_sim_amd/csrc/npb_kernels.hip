@@ -885,7 +885,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_screen_kernel(npd_maint_sc
   double values[NPB_MAINT_NPARAM], stamp[NPB_MAINT_NPARAM];
   npd_maint_values(&pm, values);
 #pragma unroll
-  for (int q = 0; q < NPB_MAINT_NPARAM; q++) stamp[q] = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q));
+  for (int q = 0; q < NPB_MAINT_NPARAM; q++)   /* read once per step by nobody else: non-temporal, so that they do not displace the step kernel's working set */
+    stamp[q] = (double)__builtin_nontemporal_load((const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q)));
   bool work = false;
   if (k == 0) {
     /* AutoMaintenanceSystem.update as far as it needs no order: a check that falls due with nothing open only moves

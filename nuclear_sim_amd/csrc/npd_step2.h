@@ -34,6 +34,7 @@
 #define NPD_STEP2_H
 
 #define NPD2_THREADS 128
+#define NPD2_SPLIT 11                         /* stage pass B: wave A evaluates stages 0 .. NPD2_SPLIT-1 (and the inlet), wave B the rest and the five extractions */
 #ifndef NPD2_OCCUPANCY
 #define NPD2_OCCUPANCY __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
@@ -496,7 +497,6 @@ __device__ __forceinline__ void npd_step2_body(
     }
     const double sg_avg_pressure = sg_ap / NPB_NUM_SG, sg_avg_temperature = sg_at / NPB_NUM_SG, sg_avg_quality = sg_aq / NPB_NUM_SG;
     const int sg_system_availability = sg_effective >= (NPB_NUM_SG - 1);
-    NPD2_SYNCJ(6);                                                                                     /* #4a: the SG 2 slots have been read */
     /* ---- turbine (dt in hours, load demand in PERCENT, secondary/__init__.py:564-569) */
     t.load_demand = load_demand;
     const double pressure_stability_factor = npd_pressure_stability_factor(sg_pressures);
@@ -513,12 +513,12 @@ __device__ __forceinline__ void npd_step2_body(
     npd2_chain_t ch;
     ch.T_in = sg_avg_temperature; ch.total_power = 0.0; ch.total_extraction = 0.0; ch.lp6_outlet_enthalpy = 0.0;
     if (!seq) {
-      /* pass B, stages 0..9 and the inlet (wave B does 10..13 and the five extraction pressures) */
-      double sat_a[10], hg_a[10], tr_a[10];
+      /* pass B, stages 0 .. NPD2_SPLIT-1 and the inlet (wave B does the rest and the five extraction pressures) */
+      double sat_a[NPD2_SPLIT], hg_a[NPD2_SPLIT], tr_a[NPD2_SPLIT];
       ch.sat_in = npd_tsat_antoine(sg_avg_pressure);
       ch.hg_in = npd_hg_from_tsat(ch.sat_in);
 #pragma unroll
-      for (int k = 0; k < 10; k++) {
+      for (int k = 0; k < NPD2_SPLIT; k++) {
         sat_a[k] = npd_tsat_antoine(p_self[k]);
         hg_a[k] = npd_hg_from_tsat(sat_a[k]);
         tr_a[k] = npd_sqrt(npd_sqrt(p_self[k] / ((k == 0) ? sg_avg_pressure : p_self[k > 0 ? k - 1 : 0])));
@@ -527,9 +527,9 @@ __device__ __forceinline__ void npd_step2_body(
 #pragma unroll
       for (int k = 0; k < 14; k++) {
         const double p_in = (k == 0) ? sg_avg_pressure : p_self[k > 0 ? k - 1 : 0];
-        const double sat_k = k < 10 ? sat_a[k < 10 ? k : 0] : XR(X_SAT + (k < 10 ? 0 : k - 10));
-        const double hg_k = k < 10 ? hg_a[k < 10 ? k : 0] : XR(X_HG + (k < 10 ? 0 : k - 10));
-        const double tr_k = k < 10 ? tr_a[k < 10 ? k : 0] : XR(X_TRATIO + (k < 10 ? 0 : k - 10));
+        const double sat_k = k < NPD2_SPLIT ? sat_a[k < NPD2_SPLIT ? k : 0] : XR(X_SAT + (k < NPD2_SPLIT ? 0 : k - NPD2_SPLIT));
+        const double hg_k = k < NPD2_SPLIT ? hg_a[k < NPD2_SPLIT ? k : 0] : XR(X_HG + (k < NPD2_SPLIT ? 0 : k - NPD2_SPLIT));
+        const double tr_k = k < NPD2_SPLIT ? tr_a[k < NPD2_SPLIT ? k : 0] : XR(X_TRATIO + (k < NPD2_SPLIT ? 0 : k - NPD2_SPLIT));
         const double ef = NPD_IS_EXT(k) ? ext_flow[NPD_EXT_IDX(k)] : 0.0;
         const double hgx = NPD_IS_EXT(k) ? XR(X_HGEXT + NPD_EXT_IDX(k)) : 0.0;
         double T_out, loading;
@@ -744,17 +744,16 @@ __device__ __forceinline__ void npd_step2_body(
     for (int k = 0; k < 8; k++) old.rotor_t[k] = (double)NPD2_TSTG(rotor_temperatures, k);
 #pragma unroll
     for (int k = 0; k < 6; k++) old.casing_t[k] = (double)NPD2_TSTG(casing_temperatures, k);
-    NPD2_SYNCJ(6);                                                                                     /* #4a */
     NPD2_SYNCJ(7);                                                                                     /* #5 */
     const double p_in0 = XR(X_PIN);
     const bool seq = __builtin_amdgcn_ballot_w64(isnan(p_in0)) != 0;
     if (!seq) {
-      /* pass B, stages 10..13 and the five extraction pressures */
+      /* pass B, stages NPD2_SPLIT .. 13 and the five extraction pressures */
 #pragma unroll
-      for (int k = 10; k < 14; k++) {
+      for (int k = NPD2_SPLIT; k < 14; k++) {
         const double pk = XR(X_PSELF + k), pkm = XR(X_PSELF + k - 1);
         const double sat = npd_tsat_antoine(pk);
-        XW(X_SAT + k - 10, sat); XW(X_HG + k - 10, npd_hg_from_tsat(sat)); XW(X_TRATIO + k - 10, npd_sqrt(npd_sqrt(pk / pkm)));
+        XW(X_SAT + k - NPD2_SPLIT, sat); XW(X_HG + k - NPD2_SPLIT, npd_hg_from_tsat(sat)); XW(X_TRATIO + k - NPD2_SPLIT, npd_sqrt(npd_sqrt(pk / pkm)));
       }
 #pragma unroll
       for (int e = 0; e < 5; e++) XW(X_HGEXT + e, npd_hg_from_tsat(npd_tsat_antoine(XR(X_PEXT + e))));

@@ -12,12 +12,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("NPB_LIB", os.path.join(ROOT, "nuclear_sim_amd", "ablate", "libnpb_stamps.so"))
 
-SEG = {1: ("A: primary, fw control", "B: turbine lube, chemistry sidecar"), 2: ("A: pumps 0,1", "B: pumps 2,3"),
-       3: ("A: pump tails, fw finish", "B: -"), 4: ("A: -", "B: -"), 5: ("A: SG 0,1", "B: SG 2"),
-       6: ("A: SG sums", "B: load condenser group"), 7: ("A: load turbine, stage pass A", "B: -"),
-       8: ("A: pass B (0..6)", "B: pass B (7..13, ext)"), 9: ("A: stage chain", "B: -"),
-       10: ("A: rotor", "B: stage post (tstg), max stress"), 11: ("A: protect, gates", "B: condenser"),
-       12: ("A: write-back, obs", "B: reward, info")}
+# segment j ends at barrier j of npd_step2.h (NPD2_SYNCJ); the work listed is what the wave does before that barrier
+SEG = {1: ("A: primary, feedwater control", "B: turbine lube, chemistry sidecar"),
+       2: ("A: pumps 0,1", "B: pumps 2,3"),
+       5: ("A: pump tails, fw finish, SG 0, load turbine", "B: SG 1,2 part 1; wait for fw flow; part 2"),
+       7: ("A: SG sums, stage pass A", "B: preload the stage arrays"),
+       8: ("A: pass B, stages 0..10", "B: pass B, stages 11..13 and extractions"),
+       9: ("A: stage chain, rotor", "B: stage post (behind the chain's flags), load condenser group"),
+       11: ("A: protection, turbine store, gates", "B: condenser"),
+       12: ("A: write-back, observations", "B: reward, secondary write-back, info")}
 
 
 def main():
@@ -51,18 +54,14 @@ def main():
     for w, role in ((0, "A"), (1, "B")):
         print("wave %s: start %.0f end %.0f" % (role, s[:, w, 0].mean(), s[:, w, 31].mean()))
         prev = 0
-        for j in (1, 2, 5, 6, 7, 8, 9, 11):
+        for j in (1, 2, 5, 7, 8, 9, 11):
             work = (s[:, w, 2 * j - 1] - s[:, w, prev]).mean(); wait = (s[:, w, 2 * j] - s[:, w, 2 * j - 1]).mean()
             print("  seg %2d %-36s work %8.0f (%4.1f %%)  wait at barrier %8.0f (%4.1f %%)" %
                   (j, SEG[j][w], work, 100 * work / total, wait, 100 * wait / total))
             prev = 2 * j
         work = (s[:, w, 31] - s[:, w, prev]).mean()
         print("  seg 12 %-36s work %8.0f (%4.1f %%)" % (SEG[12][w], work, 100 * work / total))
-    t0 = raw[:, 0, 0].min()
-    starts = np.sort(raw[:, 0, 0] - t0); ends = np.sort(raw[:, :, 31].max(axis=1) - t0)
-    q = lambda a: " ".join("%.0f" % a[int(f * (len(a) - 1))] for f in (0, .1, .25, .5, .75, .9, 1.0))
-    print("group lifetime %.0f ticks; last step, ticks since the first group's start: group starts (min 10%% 25%% 50%% 75%% 90%% max) %s; group ends %s"
-          % (total, q(starts), q(ends)))
+    print("group lifetime %.0f ticks" % total)
 
 
 if __name__ == "__main__":
