@@ -35,7 +35,8 @@ NPD_FN double npd_rcp(double y) { /* 1 / y to working precision: hardware seed +
   r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
   return r;
 }
-NPD_FN double npd_log(double x) {
+/* the logarithm of a positive finite number (a NaN comes out as NaN by itself; anything else is the caller's to exclude) */
+NPD_FN double npd_log_pos(double x) {
   double m = __builtin_amdgcn_frexp_mant(x); /* [0.5, 1) */
   int e = __builtin_amdgcn_frexp_exp(x);
   /* into [sqrt(1/2), sqrt(2)) by integer arithmetic on the high word: no compare, no select (each costs a lone wave ~20 cycles) */
@@ -54,11 +55,26 @@ NPD_FN double npd_log(double x) {
   p = __builtin_fma(p, z, 0.28571428626063380364); p = __builtin_fma(p, z, 0.39999999999899310681); p = __builtin_fma(p, z, 0.66666666666666696929);
   const double lm = __builtin_fma(s * z, p, 2.0 * s);
   const double de = (double)e;
-  const double res = __builtin_fma(de, 6.93147180369123816490e-01, __builtin_fma(de, 1.90821492927058770002e-10, lm));
+  return __builtin_fma(de, 6.93147180369123816490e-01, __builtin_fma(de, 1.90821492927058770002e-10, lm));
+}
+NPD_FN double npd_log(double x) {
+  const double res = npd_log_pos(x);
   /* everything but a positive finite number (zero, negative, +inf, NaN): one class test, and the value the float unit's own
    * logarithm gives for it: log(+-0) = -inf, log(x < 0) = NaN, log(inf) = inf, NaN -> NaN */
   const double special = (double)__builtin_amdgcn_logf((float)x);
   return __builtin_amdgcn_class(x, 0x27f) ? special : res;
+}
+/* exp of an argument the caller knows to be of moderate size (|x| < 700) or NaN: no clamp, and a NaN propagates by itself */
+NPD_FN double npd_exp_bounded(double x) {
+  const double n = __builtin_rint(x * 1.44269504088896338700e+00);
+  double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);
+  r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+  double q = 2.5100385495510319077e-8;   /* near-minimax for (exp(r) - 1 - r) / r^2, |r| <= ln2 / 2 (mpmath chebyfit, 1e-16) */
+  q = __builtin_fma(q, r, 2.762008844540974816e-7); q = __builtin_fma(q, r, 2.7557268459997064772e-6); q = __builtin_fma(q, r, 0.000024801521295954375131);
+  q = __builtin_fma(q, r, 0.00019841269863053616878); q = __builtin_fma(q, r, 0.0013888888917213716901); q = __builtin_fma(q, r, 0.0083333333333300618325);
+  q = __builtin_fma(q, r, 0.041666666666624127873); q = __builtin_fma(q, r, 0.16666666666666667453); q = __builtin_fma(q, r, 0.50000000000000010221);
+  const double p = __builtin_fma(__builtin_fma(q, r, 1.0), r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)n);
 }
 NPD_FN double npd_exp(double x) {
   const double xc = __builtin_fmin(__builtin_fmax(x, -800.0), 800.0);   /* v_max / v_min: a NaN is put back at the end */
@@ -89,6 +105,8 @@ NPD_FN double npd_log10(double x) { return npd_log(x) * 4.34294481903251827651e-
 
 /* x^c for x >= 0: exp(c * log(x)); npd_powc(0, c) = 0 for c > 0 is preserved (log(0) = -inf, exp(-inf) = 0) */
 NPD_FN double npd_powc(double x, double c) { return npd_exp(c * npd_log(x)); }
+/* the same for a base that is positive, finite and within a few orders of magnitude of 1 (or NaN) */
+NPD_FN double npd_powc_pos(double x, double c) { return npd_exp_bounded(c * npd_log_pos(x)); }
 
 /* a^p * b^q as ONE exponential of p*log(a) + q*log(b), with the logarithms supplied by the caller: the wear-rate
  * formulas raise the same few factors to several exponents, and a product of powers needs one exp, not one per

@@ -16,7 +16,7 @@ NPD_FN double npd_cond_tsat(double pressure_mpa) {
   if (pressure_mpa <= 0.001) return 10.0;
   const double A = 8.07131, B = 1730.63, C = 233.426;
   double pressure_bar = npd_clip(pressure_mpa * 10.0, 0.01, 100.0);
-  double temp_c = B / (A - npd_log10(pressure_bar)) - C;
+  double temp_c = B / (A - npd_log_pos(pressure_bar) * 4.34294481903251827651e-01) - C;   /* pressure_bar in [0.01, 100] (or NaN) */
   if (pressure_mpa >= 0.005 && pressure_mpa <= 0.01) temp_c = npd_clip(temp_c, 35.0, 45.0);
   return npd_clip(temp_c, 10.0, 374.0);
 }
@@ -24,7 +24,7 @@ NPD_FN double npd_cond_hf(double p) { return 4.18 * npd_cond_tsat(p); }      /* 
 NPD_FN double npd_cond_hg(double p) {                                         /* :1845-1850 */
   double temp = npd_cond_tsat(p);
   double h_f = npd_cond_hf(p);
-  double h_fg = 2257.0 * npd_powc(1.0 - temp / 374.0, 0.38);
+  double h_fg = 2257.0 * npd_powc_pos(1.0 - temp / 374.0, 0.38);   /* temp in [10, 51.6] */
   return h_f + h_fg;
 }
 

@@ -12,7 +12,7 @@
 NPD_FN double npd_sg_tsat(double pressure_mpa) {
   if (pressure_mpa <= 0.001) return 10.0;
   double pressure_bar = pressure_mpa * 10.0;
-  double ln_p = npd_log(pressure_bar);
+  double ln_p = npd_log_pos(pressure_bar);   /* > 0.01 bar here (or NaN); the lanes the early return covers discard it */
   double temp_c = 42.6776 + 34.5194 * ln_p + 2.8896 * npd_sq(ln_p) + 0.1153 * (ln_p * ln_p * ln_p);
   return npd_clip(temp_c, 10.0, 374.0);
 }

@@ -17,20 +17,20 @@ NPD_FN double npd_tsat_antoine(double pressure_mpa) {
   if (pressure_mpa <= 0.001) return 10.0;
   const double A = 8.07131, B = 1730.63, C = 233.426;
   double pressure_bar = npd_clip(pressure_mpa * 10.0, 0.01, 100.0);
-  double temp_c = B / (A - npd_log10(pressure_bar)) - C;
+  double temp_c = B / (A - npd_log_pos(pressure_bar) * 4.34294481903251827651e-01) - C;   /* pressure_bar in [0.01, 100] (or NaN) */
   return npd_clip(temp_c, 10.0, 374.0);
 }
 /* _saturation_enthalpy_vapor  stage_system.py:468-473 */
 NPD_FN double npd_hg_antoine(double pressure_mpa) {
   double temp = npd_tsat_antoine(pressure_mpa);
   double h_f = 4.18 * temp;
-  double h_fg = 2257.0 * npd_powc(1.0 - temp / 374.0, 0.38);
+  double h_fg = 2257.0 * npd_powc_pos(1.0 - temp / 374.0, 0.38);   /* temp in [10, 51.6]: the Antoine form over [0.01, 100] bar */
   return h_f + h_fg;
 }
 /* same, from an already known saturation temperature */
 NPD_FN double npd_hg_from_tsat(double temp) {
   double h_f = 4.18 * temp;
-  double h_fg = 2257.0 * npd_powc(1.0 - temp / 374.0, 0.38);
+  double h_fg = 2257.0 * npd_powc_pos(1.0 - temp / 374.0, 0.38);
   return h_f + h_fg;
 }
 /* TurbineStage._steam_enthalpy  stage_system.py:418-443 */
