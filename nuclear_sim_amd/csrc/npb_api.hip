@@ -78,6 +78,49 @@ static bool locate(int storage, int kind, int slot, int *col, int *sub, int *aki
 }
 static size_t arena_columns(int storage) { return storage == NPB_STORAGE_F32 ? (size_t)NPB_TOTAL_COL32 : (size_t)NPB_TOTAL_COL64; }
 
+/* Where an arena lands in physical memory changes the step kernel's time when the bytes a step touches are about the
+ * size of the 256 MB Infinity Cache (65 536 fp64 plants: 276 MB): handles created one after another in one process run
+ * at 0.097 ms or at 0.110 ms per step, reproducibly per handle for its whole life, and nothing cheaper than the step
+ * kernel itself predicts which (tools/launch_series.py).  So in that zone npb_create allocates up to
+ * four candidate arenas, times a dozen launches of the step kernel on each (construction state, no inputs, no
+ * outputs), keeps the fastest and frees the rest; the kept arena is initialised again by the caller below.  About 15 ms,
+ * once per handle.  NPB_PLACEMENT_PROBE=0 turns it off. */
+static void probe_placement(NpbHandle *h, size_t step_columns) {
+  const char *env = getenv("NPB_PLACEMENT_PROBE");
+  if (env && atoi(env) == 0) return;
+  const double touched_mb = (double)step_columns * h->real_bytes * h->pitch / 1.0e6;
+  if (touched_mb < 200.0 || touched_mb > 340.0 || h->params.mode == NPB_MODE_PRIMARY) return;
+  const bool narrow = h->storage == NPB_STORAGE_F32;
+  const size_t bytes = arena_columns(h->storage) * h->pitch * h->real_bytes;
+  const int max_candidates = 4, launches = 12;
+  void *cand[max_candidates] = {h->f64, nullptr, nullptr, nullptr};
+  float ms[max_candidates] = {0, 0, 0, 0};
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess) return;
+  if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+  int n = 0;
+  for (; n < max_candidates; n++) {
+    if (n > 0 && hipMalloc(&cand[n], bytes) != hipSuccess) { cand[n] = nullptr; (void)hipGetLastError(); break; }
+    (narrow ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, h->pitch, cand[n], nullptr, nullptr);
+    float best = 1e30f;
+    for (int k = 0; k < launches; k++) {
+      (void)hipEventRecord(a, nullptr);
+      (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, cand[n], nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                     nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr);
+      (void)hipEventRecord(b, nullptr);
+      if (hipEventSynchronize(b) != hipSuccess) { best = 1e30f; break; }
+      float t = 0; (void)hipEventElapsedTime(&t, a, b);
+      if (k >= 4 && t < best) best = t;     /* the first launches warm the caches */
+    }
+    ms[n] = best;
+  }
+  int keep = 0;
+  for (int i = 1; i < n; i++) if (ms[i] < ms[keep]) keep = i;
+  for (int i = 0; i < n; i++) if (i != keep && cand[i]) (void)hipFree(cand[i]);
+  h->f64 = cand[keep];
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+}
+
 extern "C" {
 
 int npb_version(void) { return NPB_VERSION; }
@@ -136,6 +179,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   h->storage = storage; h->real_bytes = real_bytes;
   h->f64 = nullptr; h->convert = nullptr; h->plan_dev = nullptr;
   e = hipMalloc(&h->f64, arena_columns(storage) * h->pitch * real_bytes);
+  if (e == hipSuccess) probe_placement(h, step_columns);
   if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double) + h->pitch / 64 * NPB_NUM_PUMPS * sizeof(unsigned));
   if (e != hipSuccess) {
     if (h->f64) (void)hipFree(h->f64);

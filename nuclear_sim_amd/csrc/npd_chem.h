@@ -50,7 +50,7 @@ NPD_FN void npd_chem_update(npb_chem_t *c, double dt) {
   c->antiscalant_concentration += (5.0 - c->antiscalant_concentration) * dose_rate;
   c->corrosion_inhibitor_level += (10.0 - c->corrosion_inhibitor_level) * dose_rate;
   double chlorine_decay = 0.1 * dt_hours;
-  c->chlorine_residual *= npd_exp(-chlorine_decay);
+  c->chlorine_residual *= npd_exp_bounded(-chlorine_decay);
   c->chlorine_residual += (1.0 - c->chlorine_residual) * dose_rate;
   double chlorine_effectiveness = (c->chlorine_residual > 0.2) ? 1.0 : 0.5;
   double antiscalant_effectiveness = (c->antiscalant_concentration > 2.0) ? 1.0 : 0.7;

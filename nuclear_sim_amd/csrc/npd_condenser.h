@@ -73,20 +73,20 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
   /* ---- AdvancedFoulingModel.update_fouling :324-384 */
   double water_temp = (cooling_water_temp_in + cd->cooling_water_outlet_temp) / 2.0;
   {
-    double temp_factor = npd_exp(0.1 * (water_temp - 25.0));
+    double temp_factor = npd_exp_bounded(0.1 * (water_temp - 25.0));
     double chlorine_factor = 1.0 / (1.0 + chem->chlorine_residual * 2.0);
     double nutrient_factor = nutrient_level * 1.0;
     double growth_rate = (0.001 * temp_factor * chlorine_factor * nutrient_factor);
     double thickness_factor = 1.0 / (1.0 + cd->biofouling_thickness / 2.0);
     double bio_increase = npd_pymax(0.0, growth_rate * thickness_factor * (dt / 1000.0));
-    double s_temp_factor = npd_exp(0.15 * (water_temp - 25.0) / 10.0);
+    double s_temp_factor = npd_exp_bounded(0.15 * (water_temp - 25.0) / 10.0);
     double hardness_factor = (chem->hardness / 150.0) * 0.002;
     double ph_factor = npd_pymax(0.1, (chem->ph - 6.0) / 2.0);
     double antiscalant_factor = 1.0 / (1.0 + chem->antiscalant_concentration / 5.0);
     double formation_rate = (0.0005 * s_temp_factor * hardness_factor * ph_factor * antiscalant_factor);
     double s_thickness_factor = 1.0 / (1.0 + cd->scale_thickness / 1.0);
     double scale_increase = npd_pymax(0.0, formation_rate * s_thickness_factor * (dt / 1000.0));
-    double c_temp_factor = npd_exp((water_temp - 25.0) / 20.0);
+    double c_temp_factor = npd_exp_bounded((water_temp - 25.0) / 20.0);
     double oxygen_factor = 8.0 * 0.01; /* 'dissolved_oxygen': 8.0 is hard-coded at :791 */
     double c_ph_factor = 1.0 + fabs(chem->ph - 7.5) / 2.0;
     double inhibitor_factor = 1.0 / (1.0 + chem->corrosion_inhibitor_level / 10.0);

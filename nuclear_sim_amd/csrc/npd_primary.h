@@ -62,7 +62,7 @@ NPD_FN double npd_total_reactivity_pcm(const npb_prim_t *s, double *components) 
   double xenon = (s->xenon_concentration / 1.0e15) * -1800.0;
   double samarium = (s->samarium_concentration / 5.0e14) * -600.0;
   double depletion = 3340.0 + -0.15 * s->fuel_burnup;
-  double bp = s->burnable_poison_worth * npd_exp(-0.0002 * s->fuel_burnup);
+  double bp = s->burnable_poison_worth * npd_exp_bounded(-0.0002 * s->fuel_burnup);
   double total = 0.0;
   total += rods; total += boron; total += doppler; total += mod_temp; total += mod_void;
   total += pressure; total += xenon; total += samarium; total += depletion; total += bp;
@@ -148,7 +148,7 @@ NPD_FN double npd_core_ua(double coolant_flow_rate) {
   reynolds = npd_pymax(reynolds, 1000.0);
   double prandtl = viscosity * specific_heat / thermal_conductivity;
   (void)prandtl; /* = 0.8509090909090908, a constant: prandtl ** 0.4 = 0.937461121006843 */
-  double nusselt = 0.023 * npd_powc(reynolds, 0.8) * 0.937461121006843;
+  double nusselt = 0.023 * npd_powc_pos(reynolds, 0.8) * 0.937461121006843;   /* reynolds >= 1000 */
   double h = nusselt * thermal_conductivity / fuel_rod_diameter;
   double overall_ua = h * heat_transfer_area;
   overall_ua = overall_ua * 0.1;

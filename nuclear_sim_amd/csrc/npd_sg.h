@@ -84,7 +84,7 @@ NPD_FN void npd_tsp_update(npb_sg_t *g, const npb_params_t *P, double temperatur
   double dt_years = dt_hours / (365.25 * 24.0);
 
   double temp_kelvin = temperature + 273.15;
-  double temp_factor = npd_exp(-45000.0 / (8.314 * temp_kelvin));
+  double temp_factor = npd_exp_bounded(-45000.0 / (8.314 * temp_kelvin));   /* a saturation temperature: 283 .. 647 K */
   temp_factor = temp_factor / npd_exp(-45000.0 / (8.314 * 573.15));
   double ph_factor = 1.0 + 0.5 * fabs(P->sgchem_ph - 9.2);
   double velocity_factor = npd_sqrt(flow_velocity / 3.0);
@@ -92,7 +92,7 @@ NPD_FN void npd_tsp_update(npb_sg_t *g, const npb_params_t *P, double temperatur
   double magnetite_rate = 2.5 * (1.0 + P->sgchem_iron * 1.5) * temp_factor * ph_factor * velocity_factor;
   double copper_rate = 0.8 * (1.0 + P->sgchem_copper * 2.0) * temp_factor * velocity_factor;
   double silica_rate = 1.2 * (1.0 + P->sgchem_silica / 100.0 * 1.8) * temp_factor * ph_factor;
-  double bio_temp_factor = (temperature < 60) ? 1.0 : npd_exp(-(temperature - 60) / 20);
+  double bio_temp_factor = (temperature < 60) ? 1.0 : npd_exp_bounded(-(temperature - 60) / 20);
   double biological_rate = 0.5 * (1.0 + P->sgchem_dissolved_oxygen * 10.0) * bio_temp_factor * velocity_factor;
 
   const double max_thickness = 0.023 / 2.0 * 1000.0 * 0.9;
@@ -154,13 +154,13 @@ NPD_FN void npd_scale_update(npb_sg_t *g, double temperature, double flow_veloci
   g->scale_operating_years += dt_seconds / (365.25 * 24.0 * 3600.0);
   const double boric_acid = 1000.0, lithium = 2.0, ph = 7.2, dissolved_oxygen = 0.005;
   double temp_kelvin = temperature + 273.15, ref_kelvin = 320.0 + 273.15;
-  double temp_factor = npd_exp(-65000.0 / (8.314 * temp_kelvin)) / npd_exp(-65000.0 / (8.314 * ref_kelvin));
+  double temp_factor = npd_exp_bounded(-65000.0 / (8.314 * temp_kelvin)) / npd_exp(-65000.0 / (8.314 * ref_kelvin));
   double boric_acid_factor = 1.0 / (1.0 + boric_acid / 1000.0 * 0.5);
   double lithium_factor = npd_pymax(0.5, 1.0 + (lithium - 2.0) * 0.1);
   double ph_factor = 1.0 + 0.5 * fabs(ph - 7.2);
   double velocity_factor = npd_clip(npd_powc(flow_velocity / 5.0, -0.6), 0.5, 2.0);
   double oxygen_factor = 1.0 + dissolved_oxygen * 10.0;
-  double saturation_factor = npd_exp(-g->scale_thickness / 2.0);
+  double saturation_factor = npd_exp_bounded(-g->scale_thickness / 2.0);
   double formation_rate = 0.001 * temp_factor * boric_acid_factor * lithium_factor * ph_factor *
                           velocity_factor * oxygen_factor * saturation_factor;
   formation_rate = npd_clip(formation_rate, 0.0, 0.1);
@@ -261,7 +261,7 @@ NPD_FN void npd_sg_part2(npb_sg_t *g, const npb_params_t *P, double heat_transfe
   double steam_demand_factor = (P->sg_secondary_design_flow > 0) ? actual_steam_flow / P->sg_secondary_design_flow : 0.0;
   equilibrium_pressure += -steam_demand_factor * 0.5;
   equilibrium_pressure = npd_clip(equilibrium_pressure, 3.0, 8.5);
-  double decay_factor = npd_exp(-dt / 60.0);
+  double decay_factor = npd_exp_bounded(-dt / 60.0);
   double base_new_pressure = equilibrium_pressure + (p - equilibrium_pressure) * decay_factor;
   double pressure_corrections = 0.0;
   if (actual_feedwater_flow < 0.1 && actual_steam_flow > 100.0) {

@@ -27,4 +27,11 @@ for rnd in range(2):
         real = ctypes.c_void_p(); pitch = ctypes.c_size_t(); stor = ctypes.c_int()
         env.L.npb_state_arena(env._h, ctypes.byref(real), ctypes.byref(pitch), ctypes.byref(stor))
         mn, md = burst(env)
-        print("round %d handle %d arena at 0x%012x: min %.5f median %.5f ms" % (rnd, i, real.value, mn, md), flush=True)
+        # the calibration kernel (reads and rewrites every column in the step's access shape) on the same arena
+        from nuclear_sim_amd import _lib
+        tev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        for a, b in tev:
+            a.record(); _lib.check(env.L.npb_debug_touch(env._h, env._stream()), env._h); b.record()
+        torch.cuda.synchronize()
+        tt = sorted(a.elapsed_time(b) for a, b in tev)
+        print("round %d handle %d arena at 0x%012x: step min %.5f median %.5f ms; touch min %.5f median %.5f ms" % (rnd, i, real.value, mn, md, tt[0], tt[10]), flush=True)
