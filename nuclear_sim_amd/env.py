@@ -158,6 +158,7 @@ class BatchedPlantEnv:
             self._info = self._info_buf[: self.n * len(INFO_COLUMNS)].view(self.n, len(INFO_COLUMNS))
             self._rho = self._info_buf[self.n * len(INFO_COLUMNS):].view(self.n, -1) if self._with_rho else None
         self._noise = None
+        self._noise_seeds = None if noise_seeds is None else np.asarray(noise_seeds, dtype=np.int64).copy()
         if noise_enabled and noise_seeds is not None:
             self._noise = HeatSourceNoise(noise_seeds, device=self.device)
         self._keep = []
@@ -284,6 +285,11 @@ class BatchedPlantEnv:
             _lib.check(self.L.npb_reset_reference(self._h, self._p(m), int(bool(start_at_steady_state)), self._stream()), self._h)
         else:
             _lib.check(self.L.npb_reset(self._h, self._p(m), self._stream()), self._h)
+            # a freshly constructed simulator has a freshly seeded heat-source generator (the reference's own reset() keeps
+            # drawing from the old one: constant_heat_source.py:185-194 does not touch the RNG).  Plants that share a seed
+            # share one pre-drawn stream here, so only a reset of the whole batch can restart it.
+            if mask is None and self._noise is not None and self._noise_seeds is not None:
+                self._noise = HeatSourceNoise(self._noise_seeds, device=self.device)
         return self.get_observation()
 
     def get_observation(self) -> torch.Tensor:
@@ -393,6 +399,10 @@ def secondary_result(info: Dict[str, torch.Tensor], members: Dict[str, torch.Ten
     f["ph_control_error"] = members["ph.previous_error"]
     f["load_demand"] = members["sec.load_demand"]; f["feedwater_temperature"] = one * 227.0
     f["cooling_water_inlet_temp"] = members["sec.cooling_water_temperature"]; f["cooling_water_outlet_temp"] = members["cond.cooling_water_outlet_temp"]
+    # condenser/physics.py:692-693: outlet = inlet + rise, so the rise is their difference (to 1e-15 of the temperatures)
+    f["condenser_cooling_water_temp_rise"] = members["cond.cooling_water_outlet_temp"] - members["sec.cooling_water_temperature"]
+    # feedwater/physics.py:834: the configuration's auto_level_control, True unless a control command the step never issues clears it
+    f["feedwater_auto_control"] = torch.ones_like(members["sec.cooling_water_temperature"])
     return f
 
 
@@ -629,8 +639,8 @@ class NuclearPlantSimulator:
 
     def _secondary_result(self) -> Dict[str, float]:
         """info["secondary_system"]: every scalar key of the reference's result dict (secondary/__init__.py:922-1010) that is a
-        function of what the step produces -- 50 of its 56 scalars; turbine_efficiency, turbine_hp_power, turbine_lp_power,
-        condenser_cooling_water_temp_rise, condenser_thermal_performance and feedwater_auto_control are not carried."""
+        function of what the step produces -- 52 of its 56 scalars; turbine_efficiency, turbine_hp_power, turbine_lp_power and
+        condenser_thermal_performance are step-internal values the kernel does not keep."""
         return {k: float(v[0].item()) for k, v in self._env.secondary_result().items()}
 
     def reset(self, start_at_steady_state: bool = True):
