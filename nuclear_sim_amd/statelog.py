@@ -6,9 +6,13 @@ provider's `get_state_dict()` and `pd.concat`s the row (simulator/state/state_ma
 Here a sample is one gather kernel (`npb_gather_fields`): the chosen members of every plant, widened to double, land
 in a device buffer `[sample, field, plant]`; nothing touches the host until `table()` / `write_parquet()`.
 
-Columns carry the reference's own log names where the member is one of its log columns -- the mapping
-(`state_names.json`) is made by running the reference and matching whole series value-for-value
-(the harness script named in DESIGN.md section 6) -- and `npb.<section>.<member>` otherwise.
+Columns carry the reference's own log names: `state_names.json` (made by running the reference through three eventful
+runs and matching whole series value for value, oracle/ref_harness/make_state_names.py) maps 265 of the reference's 784
+numeric log columns onto 193 state members -- several log columns can show one member (the reference logs the total
+feedwater flow three times), a few through a unit factor.  `StateLog(env)` without a field list records exactly those
+members and `table()` emits every one of the 265 columns; members selected by name that the reference does not log come
+out as `npb.<section>.<member>`.  Not reproduced: the reference's derived diagnostics (per-stage turbine conditions, SG
+capacities and heat fluxes, system averages ...: 251 columns) and the 268 columns that never vary in any of the runs.
 
     log = StateLog(env, fields=["pump.oil_level", "sec.electrical_power_output"], every=12, capacity=64)
     for t in range(steps):
@@ -33,9 +37,15 @@ _NAMES_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "state_na
 
 
 def reference_names() -> Dict[str, str]:
-    """schema label -> the reference's state-log column name, for the members that are logged there."""
+    """schema label -> ONE of the reference's state-log column names, for the members that are logged there."""
     with open(_NAMES_PATH) as fh:
         return json.load(fh)["names"]
+
+
+def reference_log_columns() -> Dict[str, tuple]:
+    """the reference's log column -> (schema label, factor): every column of its log that is a state member (times a unit factor)"""
+    with open(_NAMES_PATH) as fh:
+        return {k: (v[0], float(v[1])) for k, v in json.load(fh)["log_columns"].items()}
 
 
 def log_columns(fields: Optional[Sequence[str]] = None) -> List[tuple]:
@@ -46,9 +56,10 @@ def log_columns(fields: Optional[Sequence[str]] = None) -> List[tuple]:
     cols = SCHEMA.columns()
     out = []
     if fields is None:
+        wanted = {label for label, _f in reference_log_columns().values()}
         for kind, slot, label, _path in cols:
-            if label in names:
-                out.append((kind, slot, label, names[label]))
+            if label in wanted:
+                out.append((kind, slot, label, names.get(label, "npb." + label)))
         return out
     for want in fields:
         hit = False
@@ -67,6 +78,8 @@ class StateLog:
     def __init__(self, env, fields: Optional[Sequence[str]] = None, every: int = 1, capacity: int = 256):
         self.env = env
         self.columns = log_columns(fields)
+        # with no field list the table carries the reference's log columns (several per member, unit factors applied)
+        self._reference_layout = fields is None
         if not self.columns:
             raise ValueError("no columns to log")
         self.every = max(1, int(every))
@@ -114,6 +127,12 @@ class StateLog:
         cols = {"step": np.repeat(np.asarray(self._steps, dtype=np.int64), npl),
                 "time": np.repeat(np.asarray(self._times, dtype=np.float64), npl),
                 "plant": np.tile(idx.astype(np.int64), ns)}
+        if self._reference_layout:
+            index = {c[2]: f for f, c in enumerate(self.columns)}
+            for name, (label, factor) in sorted(reference_log_columns().items()):
+                v = data[:, index[label], :].reshape(-1)
+                cols[name] = v * factor if factor != 1.0 else v
+            return pa.table(cols)
         for f, (kind, _slot, _label, name) in enumerate(self.columns):
             v = data[:, f, :].reshape(-1)
             cols[name] = v.astype(np.int32) if kind == "i32" else v

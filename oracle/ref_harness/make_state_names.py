@@ -1,15 +1,26 @@
-"""Map schema columns onto the column names of the reference's state log (StateManager DataFrame).
+"""Map the column names of the reference's state log (StateManager DataFrame) onto schema members.
 
 Harness-only (imports the reference from /root/reference).  Runs the data-gen runner's simulator (state management
-on, as MaintenanceScenarioRunner builds it) for a few dozen steps with a varying load, reads the reference's own
-log (`sim.state_manager.data`, one row per step, names `category.variable` built by state_manager.py:169-182 from
-the auto-registered providers, auto_register.py:83-165) and, beside it, every schema column's reference attribute
-(the quoted path of include/npb_fields.h).  A schema column is mapped to the log column whose whole series equals
-its own; ambiguous or missing matches are left out.  Output: nuclear_sim_amd/state_names.json
-(python -m oracle.ref_harness.make_state_names).
+on, as MaintenanceScenarioRunner builds it) through three eventful runs -- a moving load; the same with a pump trip,
+a cooling-water swing and a second pump's NPSH collapse; a degraded plant (seal_replacement scenario, seed 3) -- and
+reads the reference's own log (`sim.state_manager.data`, one row per step, names `category.variable` built by
+state_manager.py:169-182 from the auto-registered providers, auto_register.py:83-165) and, beside it, every schema
+member's reference attribute (the quoted path of include/npb_fields.h).
+
+A LOG COLUMN is mapped to a member when the member's whole series over the three runs equals the column's
+(bit for bit), or equals it after one of a few unit factors; a column that never varies proves nothing and is left
+out.  Several log columns may map to one member (the reference logs `total_feedwater_flow` three times), and when
+several members carry the same series (the stored previous-step copies, the chemistry twins) the one whose label is
+closest to the column's name is taken.  Output: nuclear_sim_amd/state_names.json
+  names        member label -> ONE log column (the 1:1 map of round 1, kept for callers that select by member)
+  log_columns  log column -> [member label, factor]   (everything the state log can reproduce)
+and tests/golden/log_m1_oil_top_off_staggered.npz: the reference's log of the m1 fixture's run, the ground truth of the GPU test.
+(python -m oracle.ref_harness.make_state_names)
 """
+import difflib
 import json
 import os
+import re
 import sys
 
 import numpy as np
@@ -20,20 +31,24 @@ from nuclear_sim_amd.schema import SCHEMA  # noqa: E402
 from oracle.ref_harness import refsim  # noqa: E402
 from oracle.ref_harness.trace import _val  # noqa: E402
 
+FACTORS = (1.0, 100.0, 0.01, 1000.0, 0.001, 10.0, 0.1, 60.0, 1.0 / 60.0, 3600.0, 1.0 / 3600.0, 1e6, 1e-6)
+P1 = "secondary_physics.feedwater_system.pump_system.pumps['FWP-%d']"
 
-def main(steps=60):
-    refsim.setup()
+
+def _run(action, seed, steps, events):
     cols = SCHEMA.columns()
     with refsim.quiet():
-        runner, sim = refsim.make_runner_sim(action="oil_top_off", duration_hours=steps * 5.0 / 60.0)
+        runner, sim = refsim.make_runner_sim(action=action, duration_hours=steps * 5.0 / 60.0, randomization_seed=seed)
         profile = runner._generate_power_profile(steps)
         mine = np.full((steps, len(cols)), np.nan)
-        results = []
         for t in range(steps):
+            for path, v in events.get(t, []):
+                exec("sim.%s = v" % path, {"sim": sim, "v": v})
             runner._set_target_power(float(np.clip(profile[t] - 8.0 + 8.0 * np.sin(t / 3.0), 50.0, 100.0)))   # a load that moves
-            results.append(sim.step()["info"]["secondary_system"])
+            kw = {"cooling_water_temp": 25.0 + 6.0 * np.sin(t / 5.0)} if events else {}
+            sim.step(**kw)
             for j, (_kind, _slot, _label, path) in enumerate(cols):
-                mine[t, j] = _val(sim, path) if path and not path.startswith("=") else np.nan
+                mine[t, j] = _val(sim, path) if path else np.nan
     df = sim.state_manager.data
     assert len(df) == steps, (len(df), steps)
     log = {}
@@ -44,65 +59,99 @@ def main(steps=60):
             log[name] = df[name].astype(float).to_numpy()
         except (TypeError, ValueError):
             continue
-    out, ambiguous = {}, 0
-    for j, (kind, slot, label, path) in enumerate(cols):
-        series = mine[:, j]
+    return mine, log
+
+
+def _instance_token(label):
+    m = re.match(r"^(\w+)\[(\d+)\]\.", label)
+    if not m:
+        return None
+    sec, inst = m.group(1), int(m.group(2))
+    return {"pump": "FWP-%d" % (inst + 1), "mpump": "FWP-%d" % (inst + 1), "sg": "SG-%d" % inst}.get(sec)
+
+
+def _closeness(label, name):
+    base = label.split(".")[-1]
+    tail = name.split(".")[-1]
+    score = difflib.SequenceMatcher(None, re.sub(r"\[\d+\]", "", base), tail).ratio()
+    tok = _instance_token(label)
+    if tok is not None:
+        score += 1.0 if tok in name else -1.0
+    elif re.search(r"(FWP|SG)-\d", name):
+        score -= 0.5
+    k = re.search(r"\[(\d+)\]$", base)          # array element: the element number usually shows in the column name
+    if k and re.search(r"(^|[^0-9])0*%d([^0-9]|$)" % (int(k.group(1)) + 1), tail):
+        score += 0.3
+    return score
+
+
+def main():
+    refsim.setup()
+    cols = SCHEMA.columns()
+    runs = [_run("oil_top_off", None, 60, {}),
+            _run("oil_top_off", None, 70, {20: [((P1 % 1) + ".lubrication_system.oil_level", 9.0)],
+                                            40: [((P1 % 2) + ".state.npsh_available", 11.0)]}),
+            _run("seal_replacement", 3, 40, {})]
+    mine = np.concatenate([r[0] for r in runs], axis=0)
+    names_all = [n for n in runs[0][1] if all(n in r[1] for r in runs)]
+    log = {n: np.concatenate([r[1][n] for r in runs]) for n in names_all}
+    usable = [j for j in range(len(cols)) if not np.isnan(mine[:, j]).any()]
+    log_columns, constant, unmatched = {}, 0, []
+    for name, series in log.items():
         if np.isnan(series).any():
-            continue
-        hits = [n for n, v in log.items() if np.array_equal(v, series)]
-        if len(hits) > 1:
-            # identical twins (the three duty pumps, the three SGs, constants): keep the names of this instance,
-            # then the name that carries the member's own name
-            sec, inst = (label.split("[")[0], int(label.split("[")[1].split("]")[0])) if label.split(".")[0].endswith("]") else (label.split(".")[0], None)
-            token = {"pump": "FWP-%d", "sg": "SG-%d"}.get(sec)
-            if token is not None and inst is not None:
-                narrowed = [n for n in hits if (token % (inst + 1)) in n]
-                hits = narrowed or hits
-            base = label.split(".")[-1].split("[")[0]
-            narrowed = [n for n in hits if n.split(".")[-1] == base] or [n for n in hits if base in n.split(".")[-1]]
-            hits = narrowed if len(narrowed) == 1 else hits
-        if len(hits) == 1:
-            out[label] = hits[0]
-        elif len(hits) > 1:
-            ambiguous += 1
-            if os.environ.get("NPB_NAMES_VERBOSE"):
-                print("ambiguous:", label, hits[:6])
-    # one member per log column: when two members share a series (speed_percent / speed_setpoint at steady speed) the one
-    # whose own name ends the log name keeps it
-    taken = {}
-    for label, name in list(out.items()):
-        base = label.split(".")[-1].split("[")[0]
-        if name in taken:
-            other = taken[name]
-            if name.split(".")[-1] == base:
-                del out[other]; taken[name] = label
-            else:
-                del out[label]
+            unmatched.append(name); continue
+        if np.ptp(series) == 0.0:
+            constant += 1; continue
+        best = None
+        for f in FACTORS:
+            hits = [j for j in usable if np.array_equal(mine[:, j] * f if f != 1.0 else mine[:, j], series)]
+            if hits:
+                j = max(hits, key=lambda j: _closeness(cols[j][2], name))
+                best = (cols[j][2], f)
+                break
+        if best is None:
+            unmatched.append(name)
         else:
-            taken[name] = label
-    # the scalars of step()'s info["secondary_system"] dictionary (secondary/__init__.py:930-1010) that are state members
-    result_keys = {}
-    numeric = [k for k, v in results[0].items() if isinstance(v, (int, float, bool))]
-    for k in numeric:
-        series = np.array([float(r[k]) for r in results])
-        hits = [cols[j][2] for j in range(len(cols)) if not np.isnan(mine[:, j]).any() and np.array_equal(mine[:, j], series)]
-        if len(hits) > 1:   # twins: prefer the section the key names, then the member whose name ends the key
-            pref = {"condenser": "cond.", "turbine": "turb.", "feedwater": "fw.", "sg": "sec.sg_", "water_chemistry": "chem[0].", "ph_control": "ph."}
-            for word, sec_prefix in pref.items():
-                if k.startswith(word):
-                    hits = [h for h in hits if h.startswith(sec_prefix)] or hits
-            narrowed = [h for h in hits if k.endswith(h.split(".")[-1].split("[")[0])] or [h for h in hits if h.startswith("sec.")]
-            hits = narrowed if narrowed else hits
-        if hits and np.ptp(series) > 0:      # a constant series proves nothing
-            result_keys[k] = hits[0]
+            log_columns[name] = [best[0], best[1]]
+    # the 1:1 map (member -> one column): of the columns that map to a member with factor 1, the closest name
+    one = {}
+    for name, (label, f) in log_columns.items():
+        if f != 1.0:
+            continue
+        if label not in one or _closeness(label, name) > _closeness(label, one[label]):
+            one[label] = name
     path = os.path.join(ROOT, "nuclear_sim_amd", "state_names.json")
+    old = json.load(open(path)) if os.path.exists(path) else {}
     with open(path, "w") as fh:
-        json.dump({"source": "reference StateManager log, oil_top_off action-test run, %d steps" % steps,
-                   "log_columns": len(df.columns) - 1, "names": out,
-                   "secondary_result_keys": result_keys, "secondary_result_numeric_keys": len(numeric)}, fh, indent=1, sort_keys=True)
-    print("%d of %d numeric keys of step()'s secondary_system result are state members" % (len(result_keys), len(numeric)))
-    print("%d of %d schema columns mapped onto the reference's %d log columns (%d ambiguous left out) -> %s"
-          % (len(out), len(cols), len(df.columns) - 1, ambiguous, path))
+        json.dump({"source": "reference StateManager log: three action-test runs (moving load; pump trip + NPSH collapse + cooling-water swing; "
+                             "seal_replacement seed 3), %d steps in all" % len(mine),
+                   "reference_log_columns": len(runs[0][1]), "constant_in_all_runs": constant, "unmatched": sorted(unmatched),
+                   "names": one, "log_columns": log_columns,
+                   "secondary_result_keys": old.get("secondary_result_keys", {}),
+                   "secondary_result_numeric_keys": old.get("secondary_result_numeric_keys", 0)}, fh, indent=1, sort_keys=True)
+    print("%d of the reference's %d numeric log columns mapped onto %d members (%d constant in every run, %d without a member) -> %s"
+          % (len(log_columns), len(log), len(set(v[0] for v in log_columns.values())), constant, len(unmatched), path))
+    make_m1_log()
+
+
+def make_m1_log():
+    """tests/golden/log_m1_oil_top_off_staggered.npz: the reference's own log for the run of fixture m1_oil_top_off_staggered"""
+    from oracle.ref_harness import make_golden, trace
+    sc = [s for s in make_golden.scenarios() if s["name"] == "m1_oil_top_off_staggered"][0]
+    ref, sim = trace.run_reference(dict(sc), SCHEMA.columns())
+    df = sim.state_manager.data
+    keep, data = [], []
+    for name in df.columns:
+        if name == "time":
+            continue
+        try:
+            v = df[name].astype(float).to_numpy()
+        except (TypeError, ValueError):
+            continue
+        keep.append(name); data.append(v)
+    out = os.path.join(ROOT, "tests", "golden", "log_m1_oil_top_off_staggered.npz")
+    np.savez_compressed(out, names=np.array(keep), log=np.array(data).T)
+    print("log_m1: %d rows x %d columns -> %s" % (len(df), len(keep), out))
 
 
 if __name__ == "__main__":

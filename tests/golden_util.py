@@ -20,7 +20,7 @@ ATOL_SMALL = 1e-12
 def fixture_names():
     """trajectory fixtures (ic_*.npz hold initial states only, tests/test_scenarios.py)"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith("ic_")]
+    return [n for n in names if not n.startswith(("ic_", "log_"))]     # log_*: the reference's own state log of a fixture's run
 
 
 class Golden:

@@ -743,11 +743,18 @@ def test_nan_state_propagates_like_the_reference(oracle_lib):
 
 
 def test_state_log_matches_the_references_log(tmp_path):
-    """the columnar state log sampled every step of the m1 data-gen run holds, under the reference's own
-    log-column names, the values the reference's attributes had at those steps (the fixture's per-step states)."""
+    """the columnar state log sampled every step of the m1 data-gen run against the reference's OWN log of the
+    same run (tests/golden/log_m1_oil_top_off_staggered.npz = `sim.state_manager.data`): every log column the map claims
+    (265 of the reference's 784 numeric columns, several per member, unit factors applied) must hold the reference's values
+    at every step, under the reference's column names."""
+    import os
     import pyarrow.parquet as pq
-    from nuclear_sim_amd.statelog import StateLog
+    from golden_util import GOLDEN_DIR
+    from nuclear_sim_amd.statelog import StateLog, reference_log_columns
     g = Golden("m1_oil_top_off_staggered")
+    z = np.load(os.path.join(GOLDEN_DIR, "log_m1_oil_top_off_staggered.npz"))
+    ref_names = [str(x) for x in z["names"]]; ref = z["log"]
+    assert ref.shape == (g.T, len(ref_names))
     n = 64
     env = _env(g, n=n)
     f0, i0 = _host_state(env)
@@ -760,29 +767,23 @@ def test_state_log_matches_the_references_log(tmp_path):
         sp = None if np.isnan(g.setpoint[t]) else g.setpoint[t]
         env.step(action=int(g.action[t]), magnitude=float(g.magnitude[t]), power_setpoint=sp, noise_z=float(g.noise_z[t]))
         assert log.maybe_record(t + 1, (t + 1) * env.dt)
-    data = log.array()                                   # [samples, fields, plants]
-    assert data.shape == (g.T, len(log.columns), n)
-    sampled = {int(s): k for k, s in enumerate(g.state_steps)}
-    labels = [c[2] for c in g.cols]                      # the fixture's states, in schema order
-    checked = 0
-    for fi, (kind, slot, label, name) in enumerate(log.columns):
-        col = labels.index(label)
-        for t in range(g.T):
-            if t + 1 in sampled:
-                want = g.state[sampled[t + 1], col]
-                if np.isnan(want):
-                    continue
-                for lane in (0, n - 1):
-                    assert abs(data[t, fi, lane] - want) <= RTOL * abs(want) + 1e-9, (name, t, data[t, fi, lane], want)
-                checked += 1
-    assert checked > 1000
-    tab = log.table(plants=[0, 5])
+    tab = log.table(plants=[0, n - 1])
     assert tab.num_rows == g.T * 2 and tab.column_names[:3] == ["step", "time", "plant"]
-    assert "secondary.feedwater_FWP-1.oil_level" in tab.column_names
+    lc = reference_log_columns()
+    assert len(lc) >= 250 and set(lc) <= set(tab.column_names) and set(lc) <= set(ref_names)
+    checked = 0
+    for name in lc:
+        mine = tab[name].to_numpy().reshape(g.T, 2)
+        want = ref[:, ref_names.index(name)]
+        for lane in (0, 1):
+            ok = np.abs(mine[:, lane] - want) <= RTOL * np.abs(want) + 1e-9
+            assert ok.all(), (name, int(np.argmin(ok)), mine[~ok, lane][:3], want[~ok][:3])
+        checked += g.T
+    assert checked > 10000
     path = str(tmp_path / "m1.parquet")
     log.write_parquet(path, plants=[0])
     back = pq.read_table(path)
-    assert back.num_rows == g.T and np.allclose(back["secondary.feedwater_FWP-1.oil_level"].to_numpy(), data[:, [c[3] for c in log.columns].index("secondary.feedwater_FWP-1.oil_level"), 0])
+    assert back.num_rows == g.T and np.allclose(back["secondary.feedwater_FWP-1.oil_level"].to_numpy(), ref[:, ref_names.index("secondary.feedwater_FWP-1.oil_level")], rtol=1e-9)
 
 
 def test_facade_reads_and_pokes_through_reference_attribute_paths():

@@ -5,7 +5,7 @@ import re
 import pytest
 
 from nuclear_sim_amd.schema import SCHEMA
-from nuclear_sim_amd.statelog import log_columns, reference_names
+from nuclear_sim_amd.statelog import log_columns, reference_names, reference_log_columns
 
 
 def test_every_mapped_label_is_a_schema_column_and_names_are_unique():
@@ -25,6 +25,20 @@ def test_column_selection():
                                     "sec.electrical_power_output", "pump[2].status"]
     assert cols[-1][3] == "npb.pump[2].status" and cols[-1][0] == "i32"
     assert len(log_columns(["tstg.blade_temperatures"])) == 14
-    assert len(log_columns()) == len(reference_names())
+    members = {label for label, _f in reference_log_columns().values()}
+    assert len(log_columns()) == len(members)
     with pytest.raises(KeyError):
         log_columns(["pump.no_such_member"])
+
+
+def test_log_column_map_is_consistent():
+    """log column -> (member, factor): every member exists, the 1:1 names are a subset, and the reference's habit of logging one
+    quantity under several names is kept (the secondary side's total feedwater flow appears twice)"""
+    lc = reference_log_columns()
+    labels = {c[2] for c in SCHEMA.columns()}
+    assert len(lc) >= 250 and {label for label, _f in lc.values()} <= labels
+    names = reference_names()
+    assert all(lc[name] == (label, 1.0) for label, name in names.items())
+    same = [n for n, (label, f) in lc.items() if label == "sec.total_feedwater_flow"]
+    assert len(same) >= 2
+    assert all(re.match(r"^(primary|secondary)\.", n) for n in lc)
