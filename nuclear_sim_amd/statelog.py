@@ -7,7 +7,7 @@ Here a sample is one gather kernel (`npb_gather_fields`): the chosen members of 
 in a device buffer `[sample, field, plant]`; nothing touches the host until `table()` / `write_parquet()`.
 
 Columns carry the reference's own log names: `state_names.json` (made by running the reference through three eventful
-runs and matching whole series value for value, oracle/ref_harness/make_state_names.py) maps 265 of the reference's 784
+runs and matching whole series value for value; the generator script is named in DESIGN.md section 6) maps 265 of the reference's 784
 numeric log columns onto 193 state members -- several log columns can show one member (the reference logs the total
 feedwater flow three times), a few through a unit factor.  `StateLog(env)` without a field list records exactly those
 members and `table()` emits every one of the 265 columns; members selected by name that the reference does not log come
