@@ -852,8 +852,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_reset_kernel(npb_params_t P, siz
  * threshold scan with work-order creation (npd_maintenance.h), for the four feedwater pumps.  Two launches:
  *   npb_maint_screen_kernel  what nearly every step of nearly every plant ends with: nothing to do.  HBM-bound and
  *     small -- per plant sim_time, three members of the maintenance section, and per pump the 15 members thresholds
- *     look at and the 16 last-violation stamps, 128 independent loads (~1 KB) issued at once and evaluated without a
- *     branch, one wave per (64 plants, pump).  It moves last_check_time where a check fell due with no order open, and
+ *     look at (~0.5 KB, issued at once, evaluated without a branch), plus that pump's 16 last-violation stamps where a wave
+ *     has any violated row at all; one wave per (64 plants, pump).  It moves last_check_time where a check fell due with no order open, and
  *     writes one flag word per wave: some plant has a check falling on open orders, or a fresh violation on this pump.
  *   npb_maint_kernel         the full rule, for the 64 plants of a flagged wave only: work orders, the orchestrator,
  *     the thirteen handlers.  Rare, so it is written for clarity, not for registers.
@@ -882,11 +882,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_screen_kernel(npd_maint_sc
   NPD_PM(cavitation_intensity); NPD_PM(npsh_available); NPD_PM(wear_motor_bearings); NPD_PM(wear_pump_bearings); NPD_PM(wear_thrust_bearing);
   NPD_PM(wear_mechanical_seals); NPD_PM(vibration_level); NPD_PM(oil_temperature); NPD_PM(motor_temperature); NPD_PM(seal_leakage_rate);
 #undef NPD_PM
-  double values[NPB_MAINT_NPARAM], stamp[NPB_MAINT_NPARAM];
+  double values[NPB_MAINT_NPARAM];
   npd_maint_values(&pm, values);
-#pragma unroll
-  for (int q = 0; q < NPB_MAINT_NPARAM; q++)   /* read once per step by nobody else: non-temporal, so that they do not displace the step kernel's working set */
-    stamp[q] = (double)__builtin_nontemporal_load((const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q)));
   bool work = false;
   if (k == 0) {
     /* AutoMaintenanceSystem.update as far as it needs no order: a check that falls due with nothing open only moves
@@ -898,14 +895,24 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_screen_kernel(npd_maint_sc
     work = due & (created > performed);
     if (due & !work) *(npd_real_t *)npd_gaddr(f64, N, p, NPD_SEC_COL(MAINT, 0) + NPB_F64_SLOT(npb_maint_t, last_check_time)) = (npd_real_t)t;
   }
+  /* first the comparisons alone; the 16 last-violation stamps (half of the screen's bytes) are fetched only by a wave in
+   * which some row is violated at all, to see whether it is still inside its cooldown */
+  uint32_t hits = 0;
 #pragma unroll
   for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
-    const double v = values[q], thr = S.threshold[q], lv = stamp[q];
-    const bool cooling = (lv >= 0.0) & (t - lv < S.cooldown_minutes[q]);        /* _is_threshold_in_cooldown */
+    const double v = values[q], thr = S.threshold[q];
     const bool near_eq = fabs(v - thr) < 0.001;                                  /* _check_threshold_condition */
     const bool hit = (((S.want_gt >> q) & 1u) != 0) & (v > thr) | (((S.want_lt >> q) & 1u) != 0) & (v < thr) | (((S.want_eq >> q) & 1u) != 0) & (v == thr) |
                      (((S.want_near >> q) & 1u) != 0) & near_eq | (((S.want_far >> q) & 1u) != 0) & !near_eq;
-    work |= hit & !cooling;
+    hits |= (uint32_t)hit << q;
+  }
+  if (__any(hits != 0)) {
+#pragma unroll
+    for (int q = 0; q < NPB_MAINT_NPARAM; q++) {   /* read by nobody else in a step: non-temporal, so that they do not displace the step kernel's working set */
+      const double lv = (double)__builtin_nontemporal_load((const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q)));
+      const bool cooling = (lv >= 0.0) & (t - lv < S.cooldown_minutes[q]);        /* _is_threshold_in_cooldown */
+      work |= (((hits >> q) & 1u) != 0) & !cooling;
+    }
   }
   const bool wave_has_work = __any(work) != 0;
   if (threadIdx.x == 0) wave_flags[blockIdx.x] = wave_has_work ? 1u : 0u;
