@@ -9,10 +9,12 @@ in a device buffer `[sample, field, plant]`; nothing touches the host until `tab
 Columns carry the reference's own log names: `state_names.json` (made by running the reference through three eventful
 runs and matching whole series value for value; the generator script is named in DESIGN.md section 6) maps 265 of the reference's 784
 numeric log columns onto 193 state members -- several log columns can show one member (the reference logs the total
-feedwater flow three times), a few through a unit factor.  `StateLog(env)` without a field list records exactly those
-members and `table()` emits every one of the 265 columns; members selected by name that the reference does not log come
-out as `npb.<section>.<member>`.  Not reproduced: the reference's derived diagnostics (per-stage turbine conditions, SG
-capacities and heat fluxes, system averages ...: 251 columns) and the 268 columns that never vary in any of the runs.
+feedwater flow three times), a few through a unit factor -- and `derived_log_columns()` adds the columns that are plain
+functions of the end-of-step state (pump performance factors, wear sums, steam-generator system averages, TSP deposit
+aggregates, level-control errors).  `StateLog(env)` without a field list records the members all of these need and `table()`
+emits every such column; members selected by name that the reference does not log come
+out as `npb.<section>.<member>`.  Not reproduced: the reference's diagnostics that are left over from inside the step (per-stage turbine conditions, SG
+capacities and heat fluxes, bearing loads ...: ~225 columns) and the 268 columns that never vary in any of the runs.
 
     log = StateLog(env, fields=["pump.oil_level", "sec.electrical_power_output"], every=12, capacity=64)
     for t in range(steps):
@@ -48,6 +50,63 @@ def reference_log_columns() -> Dict[str, tuple]:
         return {k: (v[0], float(v[1])) for k, v in json.load(fh)["log_columns"].items()}
 
 
+def _max(a, b):
+    return np.where(b > a, b, a)
+
+
+def derived_log_columns() -> Dict[str, tuple]:
+    """The reference's log columns that are not a state member but a plain function of state members at the moment the log
+    is taken: name -> (member labels it needs, function of their arrays).  Each formula restates the provider's
+    get_state_dict (cited); all of them were checked series for series on the three runs the name map is built from, and are
+    checked against the reference's own log in tests/test_gpu_parity.py.  (Derived values that are left over from inside
+    the step -- stage conditions, heat fluxes, the pumps' health factor -- are not functions of the end-of-step state and
+    are not here.)"""
+    out = {}
+    for k in range(4):
+        P, N = "pump[%d]." % k, "secondary.feedwater_FWP-%d." % (k + 1)
+        # pump_lubrication.py:225-238 (properties), :1596-1620 (state dict)
+        out[N + "efficiency_factor"] = ((P + "efficiency_degradation",), lambda d: _max(0.5, 1 - d / 100))
+        out[N + "flow_factor"] = ((P + "flow_degradation",), lambda d: _max(0.5, 1 - d / 100))
+        out[N + "sum_wear_level"] = ((P + "wear_impeller", P + "wear_motor_bearings", P + "wear_pump_bearings", P + "wear_thrust_bearing",
+                                     P + "wear_mechanical_seals"), lambda i, a, b, c, s_: i + _max(_max(a, b), c) + s_)
+    S = "secondary.steam_generator_SECONDARY-COMP-001-SG."      # steam_generator/enhanced_physics.py:672-723
+    three = lambda f: tuple("sg[%d].%s" % (i, f) for i in range(3))
+    mean3 = lambda a, b, c: (0 + a + b + c) / 3
+    out[S + "system_avg_tsp_fouling_fraction"] = (three("tsp_fouling_fraction"), mean3)
+    out[S + "system_avg_tsp_heat_transfer_degradation"] = (three("tsp_ht_degradation"), mean3)
+    out[S + "system_avg_scale_thickness_mm"] = (three("scale_thickness"), mean3)
+    out[S + "system_avg_scale_thermal_resistance"] = (three("scale_thermal_resistance"), mean3)
+    out[S + "system_total_fouling_impact"] = (three("tsp_ht_degradation") + three("scale_thermal_resistance"),
+                                              lambda a, b, c, x, y, z: mean3(a, b, c) + mean3(x, y, z) * 1000.0)
+    out[S + "system_total_thermal_power"] = (three("heat_transfer_rate"), lambda a, b, c: (0 + a + b + c) / 1e6)
+    out[S + "system_load_demand"] = (("sec.load_demand",), lambda x: x / 100.0)
+    F = "secondary.feedwater_SECONDARY-COMP-001-FW."             # feedwater/level_control.py state dict
+    errs = tuple("fw.previous_level_errors[%d]" % i for i in range(3))
+    out[F + "level_control_avg_error"] = (errs, lambda a, b, c: (np.abs(a) + np.abs(b) + np.abs(c)) / 3)
+    out[F + "level_control_max_error"] = (errs, lambda a, b, c: _max(_max(np.abs(a), np.abs(b)), np.abs(c)))
+    for i in range(3):                                           # tsp_fouling_model.py:131-152
+        need = tuple("sg[%d].tsp_%s[%d]" % (i, sp, l) for l in range(7) for sp in ("magnetite", "copper", "silica", "biological"))
+
+        def totals(*v):
+            return [v[4 * l] + v[4 * l + 1] + v[4 * l + 2] + v[4 * l + 3] for l in range(7)]
+
+        def avg(*v):
+            s_ = 0.0
+            for t_ in totals(*v):
+                s_ = s_ + t_
+            return s_ / 7
+
+        def mx(*v):
+            m_ = 0.0 * v[0]
+            for t_ in totals(*v):
+                m_ = _max(m_, t_)
+            return m_
+        out["secondary.steam_generator_SG-%d.tsp_average_deposit_thickness" % i] = (need, avg)
+        out["secondary.steam_generator_SG-%d.tsp_maximum_deposit_thickness" % i] = (need, mx)
+    mapped = set(reference_log_columns())
+    return {k: v for k, v in out.items() if k not in mapped}
+
+
 def log_columns(fields: Optional[Sequence[str]] = None) -> List[tuple]:
     """[(kind, slot, schema label, log column name)] of the members a log would hold.  `fields`: schema names
     ("pump.oil_level" = every instance and element, or a full label such as "pump[2].oil_level"); None = every
@@ -57,6 +116,8 @@ def log_columns(fields: Optional[Sequence[str]] = None) -> List[tuple]:
     out = []
     if fields is None:
         wanted = {label for label, _f in reference_log_columns().values()}
+        for need, _fn in derived_log_columns().values():
+            wanted.update(need)
         for kind, slot, label, _path in cols:
             if label in wanted:
                 out.append((kind, slot, label, names.get(label, "npb." + label)))
@@ -132,6 +193,8 @@ class StateLog:
             for name, (label, factor) in sorted(reference_log_columns().items()):
                 v = data[:, index[label], :].reshape(-1)
                 cols[name] = v * factor if factor != 1.0 else v
+            for name, (need, fn) in sorted(derived_log_columns().items()):
+                cols[name] = np.asarray(fn(*[data[:, index[label], :].reshape(-1) for label in need]), dtype=np.float64)
             return pa.table(cols)
         for f, (kind, _slot, _label, name) in enumerate(self.columns):
             v = data[:, f, :].reshape(-1)

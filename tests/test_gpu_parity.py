@@ -750,7 +750,7 @@ def test_state_log_matches_the_references_log(tmp_path):
     import os
     import pyarrow.parquet as pq
     from golden_util import GOLDEN_DIR
-    from nuclear_sim_amd.statelog import StateLog, reference_log_columns
+    from nuclear_sim_amd.statelog import StateLog, reference_log_columns, derived_log_columns
     g = Golden("m1_oil_top_off_staggered")
     z = np.load(os.path.join(GOLDEN_DIR, "log_m1_oil_top_off_staggered.npz"))
     ref_names = [str(x) for x in z["names"]]; ref = z["log"]
@@ -771,8 +771,10 @@ def test_state_log_matches_the_references_log(tmp_path):
     assert tab.num_rows == g.T * 2 and tab.column_names[:3] == ["step", "time", "plant"]
     lc = reference_log_columns()
     assert len(lc) >= 250 and set(lc) <= set(tab.column_names) and set(lc) <= set(ref_names)
+    derived = derived_log_columns()      # plain functions of the end-of-step state (pump factors, wear sums, SG system averages ...)
+    assert len(derived) >= 20 and set(derived) <= set(tab.column_names) and set(derived) <= set(ref_names) and not set(derived) & set(lc)
     checked = 0
-    for name in lc:
+    for name in list(lc) + list(derived):
         mine = tab[name].to_numpy().reshape(g.T, 2)
         want = ref[:, ref_names.index(name)]
         for lane in (0, 1):

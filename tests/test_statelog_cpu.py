@@ -25,7 +25,10 @@ def test_column_selection():
                                     "sec.electrical_power_output", "pump[2].status"]
     assert cols[-1][3] == "npb.pump[2].status" and cols[-1][0] == "i32"
     assert len(log_columns(["tstg.blade_temperatures"])) == 14
+    from nuclear_sim_amd.statelog import derived_log_columns
     members = {label for label, _f in reference_log_columns().values()}
+    for need, _fn in derived_log_columns().values():
+        members.update(need)
     assert len(log_columns()) == len(members)
     with pytest.raises(KeyError):
         log_columns(["pump.no_such_member"])
