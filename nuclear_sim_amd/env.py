@@ -396,7 +396,8 @@ def secondary_result(info: Dict[str, torch.Tensor], members: Dict[str, torch.Ten
     f["water_chemistry_aggressiveness"] = members["chem.water_aggressiveness"]
     f["water_chemistry_treatment_efficiency"] = members["chem.treatment_efficiency"]
     f["ph_control_output"] = members["ph.controller_output"]; f["ph_control_ammonia_dose"] = members["ph.pending_ammonia_dose"]
-    f["ph_control_error"] = members["ph.previous_error"]
+    # ph_control_system.py:243: setpoint - measured, computed every step (previous_error only follows it while the controller is enabled)
+    f["ph_control_error"] = 9.2 - members["ph.measured_ph"]
     f["load_demand"] = members["sec.load_demand"]; f["feedwater_temperature"] = one * 227.0
     f["cooling_water_inlet_temp"] = members["sec.cooling_water_temperature"]; f["cooling_water_outlet_temp"] = members["cond.cooling_water_outlet_temp"]
     # condenser/physics.py:692-693: outlet = inlet + rise, so the rise is their difference (to 1e-15 of the temperatures)
@@ -409,7 +410,7 @@ def secondary_result(info: Dict[str, torch.Tensor], members: Dict[str, torch.Ten
 SECONDARY_RESULT_MEMBERS = ("sec.electrical_power_output", "sec.thermal_efficiency", "sec.sg_avg_temperature", "sec.sg_avg_quality",
                             "cond.heat_rejection_rate", "cond.vacuum_system_efficiency", "fw.running_mask", "fw.system_availability",
                             "chem.ph", "chem.water_aggressiveness", "chem.treatment_efficiency", "ph.controller_output",
-                            "ph.pending_ammonia_dose", "ph.previous_error", "sec.load_demand", "sec.cooling_water_temperature",
+                            "ph.pending_ammonia_dose", "ph.measured_ph", "sec.load_demand", "sec.cooling_water_temperature",
                             "cond.cooling_water_outlet_temp")
 
 

@@ -189,7 +189,69 @@ def scenarios():
                   actions=lambda t: (int(acts[t]), float(mags[t])), resets={70: True}))
     S.append(dict(name="p2_primary_only_constant", steps=80, noise=True, noise_seed=21, every=2, enable_secondary=False,
                   setpoints=lambda t: 100.0 - 0.5 * t if t < 40 else None))
+    S.extend(fuzz_scenarios())
     return S
+
+
+# members whose reference attribute is a per-step COPY of something the simulator object holds (sim.cooling_water_temp, sim.load_demand,
+# the time): assigning the copy has no effect in the reference, the schema column is the carried value
+FUZZ_SKIP = ("prim.sim_time", "sec.cooling_water_temperature", "sec.load_demand", "turb.load_demand")
+# members the reference keeps a derived copy of (TurbineStage.blade_condition_factor / fouling_factor are stored at the end of a
+# step from blade_wear_factor / deposit_thickness and read at the start of the next, stage_system.py:221-224,318-321): assigning the
+# member alone would leave the copy stale for one step, which a step of the real simulator never does
+FUZZ_SKIP_PREFIX = ("tstg.stage_blade_wear_factor", "tstg.stage_deposit_thickness")
+
+
+def fuzz_scenarios(seeds=(1, 2, 3, 4, 5, 6, 7, 8)):
+    """Z1-Z8: fuzzed states.  The scenario fixtures visit what plant scenarios visit; these start the reference from states no
+    scenario would reach -- every assignable real-valued state member of a freshly constructed simulator scaled by an
+    independent factor in [0.8, 1.25] with probability 0.6 (seeds 1-4, from the default construction state, whose turbine trips on thermal
+    expansion at the first step; seeds 5-8 jitter the data-gen runner's plant, which makes power, by [0.97, 1.03]) (levels above 100 %, pressures past their limits, wear past its
+    trip thresholds, deposits, temperatures, integrators, timers that were running) -- and run it for 16 steps under random
+    operator actions and load changes.  A restatement error in a branch only such a state takes shows up here.  Seeds for
+    which the reference itself raises are dropped."""
+    from . import refsim, trace as tr
+    cols = SCHEMA.columns()
+    out = []
+    for seed in seeds:
+        running = seed > 4          # seeds 5-8: the data-gen runner's plant (proper initial conditions: it makes power), mild jitter
+        heat = "constant" if running else ("reactor" if seed % 2 == 0 else "constant")
+        if running:
+            _runner, sim = refsim.make_runner_sim(action="oil_top_off", duration_hours=2.0)
+        else:
+            sim = refsim.make_sim(dt=1.0, heat_source=heat, noise=(heat == "constant"), noise_seed=100 + seed)
+        if heat == "reactor":
+            from systems.primary.reactor.reactivity_model import create_equilibrium_state
+            with refsim.quiet():
+                st = create_equilibrium_state(power_level=100.0, control_rod_position=95.0, auto_balance=True)
+            sim.primary_physics.state = st; sim.state = st
+        rng = np.random.default_rng(7000 + seed)
+        pokes = []
+        for kind, _slot, label, path in cols:
+            if kind != "f64" or not path or "H." in path or "float(" in path or label.startswith(("maint.", "mpump.") + FUZZ_SKIP_PREFIX) or label in FUZZ_SKIP or \
+                    (path.startswith("=") and path.rstrip().endswith("]")):      # list(d.values())[k] = v would assign into a temporary
+                continue
+            v = tr._val(sim, path)
+            if not np.isfinite(v) or v == 0.0 or rng.random() >= 0.6:
+                continue
+            if running and label.startswith(("turb.", "tstg.")) and ("temperature" in label or "expansion" in label):
+                continue                     # a few degrees more metal temperature trip the turbine at once (thermal expansion)
+            lo, hi = (0.97, 1.03) if running else (0.8, 1.25)
+            pokes.append((path, float(v * rng.uniform(lo, hi))))
+        acts = rng.choice([0, 1, 2, 3, 8, 9, 10, 4, 5, 8, 8], size=16); mags = rng.uniform(0, 1, size=16)
+        sp = 100.0 - rng.uniform(0, 30)
+        sc = dict(name="z%d_fuzzed_state_%s" % (seed, "running" if running else heat), steps=16, heat_source=heat, noise=(heat == "constant"),
+                  noise_seed=42 if running else 100 + seed, every=1,
+                  pokes={(1 if running else 0): pokes},   # the runner's plant takes its initial conditions at the first step
+                  actions=(lambda t, a=acts, m=mags: (int(a[t]), float(m[t]))))
+        if running:
+            sc.update(dt=5.0, runner=dict(action="oil_top_off", duration_hours=2.0))
+        else:
+            sc["setpoints"] = (lambda t, sp=sp: sp if t == 2 else None) if heat == "constant" else None
+        if heat == "reactor":
+            sc["equilibrium"] = (100.0, 95.0)
+        out.append(sc)
+    return out
 
 
 def main(only=None):
@@ -201,7 +263,12 @@ def main(only=None):
     for sc in scenarios():
         if only and sc["name"] not in only:
             continue
-        ref, _sim = trace.run_reference(sc, cols)
+        try:
+            ref, _sim = trace.run_reference(sc, cols)
+        except Exception as e:          # a fuzzed state the reference itself cannot step: dropped
+            if not sc["name"].startswith("z"):
+                raise
+            print(sc["name"], "dropped:", type(e).__name__, str(e)[:100]); continue
         T = sc["steps"]
         every = sc.get("every", 1)
         steps = sorted(set(list(range(0, T + 1, every)) + [T] + [t + 1 for t in sc.get("pokes", {})] + list(sc.get("pokes", {}).keys())

@@ -43,6 +43,16 @@ def _val(sim, path):
         return np.nan
 
 
+def _poke(sim, path, v):
+    """assign a reference attribute: a plain attribute chain, or one of the schema's "=expression" paths when the expression is
+    itself assignable (list(root....values())[k].member)"""
+    if path.startswith("="):
+        from .leaves import H
+        exec(path[1:] + " = v", {"root": sim, "H": H, "v": v})
+    else:
+        exec("sim.%s = v" % path, {"sim": sim, "v": v})
+
+
 def poke_value(v):
     """a poke's value: a number, or "=<expr>" evaluated with the reference's enums in scope (e.g. "=PumpStatus.STOPPING")"""
     if isinstance(v, str) and v.startswith("="):
@@ -88,7 +98,7 @@ def run_reference(sc, columns):
         sim.primary_physics.state = st
         sim.state = st
     for path, v in sc.get("init_pokes", []):
-        exec("sim.%s = v" % path, {"sim": sim, "v": poke_value(v)})
+        _poke(sim, path, poke_value(v))
     T = sc["steps"]
     paths = [c[3] for c in columns]
     state = np.full((T + 1, len(paths)), np.nan)
@@ -107,7 +117,7 @@ def run_reference(sc, columns):
     reset_steps, reset_modes, reset_obs, reset_state = [], [], [], []
     for t in range(T):
         for path, v in sc.get("pokes", {}).get(t, []):
-            exec("sim.%s = v" % path, {"sim": sim, "v": poke_value(v)})
+            _poke(sim, path, poke_value(v))
         if t in resets:
             with refsim.quiet():
                 ob = sim.reset(start_at_steady_state=bool(resets[t]))
