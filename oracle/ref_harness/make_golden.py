@@ -202,11 +202,11 @@ FUZZ_SKIP = ("prim.sim_time", "sec.cooling_water_temperature", "sec.load_demand"
 FUZZ_SKIP_PREFIX = ("tstg.stage_blade_wear_factor", "tstg.stage_deposit_thickness")
 
 
-def fuzz_scenarios(seeds=tuple(range(1, 13)) + tuple(int(x) for x in os.environ.get("NPB_FUZZ_EXTRA", "").split())):
+def fuzz_scenarios(seeds=tuple(range(1, 17)) + tuple(int(x) for x in os.environ.get("NPB_FUZZ_EXTRA", "").split())):
     """Z1-Z8: fuzzed states.  The scenario fixtures visit what plant scenarios visit; these start the reference from states no
     scenario would reach -- every assignable real-valued state member of a freshly constructed simulator scaled by an
     independent factor in [0.8, 1.25] with probability 0.6 (seeds 1-4, from the default construction state, whose turbine trips on thermal
-    expansion at the first step; seeds 5-8 jitter the data-gen runner's plant, which makes power, by [0.97, 1.03], seeds 9-12 by [0.85, 1.18]) (levels above 100 %, pressures past their limits, wear past its
+    expansion at the first step; seeds 5-8 jitter the data-gen runner's plant, which makes power, by [0.97, 1.03], seeds 9-12 by [0.85, 1.18]; seeds 13-16 also flip flags and redraw pump states) (levels above 100 %, pressures past their limits, wear past its
     trip thresholds, deposits, temperatures, integrators, timers that were running) -- and run it for 16 steps under random
     operator actions and load changes.  A restatement error in a branch only such a state takes shows up here.  Seeds for
     which the reference itself raises are dropped."""
@@ -236,8 +236,17 @@ def fuzz_scenarios(seeds=tuple(range(1, 13)) + tuple(int(x) for x in os.environ.
                 continue
             if running and label.startswith(("turb.", "tstg.")) and ("temperature" in label or "expansion" in label):
                 continue                     # a few degrees more metal temperature trip the turbine at once (thermal expansion)
-            lo, hi = ((0.97, 1.03) if seed <= 8 else (0.85, 1.18)) if running else (0.8, 1.25)
+            lo, hi = ((0.97, 1.03) if (seed <= 8 or seed > 12) else (0.85, 1.18)) if running else (0.8, 1.25)
             pokes.append((path, float(v * rng.uniform(lo, hi))))
+        if seed > 12:       # seeds 13-16: the flags and state machines as well -- every boolean member flipped with probability 0.2, pump states redrawn with 0.3
+            for kind, _slot, label, path in cols:
+                if kind != "i32" or not path or path.startswith("=") or label.startswith(("maint.", "mpump.")):
+                    continue
+                if label.endswith(".status"):
+                    if rng.random() < 0.3:
+                        pokes.append((path, "=PumpStatus.%s" % rng.choice(["STOPPED", "STARTING", "RUNNING", "STOPPING"])))
+                elif rng.random() < 0.2:
+                    pokes.append((path, "=%s" % (not bool(tr._val(sim, path)))))
         acts = rng.choice([0, 1, 2, 3, 8, 9, 10, 4, 5, 8, 8], size=16); mags = rng.uniform(0, 1, size=16)
         sp = 100.0 - rng.uniform(0, 30)
         sc = dict(name="z%d_fuzzed_state_%s" % (seed, "running" if running else heat), steps=16, heat_source=heat, noise=(heat == "constant"),

@@ -57,7 +57,7 @@ def poke_value(v):
     """a poke's value: a number, or "=<expr>" evaluated with the reference's enums in scope (e.g. "=PumpStatus.STOPPING")"""
     if isinstance(v, str) and v.startswith("="):
         from systems.primary.coolant.pump_models import PumpStatus
-        return eval(v[1:], {"PumpStatus": PumpStatus, "nan": float("nan"), "inf": float("inf")})
+        return eval(v[1:], {"PumpStatus": PumpStatus, "nan": float("nan"), "inf": float("inf"), "True": True, "False": False})
     return v
 
 
