@@ -202,11 +202,11 @@ FUZZ_SKIP = ("prim.sim_time", "sec.cooling_water_temperature", "sec.load_demand"
 FUZZ_SKIP_PREFIX = ("tstg.stage_blade_wear_factor", "tstg.stage_deposit_thickness")
 
 
-def fuzz_scenarios(seeds=tuple(range(1, 17)) + tuple(int(x) for x in os.environ.get("NPB_FUZZ_EXTRA", "").split())):
+def fuzz_scenarios(seeds=tuple(range(1, 21)) + tuple(int(x) for x in os.environ.get("NPB_FUZZ_EXTRA", "").split())):
     """Z1-Z8: fuzzed states.  The scenario fixtures visit what plant scenarios visit; these start the reference from states no
     scenario would reach -- every assignable real-valued state member of a freshly constructed simulator scaled by an
     independent factor in [0.8, 1.25] with probability 0.6 (seeds 1-4, from the default construction state, whose turbine trips on thermal
-    expansion at the first step; seeds 5-8 jitter the data-gen runner's plant, which makes power, by [0.97, 1.03], seeds 9-12 by [0.85, 1.18]; seeds 13-16 also flip flags and redraw pump states) (levels above 100 %, pressures past their limits, wear past its
+    expansion at the first step; seeds 5-8 jitter the data-gen runner's plant, which makes power, by [0.97, 1.03], seeds 9-12 by [0.85, 1.18]; seeds 13-16 also flip flags and redraw pump states; seeds 17-20 jitter the default plant and call reset() at once) (levels above 100 %, pressures past their limits, wear past its
     trip thresholds, deposits, temperatures, integrators, timers that were running) -- and run it for 16 steps under random
     operator actions and load changes.  A restatement error in a branch only such a state takes shows up here.  Seeds for
     which the reference itself raises are dropped."""
@@ -214,7 +214,7 @@ def fuzz_scenarios(seeds=tuple(range(1, 17)) + tuple(int(x) for x in os.environ.
     cols = SCHEMA.columns()
     out = []
     for seed in seeds:
-        running = seed > 4          # seeds 5-8: the data-gen runner's plant (proper initial conditions: it makes power), mild jitter
+        running = 4 < seed <= 16    # seeds 5-8: the data-gen runner's plant (proper initial conditions: it makes power), mild jitter
         heat = "constant" if running else ("reactor" if seed % 2 == 0 else "constant")
         if running:
             _runner, sim = refsim.make_runner_sim(action="oil_top_off", duration_hours=2.0)
@@ -253,6 +253,9 @@ def fuzz_scenarios(seeds=tuple(range(1, 17)) + tuple(int(x) for x in os.environ.
                   noise_seed=42 if running else 100 + seed, every=1,
                   pokes={(1 if running else 0): pokes},   # the runner's plant takes its initial conditions at the first step
                   actions=(lambda t, a=acts, m=mags: (int(a[t]), float(m[t]))))
+        if seed > 16:       # seeds 17-20: reset() right after the jitter -- which members survive a reset, on values no run would leave behind
+            sc["pokes"] = {2: pokes}; sc["resets"] = {2: seed % 2 == 1}
+            sc["name"] = "z%d_fuzzed_state_then_reset_%s" % (seed, heat)
         if running:
             sc.update(dt=5.0, runner=dict(action="oil_top_off", duration_hours=2.0))
         else:
