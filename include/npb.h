@@ -84,7 +84,10 @@ NPB_API void npb_default_params(npb_params_t *p);
 /* NuclearPlantSimulator.__init__ (sim.py:30-87) for n_plants plants on HIP device `device`:
  * allocates the SoA arena and fills it with the construction-time state.  One handle carries at most
  * 4 GiB of fp64 state (about one million plants: the step kernel's column offsets are 32-bit);
- * larger batches use several handles (they are independent). */
+ * larger batches use several handles (they are independent).  When the bytes a step touches are about the size of the
+ * 256 MB Infinity Cache (200-340 MB: 65 536 fp64 plants), where the arena lands in physical memory decides between 0.097
+ * and 0.110 ms per step; creation then times the step kernel on up to four candidate arenas and keeps the fastest
+ * (~15 ms; the arena ends in the construction-time state all the same; environment NPB_PLACEMENT_PROBE=0 turns it off). */
 NPB_API int npb_create(const npb_params_t *params, int n_plants, int device, NpbHandle **out);
 /* The same with the element type of the real-valued state columns chosen (BASELINE config 5, "fp32-mixed"):
  * NPB_STORAGE_F32 keeps the carried state as float in HBM and in the LDS staging -- half the traffic of

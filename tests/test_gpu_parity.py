@@ -987,3 +987,32 @@ def test_facade_without_a_secondary_side_and_with_the_reactor_models_terms(tmp_p
     sim = NuclearPlantSimulator(dt=1.0, heat_source=ConstantHeatSource(noise_enabled=False), secondary_config_file=str(path))
     assert [sim._env.get_field("pump.oil_level", instance=k)[0].item() for k in range(4)] == [61.0, 62.0, 63.0, 64.0]
     assert sim._env.params.maint_start_delay_hours == 1.0
+
+
+def test_placement_probing_leaves_the_construction_state(monkeypatch):
+    """npb_create times the step kernel on candidate arenas when the step's working set is about the size of the Infinity Cache
+    (65 536 plants) and keeps the fastest: the handle it returns must be in the construction-time state all the same, and
+    behave exactly like one created with the probe turned off."""
+    import torch
+    n = 65536
+    z = np.random.default_rng(3).standard_normal((3, n))
+    sp = np.linspace(70.0, 100.0, n)
+
+    def run():
+        env = _env(n=n, noise_enabled=True)
+        f0, i0 = env.state_arrays()
+        outs = []
+        for t in range(3):
+            obs, rew, done, info = env.step(power_setpoint=sp, noise_z=z[t])
+            outs.append((obs.clone(), rew.clone(), info["trip_flags"].clone()))
+        f1, i1 = env.state_arrays()
+        return f0, i0, f1, i1, outs
+
+    monkeypatch.setenv("NPB_PLACEMENT_PROBE", "0")
+    a = run()
+    monkeypatch.setenv("NPB_PLACEMENT_PROBE", "1")
+    b = run()
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)
+    for (o1, r1, f1), (o2, r2, f2) in zip(a[4], b[4]):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(f1, f2)
