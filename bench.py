@@ -119,6 +119,40 @@ def c3_noise(lo, n, total):
     return np.ascontiguousarray(z.T)
 
 
+def step_kernel_name(n):
+    """which step kernel npb_step launches for n plants (npb_kernels.hip, NPB_LAUNCHER(step)); NPB_STEP_KERNEL overrides"""
+    forced = os.environ.get("NPB_STEP_KERNEL", "0")
+    npad = (n + 63) // 64 * 64
+    if forced == "1" or (forced not in ("2", "3") and npad > 57344):
+        return "npb_step_kernel"
+    return "npb_step2_wide_kernel" if (npad <= 32768 and forced != "3") else "npb_step2_kernel"
+
+
+def past_the_knee(n, device, storage, bytes_per_plant, K=40):
+    import ctypes
+    import torch
+    from nuclear_sim_amd import _lib
+    from nuclear_sim_amd.env import BatchedPlantEnv
+    env = BatchedPlantEnv(n, dt=1.0, heat_source="constant", noise_enabled=True, noise_std_percent=0.1, device=device, storage=storage)
+    dev = env.device
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    z = torch.randn((8, n), device=dev, dtype=torch.float64, generator=gen)
+    sp = torch.full((n,), 92.0, device=dev, dtype=torch.float64)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    for t in range(K + 5):
+        if t >= 5:
+            ev[t - 5][0].record()
+        _lib.check(env.L.npb_step(env._h, None, None, ctypes.c_void_p(sp.data_ptr()), ctypes.c_void_p(z[t % 8].data_ptr()), None, env._p(env._obs),
+                                  env._p(env._reward), env._p(env._done), env._p(env._flags), env._p(env._info), stream), env._h)
+        if t >= 5:
+            ev[t - 5][1].record()
+    torch.cuda.synchronize(dev)
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    achieved = bytes_per_plant * n / (ms * 1e-3) / 1e9
+    return {"plants": n, "kernel": step_kernel_name(n), "kernel_ms": ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,12 +300,16 @@ def main():
                                             "(measured writes 212 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "
                                             "of the reads is served by the 256 MB Infinity Cache; NULL inputs (20 B/plant) are "
                                             "already excluded",
-                         "kernel": "npb_step_kernel" + (" + npb_maint_kernel" if args.maintenance else ""), "kernel_ms": kernel_ms},
+                         "kernel": step_kernel_name(n) + (" + npb_maint_screen_kernel + npb_maint_kernel" if args.maintenance else ""),
+                         "kernel_ms": kernel_ms},
             "selfcheck": {"steps": K_long, "seconds": long_elapsed, "value": n * K_long / long_elapsed, "ms_per_step": long_elapsed / K_long * 1e3,
                           "what": "rank 0's own rate over a longer run of the same loop (inputs cycled); not the headline"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            # the same kernel with the working set well past the 256 MB Infinity Cache (twice the plants): what the fraction is
+            # when nothing of the state survives in the memory-side cache between two steps
+            out["roofline"]["past_the_cache_knee"] = past_the_knee(2 * n, local_rank, args.storage, bytes_per_plant)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
