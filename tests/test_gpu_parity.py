@@ -521,6 +521,47 @@ def test_full_size_properties():
     np.testing.assert_allclose(o1[:, 14], sf / 1665, rtol=2e-7, atol=0)   # an output member: kept as float in the arena
 
 
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_full_size_against_the_oracle_on_a_sample(oracle_lib, storage):
+    """BASELINE config 3 (and, with fp32 state storage, config 5's size) at its full size -- 65 536 plants, the bench's workload (per-plant load-following setpoints, per-plant
+    noise), the kernel and the arena placement the bench runs with -- against the CPU oracle on 192 of the plants spread over
+    the whole batch (first, last, and the wave boundaries included): plants are independent, so the oracle steps just
+    those with their own inputs.  Every state member, observation, reward and flag of the sampled plants.  (fp32 storage: against
+    the oracle with its state rounded to float after every step, the same algorithm.)"""
+    import torch
+    n, T = 65536, 60
+    rng = np.random.default_rng(2024)
+    sample = np.unique(np.concatenate([[0, 1, 63, 64, 65, 127, n - 65, n - 64, n - 1], rng.choice(n, 183, replace=False)]))
+    env = _env(n=n, noise_enabled=True, storage=storage)
+    narrow = storage == "f32"
+    tol = F32_EMU_RTOL if narrow else RTOL
+    P = oracle_lib.Params(); P.hs_noise_enabled = 1
+    ora = oracle_lib.OraclePlants(len(sample), P)
+    gid = np.arange(n); period = 600.0 + 60.0 * (gid % 16)
+    for k in range(4):      # heterogeneous pumps, as everywhere else
+        lv = rng.uniform(30.0, 100.0, n)
+        env.set_field("pump.oil_level", lv, instance=k); ora.set("pump.oil_level", lv[sample], instance=k)
+    if narrow:
+        ora.round_state_f32()
+    for t in range(T):
+        sp = 90.0 + 10.0 * np.sin(2.0 * np.pi * t / period)
+        z = rng.standard_normal(n)
+        obs, rew, done, info = env.step(power_setpoint=sp, noise_z=z)
+        o_obs, o_rew, o_done, o_flags, _ = ora.step(setpoint=sp[sample], noise_z=z[sample])
+        if narrow:
+            ora.round_state_f32()
+        idx = torch.as_tensor(sample, device=env.device)
+        np.testing.assert_allclose(obs[idx].cpu().numpy(), o_obs, rtol=tol, atol=1e-12)
+        np.testing.assert_allclose(rew[idx].cpu().numpy(), o_rew, rtol=tol, atol=1e-6 if narrow else 1e-9)
+        assert np.array_equal(done[idx].cpu().numpy(), o_done)
+        assert np.array_equal(info["trip_flags"][idx].cpu().numpy().astype(np.uint32), o_flags)
+    f, i = env.state_arrays()
+    f = f[:, idx].cpu().numpy(); i = i[:, idx].cpu().numpy()
+    of, oi = ora.state_all()        # [sampled plants, members]
+    assert np.array_equal(i, oi.T)
+    np.testing.assert_allclose(f, of.T, rtol=tol, atol=1e-9 if narrow else ATOL_SMALL)
+
+
 # ---------------------------------------------------------------------------------------------------
 # fp32 state storage (BASELINE config 5): fp64 arithmetic, columns kept as float in HBM
 F32_EMU_RTOL = 2e-5     # against the oracle with its state rounded to float every step (same algorithm)
