@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPB_VERSION 130 /* 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
+#define NPB_VERSION 131 /* 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
 #ifndef NPB_API
 #define NPB_API __attribute__((visibility("default")))
 #endif

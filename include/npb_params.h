@@ -67,6 +67,10 @@ typedef struct npb_params_t {
   int mode;                /* NPB_MODE_FULL | NPB_MODE_PRIMARY_SG | NPB_MODE_PRIMARY */
   int maint_enabled;       /* 1: run the automatic maintenance of the feedwater pumps after every step (maint.*, mpump.* columns) */
   int info_reactivity_components; /* 1: under NPB_HEAT_REACTOR the step also writes info["reactivity_components"] (npb.h NPB_RHO_*) */
+  int kinetics_rk4_substeps;      /* 0: the reference's clipped explicit-Euler point kinetics (the parity path).  n > 0: the
+                                   * point-kinetics equations themselves (flux + six precursor groups, no rate clips) advanced by n
+                                   * classical RK4 sub-steps per dt inside the step kernel -- BASELINE config 2's "rk4" mode; the
+                                   * reference has no such integrator, so this mode is self-consistency-tested only */
 } npb_params_t;
 
 enum { NPB_HEAT_CONSTANT = 0, NPB_HEAT_REACTOR = 1 };
@@ -83,6 +87,7 @@ static inline void npb_params_default(npb_params_t *p) {
   p->mode = NPB_MODE_FULL;
   p->maint_enabled = 0;
   p->info_reactivity_components = 0;
+  p->kinetics_rk4_substeps = 0;
 }
 
 #endif /* NPB_PARAMS_H */

@@ -30,7 +30,7 @@ class NpbError(RuntimeError):
 def _make_params_struct():
     fields = [(name, ctypes.c_double) for name, _d, _p in PARAMS]
     fields += [("dt", ctypes.c_double), ("heat_source", ctypes.c_int), ("hs_noise_enabled", ctypes.c_int),
-               ("mode", ctypes.c_int), ("maint_enabled", ctypes.c_int), ("info_reactivity_components", ctypes.c_int)]
+               ("mode", ctypes.c_int), ("maint_enabled", ctypes.c_int), ("info_reactivity_components", ctypes.c_int), ("kinetics_rk4_substeps", ctypes.c_int)]
     return type("NpbParams", (ctypes.Structure,), {"_fields_": fields})
 
 

@@ -87,6 +87,38 @@ NPD_FN void npd_reactor_heat_source(npb_prim_t *s, const npb_params_t *P, double
   if (s->scram_status) reactivity = -0.5;
   /* solve_point_kinetics */
   double rho = npd_clip(reactivity, -0.9, 0.1);
+  if (P->kinetics_rk4_substeps > 0) {
+    /* BASELINE config 2's "rk4" mode (no reference counterpart): dn/dt = (rho - beta) / Lambda * n + sum lambda_i C_i,
+     * dC_i/dt = beta_i / Lambda * n - lambda_i C_i, classical RK4, kinetics_rk4_substeps sub-steps per dt, reactivity held over
+     * the step as the reference holds it; no rate clips, the flux kept inside the reference's physical band at the end */
+    const int ns = P->kinetics_rk4_substeps;
+    const double h = dt / ns, a = (rho - BETA) / LAMBDA_PROMPT, b = (BETA / 6) / LAMBDA_PROMPT;
+    double n = s->neutron_flux, C[6];
+    for (int i = 0; i < 6; i++) C[i] = s->precursors[i];
+    for (int it = 0; it < ns; it++) {
+      double kn[4], kc[4][6], yn = n, yc[6];
+      for (int i = 0; i < 6; i++) yc[i] = C[i];
+      for (int st = 0; st < 4; st++) {
+        double src = 0.0;
+        for (int i = 0; i < 6; i++) src += LAMBDA[i] * yc[i];
+        kn[st] = a * yn + src;
+        for (int i = 0; i < 6; i++) kc[st][i] = b * yn - LAMBDA[i] * yc[i];
+        const double w = (st == 2) ? h : 0.5 * h;
+        if (st < 3) { yn = n + w * kn[st]; for (int i = 0; i < 6; i++) yc[i] = C[i] + w * kc[st][i]; }
+      }
+      n += h / 6.0 * (kn[0] + 2.0 * kn[1] + 2.0 * kn[2] + kn[3]);
+      for (int i = 0; i < 6; i++) C[i] += h / 6.0 * (kc[0][i] + 2.0 * kc[1][i] + 2.0 * kc[2][i] + kc[3][i]);
+    }
+    s->neutron_flux = npd_clip(n, 1e8, 1e14);
+    for (int i = 0; i < 6; i++) s->precursors[i] = npd_pymax(C[i], 0.0);
+    double pp_rk = s->neutron_flux / 1e13;
+    *thermal_power_mw = pp_rk * P->rated_power_mw;
+    *power_percent = pp_rk * 100.0;
+    s->power_level = *power_percent;
+    s->reactivity = reactivity;
+    *total_pcm = total;
+    return;
+  }
   double flux_dot = 0.0, prec_dot[6] = {0, 0, 0, 0, 0, 0};
   if (!(fabs(rho) < 0.01)) {
     double eff = rho; /* second <0.01 branch (:47-50) is unreachable */

@@ -115,7 +115,8 @@ class BatchedPlantEnv:
     def __init__(self, n_envs: int, dt: float = 1.0, heat_source: str = "constant", noise_enabled: bool = False,
                  noise_std_percent: float = 0.1, noise_seeds: Optional[Sequence[int]] = None,
                  mode: str = "full", device: int = 0, params: Optional[dict] = None, maintenance: bool = False,
-                 storage: str = "f64", maintenance_thresholds: Optional[dict] = None, reactivity_components: bool = False):
+                 storage: str = "f64", maintenance_thresholds: Optional[dict] = None, reactivity_components: bool = False,
+                 integrator: str = "reference"):
         if not torch.cuda.is_available():
             raise _lib.NpbError("BatchedPlantEnv needs a HIP device (torch.cuda.is_available() is False); "
                                 "there is no CPU fallback")
@@ -132,6 +133,10 @@ class BatchedPlantEnv:
         self.mode = mode
         # info["reactivity_components"] (sim.py:205) exists under the reactor heat source only; asked for, the step writes the
         # ten terms behind the info columns (include/npb.h NPB_RHO_*)
+        # integrator="rk4" (BASELINE config 2; reactor heat source): the point-kinetics equations by classical RK4 sub-steps inside
+        # the step kernel instead of the reference's clipped explicit Euler -- no reference counterpart.  Explicit RK4 is stable on
+        # the prompt mode for a sub-step below 2.78 * Lambda / beta = 4.3 ms; 2 ms is taken.
+        p.kinetics_rk4_substeps = {"reference": 0, "rk4": max(1, int(np.ceil(float(dt) / 0.002)))}[integrator]
         self._with_rho = bool(reactivity_components) and heat_source == "reactor"
         p.info_reactivity_components = int(self._with_rho)
         # automatic oil_top_off maintenance after every step, as the data-gen runner's simulator has it

@@ -54,7 +54,7 @@ class Params:
         self._buf = np.zeros(L.npo_params_size(), dtype=np.uint8)
         L.npo_params_default(_ptr(self._buf))
         nd = len(self._names)
-        assert self._buf.size == (nd * 8 + 8 + 5 * 4 + 7) // 8 * 8, (self._buf.size, nd)
+        assert self._buf.size == (nd * 8 + 8 + 6 * 4 + 7) // 8 * 8, (self._buf.size, nd)
 
     def _dview(self):
         return self._buf[: (len(self._names) + 1) * 8].view(np.float64)
@@ -69,7 +69,7 @@ class Params:
             return float(self._dview()[self._names.index(k)])
         if k == "dt":
             return float(self._dview()[len(self._names)])
-        ints = ["heat_source", "hs_noise_enabled", "mode", "maint_enabled", "info_reactivity_components"]
+        ints = ["heat_source", "hs_noise_enabled", "mode", "maint_enabled", "info_reactivity_components", "kinetics_rk4_substeps"]
         if k in ints:
             return int(self._iview()[ints.index(k)])
         raise AttributeError(k)
@@ -81,8 +81,8 @@ class Params:
             self._dview()[self._names.index(k)] = v
         elif k == "dt":
             self._dview()[len(self._names)] = v
-        elif k in ("heat_source", "hs_noise_enabled", "mode", "maint_enabled", "info_reactivity_components"):
-            self._iview()[["heat_source", "hs_noise_enabled", "mode", "maint_enabled", "info_reactivity_components"].index(k)] = v
+        elif k in ("heat_source", "hs_noise_enabled", "mode", "maint_enabled", "info_reactivity_components", "kinetics_rk4_substeps"):
+            self._iview()[["heat_source", "hs_noise_enabled", "mode", "maint_enabled", "info_reactivity_components", "kinetics_rk4_substeps"].index(k)] = v
         else:
             raise AttributeError(k)
 

@@ -179,14 +179,20 @@ def test_ragged_batch_sizes(oracle_lib, n):
     assert bool((guard_obs[n:] == -7.0).all()), "rows beyond n_plants were written"
 
 
-def test_config2_reactor_and_sg_only_at_4096(oracle_lib):
+@pytest.mark.parametrize("integrator", ["reference", "rk4"])
+def test_config2_reactor_and_sg_only_at_4096(oracle_lib, integrator):
     """BASELINE config 2 shape: 4096 plants, point-kinetics heat source + steam generators only, dt = 0.1, random
-    actuator actions (the reference integrates with clipped Euler; there is no RK4 to compare with)."""
+    actuator actions, in both of its integrator modes: the reference's clipped explicit Euler (the parity path) and "rk4" --
+    the point-kinetics equations advanced by RK4 sub-steps inside the step kernel, which the reference does not have
+    (tests/test_rk4_cpu.py checks that mode against the closed-form solution; here the kernel must do what the CPU
+    restatement does)."""
     n, T = 4096, 40
     rng = np.random.default_rng(4096)
-    env = _env(n=n, dt=0.1, heat_source="reactor", mode="primary_sg")
+    env = _env(n=n, dt=0.1, heat_source="reactor", mode="primary_sg", integrator=integrator)
     env.set_fields(__import__("nuclear_sim_amd.env", fromlist=["equilibrium_state"]).equilibrium_state())
     P = oracle_lib.Params(); P.dt = 0.1; P.heat_source = 1; P.mode = 1
+    P.kinetics_rk4_substeps = env.params.kinetics_rk4_substeps
+    assert (P.kinetics_rk4_substeps == 50) == (integrator == "rk4")
     ora = oracle_lib.OraclePlants(n, P)
     from nuclear_sim_amd.env import equilibrium_state
     for key, v in equilibrium_state().items():
