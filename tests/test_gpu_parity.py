@@ -752,6 +752,62 @@ def test_config5_transients(oracle_lib, storage):
     print("config 5 (%s storage): worst observation deviation %.2e, scrams %d of %d" % (storage, worst, int((first_done >= 0).sum()), n))
 
 
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_config5_transients_at_full_size(oracle_lib, storage):
+    """The same at BASELINE config 5's own size, 65 536 interleaved plants (every wave holds all four transient scripts),
+    300 steps (all three pokes inside), the oracle on 256 plants spread over the batch: observations to the mode's
+    tolerance, scram steps and the first step of every trip flag exact."""
+    import torch
+    from nuclear_sim_amd.env import equilibrium_state
+    n, T = 65536, 300
+    rng = np.random.default_rng(55)
+    sample = np.unique(np.concatenate([np.arange(8), [n - 4, n - 3, n - 2, n - 1], rng.choice(n, 244, replace=False)]))
+    m = len(sample)
+    env = _env(n=n, heat_source="reactor", storage=storage)
+    P = oracle_lib.Params(); P.heat_source = 1
+    ora = oracle_lib.OraclePlants(m, P)
+    env.set_fields(equilibrium_state())
+    for key, v in equilibrium_state().items():
+        name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
+        ora.set(name, v, instance=inst, k=k)
+    kind, acts = _config5_scripts(n, T)
+    ks = kind[sample]
+    assert all((ks == j).sum() >= 30 for j in range(4))
+    idx = torch.as_tensor(sample, device=env.device)
+    rtol = RTOL if storage == "f64" else F32_OBS_RTOL
+    first_done = np.full(m, -1); o_first_done = np.full(m, -1)
+    first_flag = {}; o_first_flag = {}
+
+    def poke(name, which, value):
+        v = np.where(kind == which, value, env.get_field(name).cpu().numpy())
+        ov = np.where(ks == which, value, np.array([ora.get(name, plant=q) for q in range(m)]))
+        env.set_field(name, v); ora.set(name, ov)
+    for t in range(T):
+        if t == 150:
+            poke("prim.fuel_temperature", 3, 1300.0)
+        if t == 200:
+            poke("pump.oil_level", 3, 9.0)
+        if t == 250:
+            poke("prim.neutron_flux", 2, 1.3e13)
+        o_obs, _r, o_done, o_flags, _i = ora.step(action=acts[t][sample])
+        obs, _rew, done, info = env.step(action=acts[t])
+        obs = obs[idx].cpu().numpy(); done = done[idx].cpu().numpy(); flags = info["trip_flags"][idx].cpu().numpy().astype(np.uint32)
+        np.testing.assert_allclose(obs, o_obs, rtol=rtol, atol=1e-7 if storage == "f32" else 1e-12, err_msg="obs step %d" % t)
+        first_done = np.where((first_done < 0) & (done != 0), t, first_done)
+        o_first_done = np.where((o_first_done < 0) & (o_done != 0), t, o_first_done)
+        for bit in range(12):
+            a = first_flag.setdefault(bit, np.full(m, -1)); b = o_first_flag.setdefault(bit, np.full(m, -1))
+            first_flag[bit] = np.where((a < 0) & (((flags >> bit) & 1) != 0), t, a)
+            o_first_flag[bit] = np.where((b < 0) & (((o_flags >> bit) & 1) != 0), t, b)
+    assert np.array_equal(first_done, o_first_done), "scram step indices"
+    for bit in range(12):
+        assert np.array_equal(first_flag[bit], o_first_flag[bit]), "first step of trip flag bit %d" % bit
+    assert (first_done[ks == 3] == 150).all() and (first_done[ks == 2] >= 250).all() and (first_done[ks < 2] < 0).all()
+    # and over the whole batch: every plant of script 3 scrammed, none of scripts 0 and 1
+    scram = (env.get_field("prim.scram_status").cpu().numpy() != 0)
+    assert scram[kind == 3].all() and scram[kind == 2].all() and not scram[kind < 2].any()
+
+
 def test_nan_state_propagates_like_the_reference(oracle_lib):
     """np.clip and Python's max / min pass a NaN first operand through; the device code clips with the hardware
     min / max (which drop NaN) plus a term that restores exactly that (npd_common.h).  Poke NaN into secondary-side
