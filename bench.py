@@ -173,11 +173,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    # rehearsal on a one-GPU box (tools/bench_rehearsal.sh): every rank on device NPB_BENCH_DEVICE, collectives over gloo
+    if os.environ.get("NPB_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["NPB_BENCH_DEVICE"])
+    backend = os.environ.get("NPB_BENCH_BACKEND", "nccl")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
 
     from nuclear_sim_amd.env import BatchedPlantEnv
