@@ -106,7 +106,8 @@ NPB_API int npb_num_plants(const NpbHandle *h);
 NPB_API int npb_set_params(NpbHandle *h, const npb_params_t *params);
 /* thresholds of the automatic maintenance of the feedwater pumps (include/npb_maint.h): what the reference reads from
  * the maintenance_system section of its configuration into StateManager.maintenance_thresholds.  A new handle carries
- * npb_maint_table_default() (the data-gen action-test configuration). */
+ * npb_maint_table_default() (the data-gen action-test configuration), whose oil_level row follows the two parameters of ABI
+ * version 1 (params.maint_oil_level_threshold / _cooldown_hours); a table set here is taken exactly as given. */
 NPB_API int npb_set_maintenance_table(NpbHandle *h, const npb_maint_table_t *table);
 NPB_API void npb_default_maintenance_table(npb_maint_table_t *table);
 

@@ -23,6 +23,7 @@ struct NpbHandle {
   unsigned *maint_flags; /* NPB_NUM_PUMPS words per wave of plants: the maintenance screen's verdict (behind the staging column) */
   int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel, 3 = its two-waves-per-SIMD build (npb_set_step_kernel) */
   npb_maint_table_t maint_table;   /* thresholds of the automatic maintenance (include/npb_maint.h) */
+  bool maint_table_custom;         /* set through npb_set_maintenance_table: the table is then taken as it is */
   int *plan_dev;       /* npb_gather_fields: {column, sub, kind} per requested field, and the request it was built for */
   std::vector<int> plan_key;
   std::string error;
@@ -173,6 +174,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   NpbHandle *h = new NpbHandle();
   if (params) h->params = *params; else npb_params_default(&h->params);
   npb_maint_table_default(&h->maint_table);
+  h->maint_table_custom = false;
   { const char *e = getenv("NPB_STEP_KERNEL"); h->step_kernel = e ? atoi(e) : 0; if (h->step_kernel < 0 || h->step_kernel > 3) h->step_kernel = 0; }
   h->n_plants = n_plants; h->device = device;
   h->pitch = ((size_t)n_plants + 63) / 64 * 64;
@@ -232,6 +234,7 @@ int npb_set_maintenance_table(NpbHandle *h, const npb_maint_table_t *table) {
       return fail(h, NPB_EINVAL, "npb_set_maintenance_table: action / comparison / priority / bearing code out of range");
   }
   h->maint_table = *table;
+  h->maint_table_custom = true;
   return NPB_OK;
 }
 void npb_default_maintenance_table(npb_maint_table_t *table) { if (table) npb_maint_table_default(table); }
@@ -341,9 +344,11 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
   (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, action, magnitude, power_setpoint,
                                                  noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, h->step_kernel, (hipStream_t)stream);
   if (h->params.maint_enabled) {
-    npb_maint_table_t table = h->maint_table;   /* the two oil_level params of ABI version 1 override their table row */
-    table.threshold[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_threshold;
-    table.cooldown_hours[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_cooldown_hours;
+    npb_maint_table_t table = h->maint_table;
+    if (!h->maint_table_custom) {   /* with the default table the two oil_level params of ABI version 1 still set their row */
+      table.threshold[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_threshold;
+      table.cooldown_hours[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_cooldown_hours;
+    }
     (narrow ? npb32_launch_maint : npb_launch_maint)(&h->params, &table, h->pitch, h->f64, h->maint_flags, (hipStream_t)stream);
   }
   hipError_t e = hipGetLastError();

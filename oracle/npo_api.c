@@ -33,6 +33,7 @@ NPO_API int npo_set_threads(int n) {
 NPO_API void npo_set_maint_table(const npb_maint_table_t *t) {
   if (t) npo_maint_table = *t; else npb_maint_table_default(&npo_maint_table);
   npo_maint_table_set = 1;
+  npo_maint_table_custom = t != 0;
 }
 NPO_API int npo_maint_table_size(void) { return (int)sizeof(npb_maint_table_t); }
 NPO_API void npo_default_maint_table(npb_maint_table_t *t) { npb_maint_table_default(t); }

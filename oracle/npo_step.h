@@ -16,6 +16,7 @@
 /* thresholds of the automatic maintenance: one table per process, set through npo_set_maint_table (npo_api.c) */
 static npb_maint_table_t npo_maint_table;
 static int npo_maint_table_set = 0;
+static int npo_maint_table_custom = 0;   /* a table given by the caller is taken as it is (as npb_set_maintenance_table) */
 
 /* get_observation  sim.py:290-333 */
 NPO_FN void npo_observation(const npo_plant_t *pl, int mode, double *obs) {
@@ -136,9 +137,11 @@ NPO_FN void npo_step(npo_plant_t *pl, const npb_params_t *P, const npo_inputs_t 
   /* maintenance_system.update + state_manager.collect_states  sim.py:208-223; nothing they touch
    * feeds the observation, reward or info built above */
   if (P->maint_enabled) {
-    npb_maint_table_t table = npo_maint_table;   /* as npb_step: the two oil_level params override their table row */
-    table.threshold[NPB_MP_OIL_LEVEL] = P->maint_oil_level_threshold;
-    table.cooldown_hours[NPB_MP_OIL_LEVEL] = P->maint_oil_level_cooldown_hours;
+    npb_maint_table_t table = npo_maint_table;   /* as npb_step: with the default table the two oil_level params set their row */
+    if (!npo_maint_table_custom) {
+      table.threshold[NPB_MP_OIL_LEVEL] = P->maint_oil_level_threshold;
+      table.cooldown_hours[NPB_MP_OIL_LEVEL] = P->maint_oil_level_cooldown_hours;
+    }
     npo_maintenance_update(pl, P, &table);
   }
 }

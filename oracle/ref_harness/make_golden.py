@@ -202,11 +202,12 @@ FUZZ_SKIP = ("prim.sim_time", "sec.cooling_water_temperature", "sec.load_demand"
 FUZZ_SKIP_PREFIX = ("tstg.stage_blade_wear_factor", "tstg.stage_deposit_thickness")
 
 
-def fuzz_scenarios(seeds=tuple(range(1, 21)) + tuple(int(x) for x in os.environ.get("NPB_FUZZ_EXTRA", "").split())):
+def fuzz_scenarios(seeds=tuple(range(1, 27)) + tuple(int(x) for x in os.environ.get("NPB_FUZZ_EXTRA", "").split())):
     """Z1-Z8: fuzzed states.  The scenario fixtures visit what plant scenarios visit; these start the reference from states no
     scenario would reach -- every assignable real-valued state member of a freshly constructed simulator scaled by an
     independent factor in [0.8, 1.25] with probability 0.6 (seeds 1-4, from the default construction state, whose turbine trips on thermal
-    expansion at the first step; seeds 5-8 jitter the data-gen runner's plant, which makes power, by [0.97, 1.03], seeds 9-12 by [0.85, 1.18]; seeds 13-16 also flip flags and redraw pump states; seeds 17-20 jitter the default plant and call reset() at once) (levels above 100 %, pressures past their limits, wear past its
+    expansion at the first step; seeds 5-8 jitter the data-gen runner's plant, which makes power, by [0.97, 1.03], seeds 9-12 by [0.85, 1.18]; seeds 13-16 also flip flags and redraw pump states; seeds 17-20 jitter the default plant and call reset() at once; seeds 21-26 move every maintenance threshold next to the plant's
+    present values) (levels above 100 %, pressures past their limits, wear past its
     trip thresholds, deposits, temperatures, integrators, timers that were running) -- and run it for 16 steps under random
     operator actions and load changes.  A restatement error in a branch only such a state takes shows up here.  Seeds for
     which the reference itself raises are dropped."""
@@ -214,7 +215,7 @@ def fuzz_scenarios(seeds=tuple(range(1, 21)) + tuple(int(x) for x in os.environ.
     cols = SCHEMA.columns()
     out = []
     for seed in seeds:
-        running = 4 < seed <= 16    # seeds 5-8: the data-gen runner's plant (proper initial conditions: it makes power), mild jitter
+        running = 4 < seed <= 16 or seed > 20    # seeds 5-8: the data-gen runner's plant (proper initial conditions: it makes power), mild jitter
         heat = "constant" if running else ("reactor" if seed % 2 == 0 else "constant")
         if running:
             _runner, sim = refsim.make_runner_sim(action="oil_top_off", duration_hours=2.0)
@@ -236,7 +237,7 @@ def fuzz_scenarios(seeds=tuple(range(1, 21)) + tuple(int(x) for x in os.environ.
                 continue
             if running and label.startswith(("turb.", "tstg.")) and ("temperature" in label or "expansion" in label):
                 continue                     # a few degrees more metal temperature trip the turbine at once (thermal expansion)
-            lo, hi = ((0.97, 1.03) if (seed <= 8 or seed > 12) else (0.85, 1.18)) if running else (0.8, 1.25)
+            lo, hi = ((0.97, 1.03) if (seed <= 8 or 12 < seed <= 16) else (0.85, 1.18)) if running else (0.8, 1.25)
             pokes.append((path, float(v * rng.uniform(lo, hi))))
         if seed > 12:       # seeds 13-16: the flags and state machines as well -- every boolean member flipped with probability 0.2, pump states redrawn with 0.3
             for kind, _slot, label, path in cols:
@@ -253,11 +254,33 @@ def fuzz_scenarios(seeds=tuple(range(1, 21)) + tuple(int(x) for x in os.environ.
                   noise_seed=42 if running else 100 + seed, every=1,
                   pokes={(1 if running else 0): pokes},   # the runner's plant takes its initial conditions at the first step
                   actions=(lambda t, a=acts, m=mags: (int(a[t]), float(m[t]))))
-        if seed > 16:       # seeds 17-20: reset() right after the jitter -- which members survive a reset, on values no run would leave behind
+        if 16 < seed <= 20: # seeds 17-20: reset() right after the jitter -- which members survive a reset, on values no run would leave behind
             sc["pokes"] = {2: pokes}; sc["resets"] = {2: seed % 2 == 1}
             sc["name"] = "z%d_fuzzed_state_then_reset_%s" % (seed, heat)
+        if seed > 20:       # seeds 21-26: the maintenance control plane under fire -- every threshold of the feedwater pumps moved to within
+            # 3 % of where pump 1 is now (so about half are violated at once and the rest come and go), cooldowns of 15-60 min, on a
+            # plant jittered by 15 %: violations in every combination, the orchestrator's promotions, the work-order queue across
+            # pumps, the handlers -- 48 steps (4 h); every maint.* / mpump.* column is compared
+            from systems.secondary.feedwater import pump_system as _ps  # noqa: F401  (the runner's plant is already built)
+            M = {"oil_level": "oil_level", "oil_contamination_level": "oil_contamination", "lubrication_effectiveness": "lubrication_effectiveness",
+                 "impeller_wear": "wear_impeller", "cavitation_damage": "cavitation_damage", "cavitation_intensity": "cavitation_intensity",
+                 "npsh_available": "npsh_available", "motor_bearing_wear": "wear_motor_bearings", "pump_bearing_wear": "wear_pump_bearings",
+                 "thrust_bearing_wear": "wear_thrust_bearing", "seal_wear": "wear_mechanical_seals", "vibration_level": "vibration_level",
+                 "oil_temperature": "oil_temperature", "motor_temperature": "motor_temperature", "seal_leakage_rate": "seal_leakage_rate"}
+            path_of = {c[2]: c[3] for c in cols}
+            override = []
+            for name, member in M.items():
+                v = tr._val(sim, path_of["pump[0].%s" % member])
+                if not np.isfinite(v) or v == 0.0:
+                    continue
+                override.append((name, {"threshold": float(v * rng.uniform(0.97, 1.03)), "cooldown_hours": float(rng.choice([0.25, 0.5, 1.0]))}))
+            sc["thresholds_override"] = override
+            sc["steps"] = 48
+            acts = rng.choice([8, 8, 8, 0, 1], size=48); mags = rng.uniform(0, 1, size=48)
+            sc["actions"] = (lambda t, a=acts, m=mags: (int(a[t]), float(m[t])))
+            sc["name"] = "z%d_fuzzed_maintenance" % seed
         if running:
-            sc.update(dt=5.0, runner=dict(action="oil_top_off", duration_hours=2.0))
+            sc.update(dt=5.0, runner=dict(action="oil_top_off", duration_hours=4.0 if seed > 20 else 2.0))
         else:
             sc["setpoints"] = (lambda t, sp=sp: sp if t == 2 else None) if heat == "constant" else None
         if heat == "reactor":
