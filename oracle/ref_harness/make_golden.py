@@ -202,7 +202,7 @@ FUZZ_SKIP = ("prim.sim_time", "sec.cooling_water_temperature", "sec.load_demand"
 FUZZ_SKIP_PREFIX = ("tstg.stage_blade_wear_factor", "tstg.stage_deposit_thickness")
 
 
-def fuzz_scenarios(seeds=tuple(range(1, 27)) + tuple(int(x) for x in os.environ.get("NPB_FUZZ_EXTRA", "").split())):
+def fuzz_scenarios(seeds=tuple(range(1, 29)) + tuple(int(x) for x in os.environ.get("NPB_FUZZ_EXTRA", "").split())):
     """Z1-Z8: fuzzed states.  The scenario fixtures visit what plant scenarios visit; these start the reference from states no
     scenario would reach -- every assignable real-valued state member of a freshly constructed simulator scaled by an
     independent factor in [0.8, 1.25] with probability 0.6 (seeds 1-4, from the default construction state, whose turbine trips on thermal
@@ -215,7 +215,7 @@ def fuzz_scenarios(seeds=tuple(range(1, 27)) + tuple(int(x) for x in os.environ.
     cols = SCHEMA.columns()
     out = []
     for seed in seeds:
-        running = 4 < seed <= 16 or seed > 20    # seeds 5-8: the data-gen runner's plant (proper initial conditions: it makes power), mild jitter
+        running = 4 < seed <= 16 or seed > 20    # seeds 27, 28: as 9-12 but 80 steps under load changes; seeds 5-8: the data-gen runner's plant (proper initial conditions: it makes power), mild jitter
         heat = "constant" if running else ("reactor" if seed % 2 == 0 else "constant")
         if running:
             _runner, sim = refsim.make_runner_sim(action="oil_top_off", duration_hours=2.0)
@@ -257,7 +257,13 @@ def fuzz_scenarios(seeds=tuple(range(1, 27)) + tuple(int(x) for x in os.environ.
         if 16 < seed <= 20: # seeds 17-20: reset() right after the jitter -- which members survive a reset, on values no run would leave behind
             sc["pokes"] = {2: pokes}; sc["resets"] = {2: seed % 2 == 1}
             sc["name"] = "z%d_fuzzed_state_then_reset_%s" % (seed, heat)
-        if seed > 20:       # seeds 21-26: the maintenance control plane under fire -- every threshold of the feedwater pumps moved to within
+        if seed > 26:
+            sc["steps"] = 80; sc["every"] = 2
+            acts = rng.choice([0, 1, 2, 3, 8, 9, 10, 4, 5, 8, 8], size=80); mags = rng.uniform(0, 1, size=80)
+            sc["actions"] = (lambda t, a=acts, m=mags: (int(a[t]), float(m[t])))
+            sc["setpoints"] = (lambda t, r=rng.uniform(60, 100, size=80): float(r[t]) if t % 10 == 5 else None)
+            sc["name"] = "z%d_fuzzed_state_running_long" % seed
+        if 20 < seed <= 26:       # seeds 21-26: the maintenance control plane under fire -- every threshold of the feedwater pumps moved to within
             # 3 % of where pump 1 is now (so about half are violated at once and the rest come and go), cooldowns of 15-60 min, on a
             # plant jittered by 15 %: violations in every combination, the orchestrator's promotions, the work-order queue across
             # pumps, the handlers -- 48 steps (4 h); every maint.* / mpump.* column is compared
@@ -280,7 +286,7 @@ def fuzz_scenarios(seeds=tuple(range(1, 27)) + tuple(int(x) for x in os.environ.
             sc["actions"] = (lambda t, a=acts, m=mags: (int(a[t]), float(m[t])))
             sc["name"] = "z%d_fuzzed_maintenance" % seed
         if running:
-            sc.update(dt=5.0, runner=dict(action="oil_top_off", duration_hours=4.0 if seed > 20 else 2.0))
+            sc.update(dt=5.0, runner=dict(action="oil_top_off", duration_hours=7.0 if seed > 26 else 4.0 if seed > 20 else 2.0))
         else:
             sc["setpoints"] = (lambda t, sp=sp: sp if t == 2 else None) if heat == "constant" else None
         if heat == "reactor":
