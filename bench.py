@@ -304,7 +304,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_plant * n,
                          "bytes_not_moved": "the algorithmic figure counts every carried column as read + written; the kernel "
                                             "skips the store of a column whose bits did not change for any plant of a wave "
-                                            "(measured writes 212 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "
+                                            "(measured writes ~200 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "
                                             "of the reads is served by the 256 MB Infinity Cache; NULL inputs (20 B/plant) are "
                                             "already excluded",
                          "kernel": step_kernel_name(n) + (" + npb_maint_screen_kernel + npb_maint_kernel" if args.maintenance else ""),
