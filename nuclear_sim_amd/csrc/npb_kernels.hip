@@ -902,8 +902,9 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_screen_kernel(npd_maint_sc
   for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
     const double v = values[q], thr = S.threshold[q];
     const bool near_eq = fabs(v - thr) < 0.001;                                  /* _check_threshold_condition */
-    const bool hit = (((S.want_gt >> q) & 1u) != 0) & (v > thr) | (((S.want_lt >> q) & 1u) != 0) & (v < thr) | (((S.want_eq >> q) & 1u) != 0) & (v == thr) |
-                     (((S.want_near >> q) & 1u) != 0) & near_eq | (((S.want_far >> q) & 1u) != 0) & !near_eq;
+    const bool hit = ((((S.want_gt >> q) & 1u) != 0) & (v > thr)) | ((((S.want_lt >> q) & 1u) != 0) & (v < thr)) |
+                     ((((S.want_eq >> q) & 1u) != 0) & (v == thr)) | ((((S.want_near >> q) & 1u) != 0) & near_eq) |
+                     ((((S.want_far >> q) & 1u) != 0) & !near_eq);
     hits |= (uint32_t)hit << q;
   }
   if (__any(hits != 0)) {
