@@ -25,14 +25,14 @@
 extern "C" {
 #endif
 
-#define NPB_VERSION 131 /* 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
+#define NPB_VERSION 132 /* 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
 #ifndef NPB_API
 #define NPB_API __attribute__((visibility("default")))
 #endif
 
 enum { NPB_OK = 0, NPB_EINVAL = -1, NPB_EHIP = -2, NPB_ENOMEM = -3 };
 enum { NPB_KIND_F64 = 0, NPB_KIND_I32 = 1 };
-enum { NPB_OBS_DIM = 22, NPB_INFO_DIM = 14 };
+enum { NPB_OBS_DIM = 22, NPB_INFO_DIM = 17 };
 
 /* info columns written by npb_step (the scalar keys of step()'s info dict, sim.py:199-250) */
 enum {
@@ -42,7 +42,11 @@ enum {
   /* fp64 inputs of the reference's heat-flow bookkeeping and of the derived keys of its secondary result dict
    * (secondary/__init__.py:679-744, 922-1010; nuclear_sim_amd/env.py secondary_result): total steam-generator heat transfer
    * [W], turbine gross electrical power [MW], feedwater pump power [MW], primary thermal power over the three loops [MW] */
-  NPB_INFO_SG_HEAT_TRANSFER, NPB_INFO_TURBINE_POWER, NPB_INFO_FEEDWATER_POWER, NPB_INFO_PRIMARY_THERMAL_POWER
+  NPB_INFO_SG_HEAT_TRANSFER, NPB_INFO_TURBINE_POWER, NPB_INFO_FEEDWATER_POWER, NPB_INFO_PRIMARY_THERMAL_POWER,
+  /* the three keys of that dict that are left over from inside the turbine step (secondary/__init__.py:955-958): the stage
+   * system's cycle efficiency (h_in - h_out) / h_in (stage_system.py:983-993) and the summed outputs of the HP-1..8 and
+   * LP-1..6 stages [MW] (enhanced_physics.py:879-880); 0 where the turbine is not stepped (NPB_MODE_PRIMARY_SG) */
+  NPB_INFO_TURBINE_EFFICIENCY, NPB_INFO_TURBINE_HP_POWER, NPB_INFO_TURBINE_LP_POWER
 };
 /* info["reactivity_components"] (sim.py:205; reactivity_model.py:77-125, pcm, the dict's insertion order).  Only the
  * reactor heat source has them, and only a caller that sets params.info_reactivity_components gets them: the info
@@ -73,7 +77,7 @@ NPB_API size_t npb_state_bytes(void);
 /* algorithmic HBM bytes of one plant-step: carried fp64 members read and written (16 B), int32 members read and
  * written (8 B), output members written as float (4 B) -- all but the maint.* section, which only the
  * maintenance kernel touches -- + per-step inputs (action 4 + magnitude/setpoint/noise/cooling 4*8) + outputs
- * (obs 22*8 + reward 8 + done 1 + trip_flags 4 + info 14*8) */
+ * (obs 22*8 + reward 8 + done 1 + trip_flags 4 + info 17*8) */
 NPB_API size_t npb_step_bytes_per_plant(void);
 /* the same for one handle: with fp32 storage every carried real moves 4 bytes instead of 8, and under
  * ConstantHeatSource the 12 point-kinetics columns of the primary section are not touched at all */

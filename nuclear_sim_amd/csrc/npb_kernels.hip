@@ -598,6 +598,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
 
   double electrical_power = 0.0, thermal_efficiency = 0.0, condenser_pressure = 0.007;
   double total_system_heat_rejection = 0.0, turbine_gross_power = 0.0;
+  double turbine_efficiency = 0.0, turbine_hp_power = 0.0, turbine_lp_power = 0.0;
   if (full) {
     NPD_STAMP(11);
     /* ================= phase 3: turbine (dt in hours, load demand in PERCENT, :564-569) ========== */
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     /* ================= electrical-power gates (:750-932) ================= */
     double turbine_electrical_power = tr.electrical_power_net;
     turbine_gross_power = tr.electrical_power_gross;
+    turbine_efficiency = tr.overall_efficiency; turbine_hp_power = tr.hp_power; turbine_lp_power = tr.lp_power;
     total_system_heat_rejection = (primary_thermal_power - turbine_electrical_power) * 1e6;
     double power_reduction_factor = 1.0;
     if (fw_total_flow < 300.0) power_reduction_factor = 0.0;
@@ -734,6 +736,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_kernel(
     info[NPB_INFO_FEEDWATER_FLOW] = fw_total_flow;
     info[NPB_INFO_SG_HEAT_TRANSFER] = sg_total_thermal; info[NPB_INFO_TURBINE_POWER] = turbine_gross_power;
     info[NPB_INFO_FEEDWATER_POWER] = fw_total_power; info[NPB_INFO_PRIMARY_THERMAL_POWER] = primary_thermal_power;
+    info[NPB_INFO_TURBINE_EFFICIENCY] = turbine_efficiency;
+    info[NPB_INFO_TURBINE_HP_POWER] = turbine_hp_power; info[NPB_INFO_TURBINE_LP_POWER] = turbine_lp_power;
     npd_store_rows<NPB_INFO_DIM>(info, info_out, lds, block_base, (size_t)n_plants);
   }
   NPD_STAMP(22);

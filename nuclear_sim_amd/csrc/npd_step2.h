@@ -74,12 +74,12 @@ enum {
   X_SAT = 20, X_HG = 27, X_TRATIO = 34, X_HGEXT = 41, /* wave B's half of pass B: 7 + 7 + 7 + 5 */
   X_TOUT = 46, X_LOADING = 60,                        /* per stage, for the degradation / metal-temperature pass */
   X_MAXSTRESS = 74, X_EFFLOW = 75, X_LP6H = 76, X_CWT = 77, X_FLAG = 78,
-  /* tail scalars for reward / info (reuses X_PSELF ...) */
-  X_TAIL = 0,
+  /* tail scalars for reward / info (reuses X_PSELF ...; three more where the feedwater hand-over was) */
+  X_TAIL = 0, X_TAIL2 = 70,
   /* transposes */
   X_OBS = 22, X_INFO = 46
 };
-static_assert(X_PUMP + 4 * X_PUMP_N <= X_SGCARRY && X_SGCARRY + 6 <= X_FLAG2 && X_OBS + NPB_OBS_PAD <= X_INFO && X_INFO + NPB_OBS_PAD <= X_MAXSTRESS, "exchange slot plan");
+static_assert(X_PUMP + 4 * X_PUMP_N <= X_SGCARRY && X_SGCARRY + 6 <= X_FLAG2 && X_OBS + NPB_OBS_PAD <= X_INFO && X_INFO + NPB_OBS_PAD <= X_TAIL2 && X_TAIL2 + 3 <= X_MAXSTRESS, "exchange slot plan");
 
 /* [64][W] block held one row per lane -> row-major global memory through a transpose buffer of this wave's own */
 template <int W>
@@ -210,7 +210,7 @@ __device__ __forceinline__ bool npd2_stage_pass_a(double inlet_pressure, double 
 }
 
 /* one stage of the temperature / enthalpy chain (npd_stage_system_update, pass C) without its degradation / metal part */
-struct npd2_chain_t { double T_in, sat_in, hg_in, total_power, total_extraction, lp6_outlet_enthalpy; };
+struct npd2_chain_t { double T_in, sat_in, hg_in, total_power, total_extraction, lp6_outlet_enthalpy, hp_power, lp_power, h_in0; };
 __device__ __forceinline__ void npd2_chain_stage(int k, npd2_chain_t &c, double p_in, double p_self_k, double sat_k, double hg_k, double tratio_k,
                                                  double flow_out_k, double ef, double hg_ext_k, double total_efficiency,
                                                  double *T_out_o, double *loading_o) {
@@ -236,6 +236,8 @@ __device__ __forceinline__ void npd2_chain_stage(int k, npd2_chain_t &c, double 
   if (ef > 0) extraction_power = ef * (inlet_enthalpy - hg_ext_k) / 1000.0;
   *loading_o = actual_enthalpy_drop / npd_pymax(1.0, 0.88 * isentropic_enthalpy_drop);
   c.total_power += main_power + extraction_power; c.total_extraction += ef;
+  if (k < 8) c.hp_power += main_power + extraction_power; else c.lp_power += main_power + extraction_power;
+  if (k == 0) c.h_in0 = inlet_enthalpy;
   if (k == 13) c.lp6_outlet_enthalpy = outlet_enthalpy;
   *T_out_o = T_out;
   c.T_in = T_out; c.sat_in = sat_k; c.hg_in = hg_k;
@@ -250,6 +252,7 @@ __device__ __forceinline__ void npd2_seq_stage(int k, double &cur_p, double &cur
   npd_stage_out_t so;   /* the four efficiency factors enter the expansion only as their product (stage_system.py:209-212) */
   npd_stage_expansion(k, total_efficiency, 1.0, 1.0, 1.0, cur_p, cur_T, cur_flow, outlet_pressure, extraction_demand, &so);
   c.total_power += so.power_output; c.total_extraction += so.extraction_flow;
+  if (k < 8) c.hp_power += so.power_output; else c.lp_power += so.power_output;
   if (k == 13) c.lp6_outlet_enthalpy = so.outlet_enthalpy;
   *T_out_o = so.outlet_temperature; *loading_o = so.loading_factor;
   cur_p = so.outlet_pressure; cur_T = so.outlet_temperature; cur_flow = so.outlet_flow;
@@ -512,6 +515,8 @@ __device__ __forceinline__ void npd_step2_body(
     NPD2_SYNCJ(7);                                                                                     /* #5 */
     npd2_chain_t ch;
     ch.T_in = sg_avg_temperature; ch.total_power = 0.0; ch.total_extraction = 0.0; ch.lp6_outlet_enthalpy = 0.0;
+    ch.hp_power = 0.0; ch.lp_power = 0.0; ch.h_in0 = 0.0;
+    double turbine_efficiency = 0.0;   /* stage_system.py:983-993 (info only) */
     if (!seq) {
       /* pass B, stages 0 .. NPD2_SPLIT-1 and the inlet (wave B does the rest and the five extraction pressures) */
       double sat_a[NPD2_SPLIT], hg_a[NPD2_SPLIT], tr_a[NPD2_SPLIT];
@@ -537,6 +542,12 @@ __device__ __forceinline__ void npd_step2_body(
         XW(X_TOUT + k, T_out); XW(X_LOADING + k, loading);
         NPD2_FLAG_SET(k + 1);
       }
+      {   /* _steam_enthalpy at the last stage's outlet, whose saturation state pass B has */
+        const double T_c = npd_pymax(0.0, npd_pymin(ch.T_in, 800.0));
+        const double cp = (p_self[13] > 10.0) ? 2.5 : ((p_self[13] > 1.0) ? 2.2 : 2.0);
+        const double h_out = (T_c <= ch.sat_in) ? ch.hg_in : ch.hg_in + cp * (T_c - ch.sat_in);
+        if (sg_total_steam > 0) turbine_efficiency = (ch.h_in0 - h_out) / ch.h_in0;
+      }
     } else {
       NPD2_SYNCJ(8);                                                                                   /* #6 */
       double cur_p = sg_avg_pressure, cur_T = sg_avg_temperature, cur_flow = sg_total_steam;
@@ -546,6 +557,10 @@ __device__ __forceinline__ void npd_step2_body(
         npd2_seq_stage(k, cur_p, cur_T, cur_flow, sg_total_steam, load_demand, stage_eff[k], ch, &T_out, &loading);
         XW(X_TOUT + k, T_out); XW(X_LOADING + k, loading);
         NPD2_FLAG_SET(k + 1);
+      }
+      if (sg_total_steam > 0) {
+        const double h_in = npd_stage_steam_enthalpy(sg_avg_temperature, sg_avg_pressure);
+        turbine_efficiency = (h_in - npd_stage_steam_enthalpy(cur_T, cur_p)) / h_in;
       }
     }
     const double stage_power_mw = ch.total_power * pressure_stability_factor;
@@ -598,6 +613,7 @@ __device__ __forceinline__ void npd_step2_body(
     XW(X_TAIL + 11, sg_total_thermal); XW(X_TAIL + 12, sg_avg_temperature); XW(X_TAIL + 13, sg_avg_quality);
     XW(X_TAIL + 14, (double)(sg_system_availability | (fw_available << 1))); XW(X_TAIL + 15, prev_feedwater_temp); XW(X_TAIL + 16, cw_old);
     XW(X_TAIL + 17, operating_hours); XW(X_TAIL + 18, t.total_power_output); XW(X_TAIL + 19, fw_total_power); XW(X_TAIL + 20, primary_thermal_power);
+    XW(X_TAIL2 + 0, turbine_efficiency); XW(X_TAIL2 + 1, ch.hp_power); XW(X_TAIL2 + 2, ch.lp_power);
     NPD2_SYNCJ(11);                                                                                     /* #9 */
     /* ---- observation, done, trip flags: the primary part (sim.py:290-333) from the primary section as stored in phase 0
      * (carried members: the stored value is the value; power_level, an output member, was kept) */
@@ -832,6 +848,7 @@ __device__ __forceinline__ void npd_step2_body(
       info[NPB_INFO_FEEDWATER_FLOW] = fw_total_flow_t;
       info[NPB_INFO_SG_HEAT_TRANSFER] = XR(X_TAIL + 11); info[NPB_INFO_TURBINE_POWER] = XR(X_TAIL + 18);
       info[NPB_INFO_FEEDWATER_POWER] = XR(X_TAIL + 19); info[NPB_INFO_PRIMARY_THERMAL_POWER] = XR(X_TAIL + 20);
+      info[NPB_INFO_TURBINE_EFFICIENCY] = XR(X_TAIL2 + 0); info[NPB_INFO_TURBINE_HP_POWER] = XR(X_TAIL2 + 1); info[NPB_INFO_TURBINE_LP_POWER] = XR(X_TAIL2 + 2);
       npd2_store_rows<NPB_INFO_DIM>(info, info_out, xch + X_INFO * NPB_WAVE, lane, block_base, (size_t)n_plants);
     }
   }

@@ -165,6 +165,7 @@ NPD_FN double npd_stage_dynamic_pressure_ratio(int k, double current_pressure, d
 
 typedef struct npd_stagesys_out_t {
   double total_power, total_extraction, lp6_outlet_enthalpy;
+  double hp_power, lp_power, overall_efficiency;   /* enhanced_physics.py:879-880, stage_system.py:983-993 (info only) */
   double max_temp_rate, max_thermal_stress; /* MetalTemperatureTracker reductions */
 } npd_stagesys_out_t;
 
@@ -234,7 +235,7 @@ NPD_FN void npd_stage_system_update_seq(const npd_stage_t &st, const double *stg
                                         double inlet_temperature, double inlet_flow, double load_demand,
                                         double pressure_stability_factor, double dt, npd_stagesys_out_t *out) {
   double current_pressure = inlet_pressure, current_temperature = inlet_temperature, current_flow = inlet_flow;
-  double total_power = 0.0, total_extraction = 0.0;
+  double total_power = 0.0, total_extraction = 0.0, hp_power = 0.0, lp_power = 0.0;
   NPD_DMA_WAIT(); /* the staged stage arrays are read from here on */
 #pragma unroll 1
   for (int k = 0; k < 14; k++) {
@@ -249,12 +250,19 @@ NPD_FN void npd_stage_system_update_seq(const npd_stage_t &st, const double *stg
     npd_stage_expansion(k, actual_efficiency, blade_condition_factor, fouling_factor, blade_wear_factor, current_pressure,
                         current_temperature, current_flow, outlet_pressure, extraction_demand, &so);
     total_power += so.power_output; total_extraction += so.extraction_flow;
+    if (k < 8) hp_power += so.power_output; else lp_power += so.power_output;
     if (k == 13) out->lp6_outlet_enthalpy = so.outlet_enthalpy;
     npd_stage_post(st, stg, k, so.loading_factor, so.outlet_temperature, dt, out);
     current_pressure = so.outlet_pressure; current_temperature = so.outlet_temperature; current_flow = so.outlet_flow;
   }
   out->total_power = total_power * pressure_stability_factor;
   out->total_extraction = total_extraction;
+  out->hp_power = hp_power; out->lp_power = lp_power;
+  out->overall_efficiency = 0.0;
+  if (inlet_flow > 0) {
+    const double h_in = npd_stage_steam_enthalpy(inlet_temperature, inlet_pressure);
+    out->overall_efficiency = (h_in - npd_stage_steam_enthalpy(current_temperature, current_pressure)) / h_in;
+  }
 }
 
 /* Same result, restructured for instruction-level parallelism (one wave per SIMD has nothing else to
@@ -326,7 +334,7 @@ NPD_FN void npd_stage_system_update(const npd_stage_t &st, const double *stg, do
   NPD_DMA_WAIT(); /* the staged stage arrays are read from here on */
   /* pass C: temperature / enthalpy chain */
   double T_in = inlet_temperature, sat_in = sat_in0, hg_in = hg_in0;
-  double total_power = 0.0, total_extraction = 0.0;
+  double total_power = 0.0, total_extraction = 0.0, hp_power = 0.0, lp_power = 0.0, h_in0 = 0.0;
 #pragma unroll
   for (int k = 0; k < 14; k++) {
     const double p_in = (k == 0) ? inlet_pressure : p_self[k > 0 ? k - 1 : 0];
@@ -363,6 +371,8 @@ NPD_FN void npd_stage_system_update(const npd_stage_t &st, const double *stg, do
     if (ef > 0) extraction_power = ef * (inlet_enthalpy - hg_ext[NPD_EXT_IDX(k)]) / 1000.0;
     double loading_factor = actual_enthalpy_drop / npd_pymax(1.0, 0.88 * isentropic_enthalpy_drop);
     total_power += main_power + extraction_power; total_extraction += ef;
+    if (k < 8) hp_power += main_power + extraction_power; else lp_power += main_power + extraction_power;
+    if (k == 0) h_in0 = inlet_enthalpy;   /* = _steam_enthalpy(inlet_temperature, inlet_pressure) of stage_system.py:985 */
     if (k == 13) out->lp6_outlet_enthalpy = outlet_enthalpy;
     npd_stage_post(st, stg, k, loading_factor, T_out, dt, out);
     T_in = T_out; sat_in = sat_self[k]; hg_in = hg_self[k];
@@ -370,6 +380,13 @@ NPD_FN void npd_stage_system_update(const npd_stage_t &st, const double *stg, do
   NPD_STAMP(28);
   out->total_power = total_power * pressure_stability_factor;
   out->total_extraction = total_extraction;
+  out->hp_power = hp_power; out->lp_power = lp_power;
+  {   /* stage_system.py:983-993: _steam_enthalpy at the last stage's outlet, whose saturation state pass B already has */
+    const double T_c = npd_pymax(0.0, npd_pymin(T_in, 800.0));
+    const double cp = (p_self[13] > 10.0) ? 2.5 : ((p_self[13] > 1.0) ? 2.2 : 2.0);
+    const double h_out = (T_c <= sat_in) ? hg_in : hg_in + cp * (T_c - sat_in);
+    out->overall_efficiency = (inlet_flow > 0) ? (h_in0 - h_out) / h_in0 : 0.0;
+  }
 #undef NPD_EXT_IDX
 #undef NPD_IS_EXT
 }
@@ -397,6 +414,7 @@ static __device__ const double NPD_TLUB_OIL_FLOW[4] = {25.0, 30.0, 40.0, 15.0}; 
 typedef struct npd_turbine_result_t {
   double electrical_power_net, electrical_power_gross, mechanical_power, effective_steam_flow;
   double condenser_pressure, condenser_temperature, lp6_outlet_enthalpy;
+  double hp_power, lp_power, overall_efficiency;
   int trip_active;
 } npd_turbine_result_t;
 
@@ -603,6 +621,7 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
   res->condenser_pressure = condenser_pressure;
   res->condenser_temperature = npd_tsat_antoine(condenser_pressure);
   res->lp6_outlet_enthalpy = ss.lp6_outlet_enthalpy;
+  res->hp_power = ss.hp_power; res->lp_power = ss.lp_power; res->overall_efficiency = ss.overall_efficiency;
   res->trip_active = t->trip_active;
 }
 

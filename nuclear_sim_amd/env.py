@@ -43,7 +43,8 @@ class ControlAction(enum.Enum):
 
 INFO_COLUMNS = ("thermal_power", "reactivity", "electrical_power", "thermal_efficiency", "steam_flow",
                 "steam_pressure", "condenser_pressure", "condenser_heat_rejection", "time", "feedwater_flow",
-                "sg_heat_transfer", "turbine_power", "feedwater_power", "primary_thermal_power")
+                "sg_heat_transfer", "turbine_power", "feedwater_power", "primary_thermal_power",
+                "turbine_efficiency", "turbine_hp_power", "turbine_lp_power")
 
 
 class HeatSourceNoise:
@@ -409,6 +410,12 @@ def secondary_result(info: Dict[str, torch.Tensor], members: Dict[str, torch.Ten
     f["condenser_cooling_water_temp_rise"] = members["cond.cooling_water_outlet_temp"] - members["sec.cooling_water_temperature"]
     # feedwater/physics.py:834: the configuration's auto_level_control, True unless a control command the step never issues clears it
     f["feedwater_auto_control"] = torch.ones_like(members["sec.cooling_water_temperature"])
+    # the three values left over from inside the turbine step (secondary/__init__.py:955-958; include/npb.h NPB_INFO_TURBINE_*)
+    f["turbine_efficiency"] = info["turbine_efficiency"]; f["turbine_hp_power"] = info["turbine_hp_power"]; f["turbine_lp_power"] = info["turbine_lp_power"]
+    # condenser/physics.py:852-859: area factor (active / initial tubes, :122) x fouling factor x vacuum system efficiency, all end-of-step state
+    area_factor = members["cond.active_tube_count"] / 84000.0
+    fouling_factor = (1.0 - members["cond.total_fouling_resistance"] * 5).clamp_min(0.3)
+    f["condenser_thermal_performance"] = area_factor * fouling_factor * members["cond.vacuum_system_efficiency"]
     return f
 
 
@@ -416,7 +423,7 @@ SECONDARY_RESULT_MEMBERS = ("sec.electrical_power_output", "sec.thermal_efficien
                             "cond.heat_rejection_rate", "cond.vacuum_system_efficiency", "fw.running_mask", "fw.system_availability",
                             "chem.ph", "chem.water_aggressiveness", "chem.treatment_efficiency", "ph.controller_output",
                             "ph.pending_ammonia_dose", "ph.measured_ph", "sec.load_demand", "sec.cooling_water_temperature",
-                            "cond.cooling_water_outlet_temp")
+                            "cond.cooling_water_outlet_temp", "cond.active_tube_count", "cond.total_fouling_resistance")
 
 
 class ConstantHeatSource:
@@ -645,8 +652,8 @@ class NuclearPlantSimulator:
 
     def _secondary_result(self) -> Dict[str, float]:
         """info["secondary_system"]: every scalar key of the reference's result dict (secondary/__init__.py:922-1010) that is a
-        function of what the step produces -- 52 of its 56 scalars; turbine_efficiency, turbine_hp_power, turbine_lp_power and
-        condenser_thermal_performance are step-internal values the kernel does not keep."""
+        function of what the step produces -- all 56 scalars (turbine_efficiency, turbine_hp_power and turbine_lp_power are the
+        step's info columns NPB_INFO_TURBINE_*; condenser_thermal_performance is end-of-step state)."""
         return {k: float(v[0].item()) for k, v in self._env.secondary_result().items()}
 
     def reset(self, start_at_steady_state: bool = True):

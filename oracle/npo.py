@@ -10,6 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+import re as _re
+INFO_DIM = int(_re.search(r"NPB_INFO_DIM = (\d+)", open(os.path.join(_HERE, "..", "include", "npb.h")).read()).group(1))
 _LIB = None
 
 
@@ -180,9 +182,9 @@ class OraclePlants:
         obs = np.zeros((n, 22)); rew = np.zeros(n); done = np.zeros(n, dtype=np.uint8)
         flags = np.zeros(n, dtype=np.uint32)
         with_rho = bool(self.params.info_reactivity_components and self.params.heat_source == 1)
-        buf = np.zeros(n * (14 + (10 if with_rho else 0)))
+        buf = np.zeros(n * (INFO_DIM + (10 if with_rho else 0)))
         self.L.npo_step_batch(_ptr(self._buf), n, self.params.ptr, _ptr(a), _ptr(m), _ptr(sp), _ptr(z), _ptr(cw),
                               _ptr(obs), _ptr(rew), _ptr(done), _ptr(flags), _ptr(buf))
-        info = buf[: n * 14].reshape(n, 14)
-        self.reactivity_components = buf[n * 14:].reshape(n, 10) if with_rho else None   # second block of the info buffer
+        info = buf[: n * INFO_DIM].reshape(n, INFO_DIM)
+        self.reactivity_components = buf[n * INFO_DIM:].reshape(n, 10) if with_rho else None   # second block of the info buffer
         return obs, rew, done, flags, info

@@ -22,6 +22,7 @@ typedef struct npo_secondary_result_t {
   double condenser_pressure, total_system_heat_rejection;
   double feedwater_total_flow, feedwater_total_power;
   double sg_total_heat_transfer, turbine_power_output, primary_thermal_power;
+  double turbine_efficiency, turbine_hp_power, turbine_lp_power;   /* secondary/__init__.py:955-958 */
   int feedwater_system_available;
   uint32_t trip_flags;
 } npo_secondary_result_t;
@@ -176,6 +177,7 @@ NPO_FN void npo_secondary_tail(npo_plant_t *pl, const npb_params_t *P, const npo
   r->feedwater_system_available = fwr->system_availability;
   r->sg_total_heat_transfer = sgr->total_thermal_power; r->turbine_power_output = tr.electrical_power_gross;
   r->primary_thermal_power = primary_thermal_power;
+  r->turbine_efficiency = tr.overall_efficiency; r->turbine_hp_power = tr.hp_power; r->turbine_lp_power = tr.lp_power;
   r->trip_flags = (fwr->pump_trip_mask << 8) | (pl->fw.system_trip_active ? NPB_TRIP_FW_SYSTEM : 0) |
                   (tr.trip_active ? NPB_TRIP_TURBINE : 0);
 }

@@ -133,6 +133,8 @@ NPO_FN void npo_step(npo_plant_t *pl, const npb_params_t *P, const npo_inputs_t 
   out->info[NPB_INFO_FEEDWATER_FLOW] = r.feedwater_total_flow;
   out->info[NPB_INFO_SG_HEAT_TRANSFER] = r.sg_total_heat_transfer; out->info[NPB_INFO_TURBINE_POWER] = r.turbine_power_output;
   out->info[NPB_INFO_FEEDWATER_POWER] = r.feedwater_total_power; out->info[NPB_INFO_PRIMARY_THERMAL_POWER] = r.primary_thermal_power;
+  out->info[NPB_INFO_TURBINE_EFFICIENCY] = r.turbine_efficiency;
+  out->info[NPB_INFO_TURBINE_HP_POWER] = r.turbine_hp_power; out->info[NPB_INFO_TURBINE_LP_POWER] = r.turbine_lp_power;
 
   /* maintenance_system.update + state_manager.collect_states  sim.py:208-223; nothing they touch
    * feeds the observation, reward or info built above */

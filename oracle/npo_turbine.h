@@ -159,6 +159,8 @@ NPO_FN double npo_stage_dynamic_pressure_ratio(int k, double current_pressure, d
 typedef struct npo_stagesys_out_t {
   double total_power, total_extraction, lp6_outlet_enthalpy;
   double stage_outlet_temperature[14];
+  double hp_power, lp_power;     /* sums of the HP-1..8 / LP-1..6 stage outputs (enhanced_physics.py:879-880) */
+  double overall_efficiency;     /* stage_system.py:983-993 */
 } npo_stagesys_out_t;
 
 /* TurbineStageSystem.update_state  stage_system.py:928-1016 (+ calculate_stage_by_stage_expansion :760-926,
@@ -172,6 +174,7 @@ NPO_FN void npo_stage_system_update(npb_tstg_t *t, double inlet_pressure, double
   double current_pressure = inlet_pressure, current_temperature = inlet_temperature, current_flow = inlet_flow;
   const double final_pressure = 0.007;
   double total_power = 0.0, total_extraction = 0.0;
+  double hp_power = 0.0, lp_power = 0.0, steam_enthalpy_in = 0.0;
   double loading[14];
   for (int k = 0; k < 14; k++) {
     double pressure_ratio = npo_stage_dynamic_pressure_ratio(k, current_pressure, inlet_flow);
@@ -193,6 +196,8 @@ NPO_FN void npo_stage_system_update(npb_tstg_t *t, double inlet_pressure, double
     npo_stage_expansion(k, actual_efficiency, blade_condition_factor, fouling_factor, blade_wear_factor, current_pressure,
                         current_temperature, current_flow, outlet_pressure, extraction_demand[k], &so);
     total_power += so.power_output; total_extraction += so.extraction_flow;
+    if (k < 8) hp_power += so.power_output; else lp_power += so.power_output;
+    if (k == 0) steam_enthalpy_in = npo_stage_steam_enthalpy(inlet_temperature, inlet_pressure);
     out->stage_outlet_temperature[k] = so.outlet_temperature;
     if (k == 13) out->lp6_outlet_enthalpy = so.outlet_enthalpy;
     loading[k] = so.loading_factor;
@@ -206,6 +211,11 @@ NPO_FN void npo_stage_system_update(npb_tstg_t *t, double inlet_pressure, double
   }
   out->total_power = total_power * pressure_stability_factor;
   out->total_extraction = total_extraction;
+  out->hp_power = hp_power; out->lp_power = lp_power;
+  if (inlet_flow > 0) {   /* stage_system.py:984-991: the last stage's outlet conditions as handed on by the expansion loop */
+    double outlet_enthalpy = npo_stage_steam_enthalpy(current_temperature, current_pressure);
+    out->overall_efficiency = (steam_enthalpy_in - outlet_enthalpy) / steam_enthalpy_in;
+  } else out->overall_efficiency = 0.0;
 }
 
 /* _calculate_pressure_variation_effects  enhanced_physics.py:1312-1350 */
@@ -231,6 +241,7 @@ static const double NPO_TLUB_OIL_FLOW[4] = {25.0, 30.0, 40.0, 15.0}; /* oil_flow
 typedef struct npo_turbine_result_t {
   double electrical_power_net, electrical_power_gross, mechanical_power, effective_steam_flow;
   double condenser_pressure, condenser_temperature, lp6_outlet_enthalpy;
+  double hp_power, lp_power, overall_efficiency;   /* enhanced_physics.py:840,879-880 */
   int trip_active;
 } npo_turbine_result_t;
 
@@ -436,6 +447,7 @@ NPO_FN void npo_turbine_update(npb_turb_t *t, npb_tstg_t *g, double steam_pressu
   res->condenser_pressure = condenser_pressure;
   res->condenser_temperature = npo_tsat_antoine(condenser_pressure);
   res->lp6_outlet_enthalpy = ss.lp6_outlet_enthalpy;
+  res->hp_power = ss.hp_power; res->lp_power = ss.lp_power; res->overall_efficiency = ss.overall_efficiency;
   res->trip_active = t->trip_active;
 }
 

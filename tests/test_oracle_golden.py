@@ -76,6 +76,13 @@ def test_oracle_replays_golden(oracle_lib, name):
         assert int(done[0]) == int(g.done[t]), "%s done step %d" % (name, t)
         m = ~np.isnan(g.info[t])
         np.testing.assert_allclose(info[0][:g.info.shape[1]][m], g.info[t][m], rtol=RTOL, atol=1e-9, err_msg="%s info step %d" % (name, t))
+        # the three turbine keys of info["secondary_system"] that come out of the step itself (include/npb.h NPB_INFO_TURBINE_*)
+        # (not on a step whose state was poked: the reference's stages expand with the fouling / blade-condition factors they
+        # cached at the end of the step before -- stage_system.py:294-339 -- which a poked deposit thickness leaves stale for
+        # one step; in a run nothing but update_degradation moves them, and the state members are the thicknesses)
+        for col, key in ((14, "turbine_efficiency"), (15, "turbine_hp_power"), (16, "turbine_lp_power")):
+            if key in g.sec_keys and t not in g.pokes:
+                np.testing.assert_allclose(info[0][col], g.sec[t, g.sec_keys.index(key)], rtol=RTOL, atol=1e-9, err_msg="%s %s step %d" % (name, key, t))
         if g.rc is not None:   # info["reactivity_components"], key order = include/npb.h NPB_RHO_*
             from nuclear_sim_amd import _lib
             assert tuple(g.rc_keys) == _lib.REACTIVITY_COMPONENTS
