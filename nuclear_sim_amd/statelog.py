@@ -103,8 +103,44 @@ def derived_log_columns() -> Dict[str, tuple]:
             return m_
         out["secondary.steam_generator_SG-%d.tsp_average_deposit_thickness" % i] = (need, avg)
         out["secondary.steam_generator_SG-%d.tsp_maximum_deposit_thickness" % i] = (need, mx)
+    # turbine stages, stage_system.py:379-393 (state dict) with :294-339 (update_degradation, the last thing a step does to a
+    # stage): the logged efficiency and blade condition are recomputed there from the end-of-step degradation state.  The stage
+    # system's own dict takes every stage's un-prefixed keys in turn (:1028-1030), so the turbine-level columns are LP-6's.
+    stage_names = ["HP-%d" % (k + 1) for k in range(8)] + ["LP-%d" % (k + 1) for k in range(6)]
+    for k, sn in enumerate(stage_names):
+        targets = ["secondary.turbine_%s." % sn] + (["secondary.turbine_SECONDARY-COMP-001-TURB."] if k == 13 else [])
+        for N in targets:
+            out[N + "efficiency"] = (("tstg.stage_efficiency_degradation[%d]" % k,), lambda d: _max(0.7, 0.88 - d))
+            out[N + "blade_condition"] = (("tstg.stage_deposit_thickness[%d]" % k, "tstg.stage_blade_wear_factor[%d]" % k),
+                                          lambda dep, wear: np.minimum(1.0 / (1.0 + dep / 0.5), wear))
     mapped = set(reference_log_columns())
     return {k: v for k, v in out.items() if k not in mapped}
+
+
+def result_log_columns() -> Dict[str, tuple]:
+    """The reference's log columns that are scalar keys of the step's info["secondary_system"] (BatchedPlantEnv.secondary_result):
+    log column -> (key, factor).  The heat-flow tracker's and the stage system's state dicts hand the same numbers to the state
+    manager that the result dict carries (secondary/__init__.py:922-1010, heat_flow_tracker.py:324-351, stage_system.py:1018-1026);
+    found by matching the m1 run's log against its recorded result dicts series for series, checked against the reference's
+    own log in tests/test_gpu_parity.py."""
+    R, T = "secondary.reactor_SECONDARY-COMP-001.", "secondary.turbine_SECONDARY-COMP-001-TURB."
+    return {
+        "secondary.condenser_SECONDARY-COMP-001-COND.condenser_thermal_performance": ("condenser_thermal_performance", 1.0),
+        R + "heat_flow_condenser_heat_rejection": ("heat_flow_condenser_heat_rejection", 1.0),
+        R + "heat_flow_energy_balance_error": ("heat_flow_energy_balance_error", 1.0),
+        R + "heat_flow_energy_balance_ok": ("heat_flow_balance_ok", 1.0),
+        R + "heat_flow_energy_balance_percent": ("heat_flow_energy_balance_percent", 1.0),
+        R + "heat_flow_net_electrical_output": ("heat_flow_net_electrical_output", 1.0),
+        R + "heat_flow_overall_efficiency": ("heat_flow_overall_efficiency", 1.0),
+        R + "heat_flow_turbine_work_output": ("turbine_mechanical_power", 1.0),
+        R + "heat_flow_sg_heat_input": ("total_heat_transfer", 1e-6),
+        R + "heat_flow_steam_enthalpy_flow": ("total_heat_transfer", 0.98e-6),
+        R + "system_total_heat_transfer": ("total_heat_transfer", 1e-6),
+        R + "system_total_system_heat_rejection": ("total_system_heat_rejection", 1e-6),
+        T + "enhanced_turbine_efficiency": ("turbine_efficiency", 1.0),
+        T + "enhanced_turbine_steam_rate": ("turbine_steam_rate", 1.0),
+        T + "stage_system_efficiency": ("turbine_efficiency", 1.0),
+    }
 
 
 def log_columns(fields: Optional[Sequence[str]] = None) -> List[tuple]:
@@ -149,6 +185,9 @@ class StateLog:
         self._kinds = (ctypes.c_int * nf)(*[0 if c[0] == "f64" else 1 for c in self.columns])
         self._slots = (ctypes.c_int * nf)(*[c[1] for c in self.columns])
         self._buf = torch.empty((self.capacity, nf, env.n), dtype=torch.float64, device=env.device)
+        # the log columns that are keys of the step's secondary result dict (reference layout, plants with a secondary side)
+        self._res_keys = sorted({k for k, _f in result_log_columns().values()}) if self._reference_layout and env.params.mode == _lib.MODE_FULL else []
+        self._res = torch.empty((self.capacity, len(self._res_keys), env.n), dtype=torch.float64, device=env.device) if self._res_keys else None
         self._times: List[float] = []
         self._steps: List[int] = []
 
@@ -163,6 +202,10 @@ class StateLog:
         out = self._buf[row]
         _lib.check(self.env.L.npb_gather_fields(self.env._h, len(self.columns), self._kinds, self._slots,
                                                 ctypes.c_void_p(out.data_ptr()), self.env._stream()), self.env._h)
+        if self._res is not None:     # valid for the step just taken: call record() between that step and the next
+            res = self.env.secondary_result()
+            for j, k in enumerate(self._res_keys):
+                self._res[row, j] = res[k]
         self._times.append(float(time_minutes)); self._steps.append(int(step))
 
     def maybe_record(self, step: int, time_minutes: float) -> bool:
@@ -195,6 +238,10 @@ class StateLog:
                 cols[name] = v * factor if factor != 1.0 else v
             for name, (need, fn) in sorted(derived_log_columns().items()):
                 cols[name] = np.asarray(fn(*[data[:, index[label], :].reshape(-1) for label in need]), dtype=np.float64)
+            if self._res is not None:
+                res = self._res[:len(self._times)].cpu().numpy()[:, :, idx]
+                for name, (key, factor) in sorted(result_log_columns().items()):
+                    cols[name] = res[:, self._res_keys.index(key), :].reshape(-1) * factor
             return pa.table(cols)
         for f, (kind, _slot, _label, name) in enumerate(self.columns):
             v = data[:, f, :].reshape(-1)

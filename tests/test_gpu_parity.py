@@ -114,7 +114,7 @@ def test_hip_replays_golden(name):
                     # energy_balance_error is a ~1e-3 difference of ~3000 MW sums: absolute floor 1e-9 MW
                     np.testing.assert_allclose(col[0].item(), want, rtol=RTOL, atol=1e-9, err_msg="%s secondary_system[%s] step %d" % (name, k, t))
                     checked += 1
-            assert checked >= 45, checked
+            assert checked >= 49, checked   # all 52 recorded scalar keys but the three turbine-internal ones on a poked step
 
 
 @pytest.mark.parametrize("heat_source,mode", [("constant", "full"), ("reactor", "full"), ("reactor", "primary_sg")])
@@ -850,12 +850,13 @@ def test_nan_state_propagates_like_the_reference(oracle_lib):
 def test_state_log_matches_the_references_log(tmp_path):
     """the columnar state log sampled every step of the m1 data-gen run against the reference's OWN log of the
     same run (tests/golden/log_m1_oil_top_off_staggered.npz = `sim.state_manager.data`): every log column the map claims
-    (265 of the reference's 784 numeric columns, several per member, unit factors applied) must hold the reference's values
-    at every step, under the reference's column names."""
+    (265 of the reference's 784 numeric columns, several per member, unit factors applied; 57 plain functions of end-of-step
+    state; 15 keys of the step's secondary result) must hold the reference's values at every step, under the reference's
+    column names."""
     import os
     import pyarrow.parquet as pq
     from golden_util import GOLDEN_DIR
-    from nuclear_sim_amd.statelog import StateLog, reference_log_columns, derived_log_columns
+    from nuclear_sim_amd.statelog import StateLog, reference_log_columns, derived_log_columns, result_log_columns
     g = Golden("m1_oil_top_off_staggered")
     z = np.load(os.path.join(GOLDEN_DIR, "log_m1_oil_top_off_staggered.npz"))
     ref_names = [str(x) for x in z["names"]]; ref = z["log"]
@@ -877,9 +878,11 @@ def test_state_log_matches_the_references_log(tmp_path):
     lc = reference_log_columns()
     assert len(lc) >= 250 and set(lc) <= set(tab.column_names) and set(lc) <= set(ref_names)
     derived = derived_log_columns()      # plain functions of the end-of-step state (pump factors, wear sums, SG system averages ...)
-    assert len(derived) >= 20 and set(derived) <= set(tab.column_names) and set(derived) <= set(ref_names) and not set(derived) & set(lc)
+    assert len(derived) >= 55 and set(derived) <= set(tab.column_names) and set(derived) <= set(ref_names) and not set(derived) & set(lc)
+    results = result_log_columns()       # keys of the step's secondary result dict (heat-flow tracker, stage-system efficiency ...)
+    assert len(results) >= 15 and set(results) <= set(tab.column_names) and set(results) <= set(ref_names) and not set(results) & (set(lc) | set(derived))
     checked = 0
-    for name in list(lc) + list(derived):
+    for name in list(lc) + list(derived) + list(results):
         mine = tab[name].to_numpy().reshape(g.T, 2)
         want = ref[:, ref_names.index(name)]
         for lane in (0, 1):

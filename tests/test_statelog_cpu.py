@@ -2,6 +2,8 @@
 (oracle/ref_harness/make_state_names.py); here only its consistency with the schema is checked (no GPU)."""
 import re
 
+import numpy as np
+
 import pytest
 
 from nuclear_sim_amd.schema import SCHEMA
@@ -45,3 +47,48 @@ def test_log_column_map_is_consistent():
     same = [n for n, (label, f) in lc.items() if label == "sec.total_feedwater_flow"]
     assert len(same) >= 2
     assert all(re.match(r"^(primary|secondary)\.", n) for n in lc)
+
+
+def test_result_log_columns_are_the_references_own_result_keys():
+    """The map log column -> key of info["secondary_system"] on the reference's own data: the m1 run's state log
+    (log_m1_oil_top_off_staggered.npz) against the result dicts recorded in the same run's trajectory fixture."""
+    import os
+    from golden_util import Golden, GOLDEN_DIR
+    from nuclear_sim_amd.statelog import result_log_columns, derived_log_columns
+    g = Golden("m1_oil_top_off_staggered")
+    z = np.load(os.path.join(GOLDEN_DIR, "log_m1_oil_top_off_staggered.npz"))
+    names = [str(x) for x in z["names"]]; log = z["log"]
+    rc = result_log_columns()
+    assert len(rc) >= 15 and set(rc) <= set(names) and not set(rc) & set(reference_log_columns()) and not set(rc) & set(derived_log_columns())
+    for name, (key, factor) in rc.items():
+        want = log[:, names.index(name)]
+        np.testing.assert_allclose(g.sec[:, g.sec_keys.index(key)] * factor, want, rtol=1e-9, atol=1e-12, err_msg=name)
+        assert np.ptp(want) > 0, name
+
+
+def test_derived_log_columns_on_the_oracle_replay(oracle_lib):
+    """The columns that are plain functions of end-of-step state (pump factors, SG averages, TSP aggregates, the turbine
+    stages' efficiency and blade condition ...): the m1 run replayed on the CPU oracle, each formula evaluated on the oracle's
+    state after every step, against the reference's own log."""
+    import os
+    from golden_util import Golden, GOLDEN_DIR
+    from nuclear_sim_amd.statelog import derived_log_columns
+    import test_oracle_golden as tg
+    g = Golden("m1_oil_top_off_staggered")
+    z = np.load(os.path.join(GOLDEN_DIR, "log_m1_oil_top_off_staggered.npz"))
+    names = [str(x) for x in z["names"]]; log = z["log"]
+    o = oracle_lib.OraclePlants(1, tg._configure(oracle_lib, g))
+    f0, i0 = o.state()
+    f, i, fm, im = g.split_state(g.state[0])
+    f0[fm] = f[fm]; i0[im] = i[im]
+    o.set_state(f0, i0)
+    slot = {label: (kind, s) for kind, s, label, _p in SCHEMA.columns()}
+    derived = derived_log_columns()
+    assert len(derived) >= 55 and set(derived) <= set(names)
+    for t in range(g.T):
+        o.step(action=g.action[t], magnitude=g.magnitude[t], setpoint=g.setpoint[t], noise_z=g.noise_z[t], cw_temp=g.cooling[t])
+        fs, is_ = o.state()
+        for name, (need, fn) in derived.items():
+            args = [np.float64(fs[slot[l][1]] if slot[l][0] == "f64" else is_[slot[l][1]]) for l in need]
+            want = log[t, names.index(name)]
+            assert abs(float(fn(*args)) - want) <= 1e-6 * abs(want) + 1e-9, (name, t, float(fn(*args)), want)
