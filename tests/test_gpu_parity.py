@@ -969,7 +969,7 @@ def test_largest_handle_uses_the_whole_32bit_offset_range():
     rng = np.random.default_rng(123)
     pick = np.r_[0:64, n - 64:n]
     small = _env(n=len(pick), noise_enabled=True)
-    small.set_step_kernel(1)      # the big handle takes the one-wave kernel (batch size); same kernel, so bits can be compared
+    big.set_step_kernel(1); small.set_step_kernel(1)      # what a handle of this size takes anyway; same kernel, so bits can be compared
     lv = rng.uniform(20, 100, n)
     big.set_field("pump.oil_level", lv, instance=3); small.set_field("pump.oil_level", lv[pick], instance=3)
     tr = rng.uniform(300, 360, n)
