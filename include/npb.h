@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPB_VERSION 132 /* 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
+#define NPB_VERSION 133 /* 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
 #ifndef NPB_API
 #define NPB_API __attribute__((visibility("default")))
 #endif
@@ -47,6 +47,13 @@ enum {
    * system's cycle efficiency (h_in - h_out) / h_in (stage_system.py:983-993) and the summed outputs of the HP-1..8 and
    * LP-1..6 stages [MW] (enhanced_physics.py:879-880); 0 where the turbine is not stepped (NPB_MODE_PRIMARY_SG) */
   NPB_INFO_TURBINE_EFFICIENCY, NPB_INFO_TURBINE_HP_POWER, NPB_INFO_TURBINE_LP_POWER
+};
+/* Step-internal diagnostics (optional: npb_set_diagnostics): what the reference's state log holds per turbine stage from inside
+ * the expansion (TurbineStage.get_state_dict, stage_system.py:379-393) and nothing later in the step can recover -- fourteen
+ * values each, HP-1..8 then LP-1..6, column (NPB_DIAG_* + stage) of a [NPB_DIAG_DIM][pitch] fp64 buffer. */
+enum {
+  NPB_DIAG_STAGE_INLET_PRESSURE = 0, NPB_DIAG_STAGE_INLET_TEMPERATURE = 14, NPB_DIAG_STAGE_OUTLET_PRESSURE = 28,
+  NPB_DIAG_STAGE_OUTLET_TEMPERATURE = 42, NPB_DIAG_STAGE_POWER_OUTPUT = 56, NPB_DIAG_STAGE_LOADING_FACTOR = 70, NPB_DIAG_DIM = 84
 };
 /* info["reactivity_components"] (sim.py:205; reactivity_model.py:77-125, pcm, the dict's insertion order).  Only the
  * reactor heat source has them, and only a caller that sets params.info_reactivity_components gets them: the info
@@ -156,6 +163,11 @@ NPB_API int npb_locate_field(const NpbHandle *h, int kind, int slot, int *column
 NPB_API int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const double *power_setpoint,
              const double *noise_z, const double *cooling_water_temp, double *obs, double *reward, uint8_t *done,
              uint32_t *trip_flags, double *info, void *stream);
+
+/* Have npb_step write the NPB_DIAG_* columns of every following step into buf ([NPB_DIAG_DIM][pitch] doubles on the handle's
+ * device, pitch >= n_plants rounded up to a multiple of 64; NULL = off, the default).  While it is set the step runs the diagnostics build of the one-wave
+ * kernel at every batch size (same results, ~1.4x the time at small batches); full mode only. */
+NPB_API int npb_set_diagnostics(NpbHandle *h, double *buf, size_t pitch);
 
 /* Which of the two step kernels npb_step launches (same device functions in the same per-plant order: identical int32
  * columns and flags, reals equal to the last bit or two; this is a measurement / A-B aid):

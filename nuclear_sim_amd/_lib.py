@@ -19,6 +19,9 @@ HEAT_CONSTANT, HEAT_REACTOR = 0, 1
 STORAGE_F64, STORAGE_F32 = 0, 1
 MODE_FULL, MODE_PRIMARY_SG, MODE_PRIMARY = 0, 1, 2
 INFO_NRHO = 10   # include/npb.h NPB_INFO_NRHO
+# include/npb.h NPB_DIAG_*: step-internal diagnostics, fourteen turbine stages each (TurbineStage.get_state_dict, stage_system.py:379-393)
+DIAG_STAGE_VALUES = ("inlet_pressure", "inlet_temperature", "outlet_pressure", "outlet_temperature", "power_output", "loading_factor")
+DIAG_DIM = 14 * len(DIAG_STAGE_VALUES)
 REACTIVITY_COMPONENTS = ("control_rods", "boron", "doppler", "moderator_temp", "moderator_void", "pressure", "xenon", "samarium",
                          "fuel_depletion", "burnable_poisons")   # reactivity_model.py:87-121, NPB_RHO_*
 
@@ -119,6 +122,8 @@ def load():
     L.npb_set_params.argtypes = [vp, ctypes.POINTER(NpbParams)]
     L.npb_reset.argtypes = [vp, vp, vp]
     L.npb_set_step_kernel.argtypes = [vp, ci]
+    if hasattr(L, "npb_set_diagnostics"):     # (absent from builds older than ABI 133: tools/ab_kernel.py loads those)
+        L.npb_set_diagnostics.argtypes = [vp, vp, ctypes.c_size_t]
     L.npb_set_maintenance_table.argtypes = [vp, ctypes.POINTER(NpbMaintTable)]
     L.npb_default_maintenance_table.argtypes = [ctypes.POINTER(NpbMaintTable)]
     L.npb_reset_reference.argtypes = [vp, vp, ci, vp]

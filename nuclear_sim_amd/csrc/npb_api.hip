@@ -21,6 +21,7 @@ struct NpbHandle {
   void *f64;           /* the arena: [NPB_TOTAL_COL64][pitch] 8-byte columns, or [NPB_TOTAL_COL32][pitch] 4-byte ones */
   double *convert;     /* one staging column (pitch doubles) used by get/set_field with host buffers */
   unsigned *maint_flags; /* NPB_NUM_PUMPS words per wave of plants: the maintenance screen's verdict (behind the staging column) */
+  double *diag; size_t diag_pitch; /* npb_set_diagnostics: the caller's [NPB_DIAG_DIM][diag_pitch] buffer, or NULL */
   int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel, 3 = its two-waves-per-SIMD build (npb_set_step_kernel) */
   npb_maint_table_t maint_table;   /* thresholds of the automatic maintenance (include/npb_maint.h) */
   bool maint_table_custom;         /* set through npb_set_maintenance_table: the table is then taken as it is */
@@ -107,7 +108,7 @@ static void probe_placement(NpbHandle *h, size_t step_columns) {
     for (int k = 0; k < launches; k++) {
       (void)hipEventRecord(a, nullptr);
       (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, cand[n], nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                     nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr);
+                                                     nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr);
       (void)hipEventRecord(b, nullptr);
       if (hipEventSynchronize(b) != hipSuccess) { best = 1e30f; break; }
       float t = 0; (void)hipEventElapsedTime(&t, a, b);
@@ -222,6 +223,14 @@ int npb_set_params(NpbHandle *h, const npb_params_t *params) {
 int npb_set_step_kernel(NpbHandle *h, int variant) {
   if (!h || variant < 0 || variant > 3) return NPB_EINVAL;
   h->step_kernel = variant;
+  return NPB_OK;
+}
+
+int npb_set_diagnostics(NpbHandle *h, double *buf, size_t pitch) {
+  if (!h) return NPB_EINVAL;
+  if (buf && h->params.mode != NPB_MODE_FULL) return fail(h, NPB_EINVAL, "npb_set_diagnostics: full mode only");
+  if (buf && pitch < h->pitch) return fail(h, NPB_EINVAL, "npb_set_diagnostics: pitch must be at least n_plants rounded up to 64");
+  h->diag = buf; h->diag_pitch = buf ? pitch : 0;
   return NPB_OK;
 }
 
@@ -342,7 +351,8 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
   NPB_USE_DEVICE(h);
   const bool narrow = h->storage == NPB_STORAGE_F32;
   (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, action, magnitude, power_setpoint,
-                                                 noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, h->step_kernel, (hipStream_t)stream);
+                                                 noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, h->step_kernel, h->diag, h->diag_pitch,
+                                                 (hipStream_t)stream);
   if (h->params.maint_enabled) {
     npb_maint_table_t table = h->maint_table;
     if (!h->maint_table_custom) {   /* with the default table the two oil_level params of ABI version 1 still set their row */

@@ -73,7 +73,11 @@ typedef struct npd_stage_t {
   uint32_t laner;         /* lane * column width: this lane's plant within a column */
   uint32_t grp16;         /* grouped LDS-DMA: 64 / NPD_GROUP consecutive lanes carry one column, 16 B each:
                            * (lane / lanes_per_col) * nr + (lane % lanes_per_col) * 16 */
+  double *diag;           /* this lane's element of diagnostics column 0 (include/npb.h NPB_DIAG_*), or NULL: only the
+                           * diagnostics build of the step kernel sets it, everywhere else the stores below fold away */
+  size_t diag_pitch;
 } npd_stage_t;
+#define NPD_DIAG(st, col, v) do { if ((st).diag) (st).diag[(size_t)(col) * (st).diag_pitch] = (v); } while (0)
 
 __device__ __forceinline__ void npd_stage_init(npd_stage_t &st, void *lds, npd_real_t *arena, size_t N, size_t block_base) {
   const uint32_t lane = threadIdx.x, lpc = NPB_WAVE / NPD_GROUP;
@@ -82,6 +86,7 @@ __device__ __forceinline__ void npd_stage_init(npd_stage_t &st, void *lds, npd_r
   st.nr = (uint32_t)(N * NPD_RB);
   st.laner = lane * NPD_RB;
   st.grp16 = (lane / lpc) * st.nr + (lane % lpc) * 16u;
+  st.diag = nullptr; st.diag_pitch = 0;
 }
 __device__ __forceinline__ uint32_t npd_voff(uint32_t col, uint32_t pitch, uint32_t lane_off) {
   uint32_t v, t;

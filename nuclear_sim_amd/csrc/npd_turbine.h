@@ -252,6 +252,9 @@ NPD_FN void npd_stage_system_update_seq(const npd_stage_t &st, const double *stg
     total_power += so.power_output; total_extraction += so.extraction_flow;
     if (k < 8) hp_power += so.power_output; else lp_power += so.power_output;
     if (k == 13) out->lp6_outlet_enthalpy = so.outlet_enthalpy;
+    NPD_DIAG(st, NPB_DIAG_STAGE_INLET_PRESSURE + k, current_pressure); NPD_DIAG(st, NPB_DIAG_STAGE_INLET_TEMPERATURE + k, current_temperature);
+    NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_PRESSURE + k, so.outlet_pressure); NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_TEMPERATURE + k, so.outlet_temperature);
+    NPD_DIAG(st, NPB_DIAG_STAGE_POWER_OUTPUT + k, so.power_output); NPD_DIAG(st, NPB_DIAG_STAGE_LOADING_FACTOR + k, so.loading_factor);
     npd_stage_post(st, stg, k, so.loading_factor, so.outlet_temperature, dt, out);
     current_pressure = so.outlet_pressure; current_temperature = so.outlet_temperature; current_flow = so.outlet_flow;
   }
@@ -374,6 +377,9 @@ NPD_FN void npd_stage_system_update(const npd_stage_t &st, const double *stg, do
     if (k < 8) hp_power += main_power + extraction_power; else lp_power += main_power + extraction_power;
     if (k == 0) h_in0 = inlet_enthalpy;   /* = _steam_enthalpy(inlet_temperature, inlet_pressure) of stage_system.py:985 */
     if (k == 13) out->lp6_outlet_enthalpy = outlet_enthalpy;
+    NPD_DIAG(st, NPB_DIAG_STAGE_INLET_PRESSURE + k, p_in); NPD_DIAG(st, NPB_DIAG_STAGE_INLET_TEMPERATURE + k, T_in);
+    NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_PRESSURE + k, p_self[k]); NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_TEMPERATURE + k, T_out);
+    NPD_DIAG(st, NPB_DIAG_STAGE_POWER_OUTPUT + k, main_power + extraction_power); NPD_DIAG(st, NPB_DIAG_STAGE_LOADING_FACTOR + k, loading_factor);
     npd_stage_post(st, stg, k, loading_factor, T_out, dt, out);
     T_in = T_out; sat_in = sat_self[k]; hg_in = hg_self[k];
   }

@@ -189,6 +189,21 @@ class BatchedPlantEnv:
         results to the last bit or two (include/npb.h)"""
         _lib.check(self.L.npb_set_step_kernel(self._h, int(variant)), self._h)
 
+    def enable_diagnostics(self, on: bool = True):
+        """Have every following step also write the step-internal diagnostics (include/npb.h NPB_DIAG_*: per turbine stage inlet /
+        outlet pressure and temperature, power output, loading factor) into ``self.diagnostics`` ([DIAG_DIM, n] on the device,
+        rows in _lib.DIAG_STAGE_VALUES order x 14 stages).  The step then runs the diagnostics build of the one-wave kernel at
+        every batch size: meant for state logging, not for throughput."""
+        if on:
+            pitch = (self.n + 63) // 64 * 64
+            self._diag_buf = torch.zeros((_lib.DIAG_DIM, pitch), dtype=torch.float64, device=self.device)
+            _lib.check(self.L.npb_set_diagnostics(self._h, ctypes.c_void_p(self._diag_buf.data_ptr()), pitch), self._h)
+            self.diagnostics = self._diag_buf[:, : self.n]
+        else:
+            _lib.check(self.L.npb_set_diagnostics(self._h, None, 0), self._h)
+            self._diag_buf = None; self.diagnostics = None
+        return self.diagnostics
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self.L.npb_destroy(self._h)

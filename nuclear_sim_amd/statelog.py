@@ -169,10 +169,25 @@ def log_columns(fields: Optional[Sequence[str]] = None) -> List[tuple]:
     return out
 
 
+def diagnostic_log_columns() -> Dict[str, int]:
+    """The reference's log columns that are left over from inside the turbine stages' expansion: log column -> row of
+    BatchedPlantEnv.diagnostics (include/npb.h NPB_DIAG_*).  TurbineStage.get_state_dict (stage_system.py:379-393) under each
+    stage's own name, and once more under the turbine's, where the stage system's dict keeps the last stage's un-prefixed keys
+    (:1028-1030).  Columns that are already state members (HP-1's inlet is the steam header) are left to reference_log_columns."""
+    stage_names = ["HP-%d" % (k + 1) for k in range(8)] + ["LP-%d" % (k + 1) for k in range(6)]
+    out = {}
+    for v, value in enumerate(_lib.DIAG_STAGE_VALUES):
+        for k, sn in enumerate(stage_names):
+            out["secondary.turbine_%s.%s" % (sn, value)] = v * 14 + k
+        out["secondary.turbine_SECONDARY-COMP-001-TURB.%s" % value] = v * 14 + 13
+    known = set(json.load(open(_NAMES_PATH))["unmatched"])
+    return {name: row for name, row in out.items() if name in known}
+
+
 class StateLog:
     """Device-resident ring of samples of selected state members of every plant."""
 
-    def __init__(self, env, fields: Optional[Sequence[str]] = None, every: int = 1, capacity: int = 256):
+    def __init__(self, env, fields: Optional[Sequence[str]] = None, every: int = 1, capacity: int = 256, diagnostics: bool = False):
         self.env = env
         self.columns = log_columns(fields)
         # with no field list the table carries the reference's log columns (several per member, unit factors applied)
@@ -188,6 +203,12 @@ class StateLog:
         # the log columns that are keys of the step's secondary result dict (reference layout, plants with a secondary side)
         self._res_keys = sorted({k for k, _f in result_log_columns().values()}) if self._reference_layout and env.params.mode == _lib.MODE_FULL else []
         self._res = torch.empty((self.capacity, len(self._res_keys), env.n), dtype=torch.float64, device=env.device) if self._res_keys else None
+        # step-internal diagnostics (reference layout, full mode): switches the env to the diagnostics build of the step kernel
+        self._diag = None
+        if diagnostics and self._res_keys:
+            if getattr(env, "diagnostics", None) is None:
+                env.enable_diagnostics(True)
+            self._diag = torch.empty((self.capacity, _lib.DIAG_DIM, env.n), dtype=torch.float64, device=env.device)
         self._times: List[float] = []
         self._steps: List[int] = []
 
@@ -206,6 +227,8 @@ class StateLog:
             res = self.env.secondary_result()
             for j, k in enumerate(self._res_keys):
                 self._res[row, j] = res[k]
+        if self._diag is not None:
+            self._diag[row].copy_(self.env.diagnostics)
         self._times.append(float(time_minutes)); self._steps.append(int(step))
 
     def maybe_record(self, step: int, time_minutes: float) -> bool:
@@ -242,6 +265,10 @@ class StateLog:
                 res = self._res[:len(self._times)].cpu().numpy()[:, :, idx]
                 for name, (key, factor) in sorted(result_log_columns().items()):
                     cols[name] = res[:, self._res_keys.index(key), :].reshape(-1) * factor
+            if self._diag is not None:
+                dg = self._diag[:len(self._times)].cpu().numpy()[:, :, idx]
+                for name, row in sorted(diagnostic_log_columns().items()):
+                    cols[name] = dg[:, row, :].reshape(-1)
             return pa.table(cols)
         for f, (kind, _slot, _label, name) in enumerate(self.columns):
             v = data[:, f, :].reshape(-1)

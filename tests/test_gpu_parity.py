@@ -959,6 +959,49 @@ def test_other_feedwater_action_scenarios_run_on_the_oracle_track(oracle_lib, ac
             np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)
 
 
+def test_state_log_diagnostics_match_the_references_log():
+    """The step-internal columns of the state log (per turbine stage: inlet / outlet pressure and temperature, power output,
+    loading factor -- TurbineStage.get_state_dict, left over from inside the expansion): written by the diagnostics build of
+    the step kernel (npb_set_diagnostics), against the reference's own log of the m1 run at every step; and that build
+    leaves every state column and output exactly as the plain one-wave kernel does."""
+    import os
+    import torch
+    from golden_util import GOLDEN_DIR
+    from nuclear_sim_amd.statelog import StateLog, diagnostic_log_columns, reference_log_columns, derived_log_columns, result_log_columns
+    g = Golden("m1_oil_top_off_staggered")
+    z = np.load(os.path.join(GOLDEN_DIR, "log_m1_oil_top_off_staggered.npz"))
+    ref_names = [str(x) for x in z["names"]]; ref = z["log"]
+    n = 64
+    envs = []
+    for diag in (True, False):
+        env = _env(g, n=n)
+        f0, i0 = _host_state(env)
+        f, i, fm, im = g.split_state(g.state[0])
+        f0[fm, :] = f[fm, None]; i0[im, :] = i[im, None]
+        env.load_state_arrays(f0, i0)
+        env.set_step_kernel(1)
+        envs.append(env)
+    log = StateLog(envs[0], every=1, capacity=g.T, diagnostics=True)
+    assert envs[0].diagnostics is not None and envs[1].__dict__.get("diagnostics") is None
+    for t in range(g.T):
+        sp = None if np.isnan(g.setpoint[t]) else g.setpoint[t]
+        outs = [env.step(action=int(g.action[t]), magnitude=float(g.magnitude[t]), power_setpoint=sp, noise_z=float(g.noise_z[t])) for env in envs]
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), t
+        log.record(t + 1, (t + 1) * envs[0].dt)
+    (fa, ia), (fb, ib) = _host_state(envs[0]), _host_state(envs[1])
+    assert np.array_equal(fa.view(np.int64), fb.view(np.int64)) and np.array_equal(ia, ib)
+    tab = log.table(plants=[0, n - 1])
+    dc = diagnostic_log_columns()
+    others = set(reference_log_columns()) | set(derived_log_columns()) | set(result_log_columns())
+    assert len(dc) >= 75 and set(dc) <= set(tab.column_names) and set(dc) <= set(ref_names) and not set(dc) & others
+    for name in dc:
+        mine = tab[name].to_numpy().reshape(g.T, 2)
+        want = ref[:, ref_names.index(name)]
+        for lane in (0, 1):
+            ok = np.abs(mine[:, lane] - want) <= RTOL * np.abs(want) + 1e-9
+            assert ok.all(), (name, int(np.argmin(ok)), mine[~ok, lane][:3], want[~ok][:3])
+
+
 def test_largest_handle_uses_the_whole_32bit_offset_range():
     """One handle at the top of what npb_create accepts (1 000 000 plants: the last arena column starts 4.07 GB into
     the arena, 95 % of the kernel's 32-bit byte offsets): the first and the last wave must do exactly what the same
