@@ -50,10 +50,13 @@ enum {
 };
 /* Step-internal diagnostics (optional: npb_set_diagnostics): what the reference's state log holds per turbine stage from inside
  * the expansion (TurbineStage.get_state_dict, stage_system.py:379-393) and nothing later in the step can recover -- fourteen
- * values each, HP-1..8 then LP-1..6, column (NPB_DIAG_* + stage) of a [NPB_DIAG_DIM][pitch] fp64 buffer. */
+ * values each, HP-1..8 then LP-1..6, column (NPB_DIAG_* + stage) of a [NPB_DIAG_DIM][pitch] fp64 buffer -- and per steam generator. */
 enum {
   NPB_DIAG_STAGE_INLET_PRESSURE = 0, NPB_DIAG_STAGE_INLET_TEMPERATURE = 14, NPB_DIAG_STAGE_OUTLET_PRESSURE = 28,
-  NPB_DIAG_STAGE_OUTLET_TEMPERATURE = 42, NPB_DIAG_STAGE_POWER_OUTPUT = 56, NPB_DIAG_STAGE_LOADING_FACTOR = 70, NPB_DIAG_DIM = 84
+  NPB_DIAG_STAGE_OUTLET_TEMPERATURE = 42, NPB_DIAG_STAGE_POWER_OUTPUT = 56, NPB_DIAG_STAGE_LOADING_FACTOR = 70,
+  /* per steam generator (SteamGenerator.get_state_dict, steam_generator.py:943-985), three values each, SG-0..2 */
+  NPB_DIAG_SG_PRIMARY_INLET_TEMP = 84, NPB_DIAG_SG_PRIMARY_OUTLET_TEMP = 87, NPB_DIAG_SG_OVERALL_HTC = 90,
+  NPB_DIAG_SG_FEEDWATER_FLOW_RATE = 93, NPB_DIAG_DIM = 96
 };
 /* info["reactivity_components"] (sim.py:205; reactivity_model.py:77-125, pcm, the dict's insertion order).  Only the
  * reactor heat source has them, and only a caller that sets params.info_reactivity_components gets them: the info

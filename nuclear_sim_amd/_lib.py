@@ -21,7 +21,8 @@ MODE_FULL, MODE_PRIMARY_SG, MODE_PRIMARY = 0, 1, 2
 INFO_NRHO = 10   # include/npb.h NPB_INFO_NRHO
 # include/npb.h NPB_DIAG_*: step-internal diagnostics, fourteen turbine stages each (TurbineStage.get_state_dict, stage_system.py:379-393)
 DIAG_STAGE_VALUES = ("inlet_pressure", "inlet_temperature", "outlet_pressure", "outlet_temperature", "power_output", "loading_factor")
-DIAG_DIM = 14 * len(DIAG_STAGE_VALUES)
+DIAG_SG_VALUES = ("primary_inlet_temp", "primary_outlet_temp", "overall_htc", "feedwater_flow_rate")   # steam_generator.py:943-985
+DIAG_DIM = 14 * len(DIAG_STAGE_VALUES) + 3 * len(DIAG_SG_VALUES)
 REACTIVITY_COMPONENTS = ("control_rods", "boron", "doppler", "moderator_temp", "moderator_void", "pressure", "xenon", "samarium",
                          "fuel_depletion", "burnable_poisons")   # reactivity_model.py:87-121, NPB_RHO_*
 

@@ -215,7 +215,26 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
       NPD_STAMP(8 + i);
       npd_sg_result_t r;
       r.heat_transfer_rate = 0.0; r.steam_flow_rate = 0.0; r.thermal_efficiency = 0.0;
+#ifdef NPD_STEP1_DIAG
+      /* SteamGenerator.get_state_dict's step-internal values (steam_generator.py:943-985): the primary temperatures this step was
+       * given (:754-755), the overall heat-transfer coefficient from the pressure BEFORE the update (npd_sg_part1's own
+       * expression, :170-215 -> :289), and below the feedwater flow the fouled TSPs let through (:761 with :516-547) */
+      NPD_DIAG(st, NPB_DIAG_SG_PRIMARY_INLET_TEMP + i, c_inlet); NPD_DIAG(st, NPB_DIAG_SG_PRIMARY_OUTLET_TEMP + i, c_outlet);
+      {
+        double flow_factor = npd_powc(c_flow / P.sg_primary_design_flow, 0.8);
+        double h_primary = P.sg_primary_htc * flow_factor;
+        double pressure_factor = npd_powc(g.secondary_pressure / P.sg_design_pressure_secondary, 0.15);
+        double h_secondary = P.sg_secondary_htc * pressure_factor;
+        double r_primary = 1.0 / h_primary;
+        double r_wall = P.sg_tube_wall_thickness / P.sg_tube_conductivity;
+        double r_secondary = 1.0 / h_secondary;
+        NPD_DIAG(st, NPB_DIAG_SG_OVERALL_HTC + i, 1.0 / (r_primary + r_wall + r_secondary));
+      }
+#endif
       npd_sg_update(&g, &P, c_inlet, c_outlet, c_flow, demand, fwflow, actual_feedwater_temp, dt * 60, &r);
+#ifdef NPD_STEP1_DIAG
+      NPD_DIAG(st, NPB_DIAG_SG_FEEDWATER_FLOW_RATE + i, npd_pymin(fwflow, P.sg_design_feedwater_flow_per_sg * (1.0 / npd_sqrt(g.tsp_pressure_drop_ratio))));
+#endif
       sg_total_thermal += r.heat_transfer_rate; sg_total_steam += r.steam_flow_rate;
       sg_ap += g.secondary_pressure; sg_at += g.secondary_temperature; sg_aq += g.steam_quality;
       if (i == 0) sg_pressures[0] = g.secondary_pressure;

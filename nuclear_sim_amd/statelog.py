@@ -103,6 +103,29 @@ def derived_log_columns() -> Dict[str, tuple]:
             return m_
         out["secondary.steam_generator_SG-%d.tsp_average_deposit_thickness" % i] = (need, avg)
         out["secondary.steam_generator_SG-%d.tsp_maximum_deposit_thickness" % i] = (need, mx)
+    # steam generators: what SteamGenerator.get_state_dict recomputes from the fouling state when the log is taken
+    # (steam_generator.py:943-985 with _apply_tsp_flow_restrictions :516-547, _calculate_primary_flow_restriction :549-601 and
+    # _calculate_pump_energy_consumption :636-662, each called with the design flows of the default configuration: 500 / 500 /
+    # 5 700 kg/s, tube inner diameter 19.1 mm)
+    def primary_capacity(scale_mm):
+        d = 0.0191
+        eff = _max(d - 2.0 * (scale_mm / 1000.0), d * 0.5)
+        area_ratio = (np.pi * (eff / 2.0) ** 2) / (np.pi * (d / 2.0) ** 2)
+        pdr = 1.0 / ((eff / d) ** 4)
+        factor = np.where(pdr <= 3.0, area_ratio, area_ratio * (3.0 / pdr) ** 0.5)
+        return np.minimum(5700.0, 5700.0 * factor)
+    tsp_capacity = lambda pdr: np.minimum(500.0, 500.0 * (1.0 / np.sqrt(pdr)))
+    for i in range(3):
+        G, N = "sg[%d]." % i, "secondary.steam_generator_SG-%d." % i
+        out[N + "max_steam_flow_capacity"] = ((G + "tsp_pressure_drop_ratio",), tsp_capacity)
+        out[N + "max_feedwater_flow_capacity"] = ((G + "tsp_pressure_drop_ratio",), tsp_capacity)
+        out[N + "secondary_flow_restriction_factor"] = ((G + "tsp_pressure_drop_ratio",), lambda pdr: tsp_capacity(pdr) / 500.0)
+        out[N + "max_primary_flow_capacity"] = ((G + "scale_thickness",), primary_capacity)
+        out[N + "primary_flow_restriction_factor"] = ((G + "scale_thickness",), lambda sc: primary_capacity(sc) / 5700.0)
+        out[N + "fouling_energy_penalty_mw"] = ((G + "tsp_pressure_drop_ratio",), lambda pdr: 5.0 * (pdr - 1.0) * 0.5)
+        out[N + "total_pump_power_mw"] = ((G + "tsp_pressure_drop_ratio",), lambda pdr: 5.0 + 5.0 * (pdr - 1.0) * 0.5)
+        # steam_generator.py:251-290: the operating heat flux is the step's heat transfer over the design area, floored
+        out[N + "heat_flux"] = ((G + "heat_transfer_rate",), lambda q: _max(q / 5000.0, 5000.0))   # heat_transfer_area_per_sg = 5 000 m2
     # turbine stages, stage_system.py:379-393 (state dict) with :294-339 (update_degradation, the last thing a step does to a
     # stage): the logged efficiency and blade condition are recomputed there from the end-of-step degradation state.  The stage
     # system's own dict takes every stage's un-prefixed keys in turn (:1028-1030), so the turbine-level columns are LP-6's.
@@ -180,6 +203,9 @@ def diagnostic_log_columns() -> Dict[str, int]:
         for k, sn in enumerate(stage_names):
             out["secondary.turbine_%s.%s" % (sn, value)] = v * 14 + k
         out["secondary.turbine_SECONDARY-COMP-001-TURB.%s" % value] = v * 14 + 13
+    for v, value in enumerate(_lib.DIAG_SG_VALUES):       # SteamGenerator.get_state_dict (steam_generator.py:943-985)
+        for i in range(3):
+            out["secondary.steam_generator_SG-%d.%s" % (i, value)] = 14 * len(_lib.DIAG_STAGE_VALUES) + v * 3 + i
     known = set(json.load(open(_NAMES_PATH))["unmatched"])
     return {name: row for name, row in out.items() if name in known}
 

@@ -850,7 +850,7 @@ def test_nan_state_propagates_like_the_reference(oracle_lib):
 def test_state_log_matches_the_references_log(tmp_path):
     """the columnar state log sampled every step of the m1 data-gen run against the reference's OWN log of the
     same run (tests/golden/log_m1_oil_top_off_staggered.npz = `sim.state_manager.data`): every log column the map claims
-    (265 of the reference's 784 numeric columns, several per member, unit factors applied; 57 plain functions of end-of-step
+    (265 of the reference's 784 numeric columns, several per member, unit factors applied; 81 plain functions of end-of-step
     state; 15 keys of the step's secondary result) must hold the reference's values at every step, under the reference's
     column names."""
     import os
@@ -878,15 +878,18 @@ def test_state_log_matches_the_references_log(tmp_path):
     lc = reference_log_columns()
     assert len(lc) >= 250 and set(lc) <= set(tab.column_names) and set(lc) <= set(ref_names)
     derived = derived_log_columns()      # plain functions of the end-of-step state (pump factors, wear sums, SG system averages ...)
-    assert len(derived) >= 55 and set(derived) <= set(tab.column_names) and set(derived) <= set(ref_names) and not set(derived) & set(lc)
+    assert len(derived) >= 80 and set(derived) <= set(tab.column_names) and set(derived) <= set(ref_names) and not set(derived) & set(lc)
     results = result_log_columns()       # keys of the step's secondary result dict (heat-flow tracker, stage-system efficiency ...)
     assert len(results) >= 15 and set(results) <= set(tab.column_names) and set(results) <= set(ref_names) and not set(results) & (set(lc) | set(derived))
     checked = 0
     for name in list(lc) + list(derived) + list(results):
         mine = tab[name].to_numpy().reshape(g.T, 2)
         want = ref[:, ref_names.index(name)]
+        # 2.5 MW x (TSP pressure-drop ratio - 1): the ratio is an output member, kept as float in the arena (6e-8 of 1), so the
+        # penalty is good to 2e-7 MW of a 5 MW pump -- an absolute floor instead of 1e-6 of a value that is itself ~1e-7
+        floor = 1e-6 if name.endswith("fouling_energy_penalty_mw") else 1e-9
         for lane in (0, 1):
-            ok = np.abs(mine[:, lane] - want) <= RTOL * np.abs(want) + 1e-9
+            ok = np.abs(mine[:, lane] - want) <= RTOL * np.abs(want) + floor
             assert ok.all(), (name, int(np.argmin(ok)), mine[~ok, lane][:3], want[~ok][:3])
         checked += g.T
     assert checked > 10000
@@ -961,7 +964,8 @@ def test_other_feedwater_action_scenarios_run_on_the_oracle_track(oracle_lib, ac
 
 def test_state_log_diagnostics_match_the_references_log():
     """The step-internal columns of the state log (per turbine stage: inlet / outlet pressure and temperature, power output,
-    loading factor -- TurbineStage.get_state_dict, left over from inside the expansion): written by the diagnostics build of
+    loading factor -- TurbineStage.get_state_dict, left over from inside the expansion; per steam generator: the primary
+    temperatures it was given, the overall heat-transfer coefficient, the feedwater flow the fouled TSPs let through): written by the diagnostics build of
     the step kernel (npb_set_diagnostics), against the reference's own log of the m1 run at every step; and that build
     leaves every state column and output exactly as the plain one-wave kernel does."""
     import os
@@ -993,7 +997,7 @@ def test_state_log_diagnostics_match_the_references_log():
     tab = log.table(plants=[0, n - 1])
     dc = diagnostic_log_columns()
     others = set(reference_log_columns()) | set(derived_log_columns()) | set(result_log_columns())
-    assert len(dc) >= 75 and set(dc) <= set(tab.column_names) and set(dc) <= set(ref_names) and not set(dc) & others
+    assert len(dc) >= 95 and set(dc) <= set(tab.column_names) and set(dc) <= set(ref_names) and not set(dc) & others
     for name in dc:
         mine = tab[name].to_numpy().reshape(g.T, 2)
         want = ref[:, ref_names.index(name)]

@@ -68,7 +68,7 @@ def test_result_log_columns_are_the_references_own_result_keys():
 
 def test_derived_log_columns_on_the_oracle_replay(oracle_lib):
     """The columns that are plain functions of end-of-step state (pump factors, SG averages, TSP aggregates, the turbine
-    stages' efficiency and blade condition ...): the m1 run replayed on the CPU oracle, each formula evaluated on the oracle's
+    stages' efficiency and blade condition, the steam generators' flow capacities, restriction factors, pump power and heat flux ...): the m1 run replayed on the CPU oracle, each formula evaluated on the oracle's
     state after every step, against the reference's own log."""
     import os
     from golden_util import Golden, GOLDEN_DIR
@@ -84,7 +84,7 @@ def test_derived_log_columns_on_the_oracle_replay(oracle_lib):
     o.set_state(f0, i0)
     slot = {label: (kind, s) for kind, s, label, _p in SCHEMA.columns()}
     derived = derived_log_columns()
-    assert len(derived) >= 55 and set(derived) <= set(names)
+    assert len(derived) >= 80 and set(derived) <= set(names)
     for t in range(g.T):
         o.step(action=g.action[t], magnitude=g.magnitude[t], setpoint=g.setpoint[t], noise_z=g.noise_z[t], cw_temp=g.cooling[t])
         fs, is_ = o.state()
