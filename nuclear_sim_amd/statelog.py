@@ -84,6 +84,7 @@ def derived_log_columns() -> Dict[str, tuple]:
     errs = tuple("fw.previous_level_errors[%d]" % i for i in range(3))
     out[F + "level_control_avg_error"] = (errs, lambda a, b, c: (np.abs(a) + np.abs(b) + np.abs(c)) / 3)
     out[F + "level_control_max_error"] = (errs, lambda a, b, c: _max(_max(np.abs(a), np.abs(b)), np.abs(c)))
+    out[F + "diagnostics_maintenance_urgency"] = (("fw.overall_health_score",), lambda h: 1.0 - h)   # performance_monitoring.py:565
     for i in range(3):                                           # tsp_fouling_model.py:131-152
         need = tuple("sg[%d].tsp_%s[%d]" % (i, sp, l) for l in range(7) for sp in ("magnetite", "copper", "silica", "biological"))
 
