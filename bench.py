@@ -120,10 +120,12 @@ def c3_noise(lo, n, total):
     return np.ascontiguousarray(z.T)
 
 
-def step_kernel_name(n):
+def step_kernel_name(n, storage="f64"):
     """which step kernel npb_step launches for n plants (npb_kernels.hip, NPB_LAUNCHER(step)); NPB_STEP_KERNEL overrides"""
     forced = os.environ.get("NPB_STEP_KERNEL", "0")
     npad = (n + 63) // 64 * 64
+    if forced == "4" or (forced not in ("1", "2", "3") and npad > 57344 and npad * (8 if storage == "f64" else 4) > 90112 * 8):
+        return "npb_step_nt_kernel"
     if forced == "1" or (forced not in ("2", "3") and npad > 57344):
         return "npb_step_kernel"
     return "npb_step2_wide_kernel" if (npad <= 32768 and forced != "3") else "npb_step2_kernel"
@@ -151,7 +153,7 @@ def past_the_knee(n, device, storage, bytes_per_plant, K=40):
     torch.cuda.synchronize(dev)
     ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     achieved = bytes_per_plant * n / (ms * 1e-3) / 1e9
-    return {"plants": n, "kernel": step_kernel_name(n), "kernel_ms": ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS}
+    return {"plants": n, "kernel": step_kernel_name(n, storage), "kernel_ms": ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS}
 
 
 def main():
@@ -338,7 +340,7 @@ def main():
                                             "(measured writes ~200 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "
                                             "of the reads is served by the 256 MB Infinity Cache; NULL inputs (20 B/plant) are "
                                             "already excluded",
-                         "kernel": step_kernel_name(n) + (" + npb_maint_screen_kernel + npb_maint_kernel" if args.maintenance else ""),
+                         "kernel": step_kernel_name(n, args.storage) + (" + npb_maint_screen_kernel + npb_maint_kernel" if args.maintenance else ""),
                          "kernel_ms": kernel_ms},
             "preconditioning": {"ms": precondition_ms, "what": "a scratch handle of the same size stepped on the same inputs before the %d warm-up "
                                 "steps of the benchmarked one (whose state is not advanced), so that the timed steps run at the GPU's "

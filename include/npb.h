@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPB_VERSION 133 /* 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
+#define NPB_VERSION 134 /* 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
 #ifndef NPB_API
 #define NPB_API __attribute__((visibility("default")))
 #endif
@@ -177,7 +177,8 @@ NPB_API int npb_set_diagnostics(NpbHandle *h, double *buf, size_t pitch);
  * 0 = by batch size (default; also the environment variable NPB_STEP_KERNEL at handle creation), 1 = one wavefront per
  * 64 plants with an LDS-DMA staging pipeline, 2 = two wavefronts per 64 plants that own different subsystems (two builds of
  * it: the whole register file up to 32 768 plants, where a SIMD holds one wave anyway, 256 registers above), 3 = the
- * 256-register build at any size. */
+ * 256-register build at any size, 4 = the one-wavefront kernel with streaming (non-temporal) state stores, which 0 takes
+ * above ~90 000 plants of fp64 storage, where nothing a step writes is still cached when the next step reads it. */
 NPB_API int npb_set_step_kernel(NpbHandle *h, int variant);
 
 /* NuclearPlantSimulator.get_observation (sim.py:290-333) */

@@ -22,7 +22,7 @@ struct NpbHandle {
   double *convert;     /* one staging column (pitch doubles) used by get/set_field with host buffers */
   unsigned *maint_flags; /* NPB_NUM_PUMPS words per wave of plants: the maintenance screen's verdict (behind the staging column) */
   double *diag; size_t diag_pitch; /* npb_set_diagnostics: the caller's [NPB_DIAG_DIM][diag_pitch] buffer, or NULL */
-  int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel, 3 = its two-waves-per-SIMD build (npb_set_step_kernel) */
+  int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel, 3 = its two-waves-per-SIMD build, 4 = one-wave with streaming stores (npb_set_step_kernel) */
   npb_maint_table_t maint_table;   /* thresholds of the automatic maintenance (include/npb_maint.h) */
   bool maint_table_custom;         /* set through npb_set_maintenance_table: the table is then taken as it is */
   int *plan_dev;       /* npb_gather_fields: {column, sub, kind} per requested field, and the request it was built for */
@@ -176,7 +176,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   if (params) h->params = *params; else npb_params_default(&h->params);
   npb_maint_table_default(&h->maint_table);
   h->maint_table_custom = false;
-  { const char *e = getenv("NPB_STEP_KERNEL"); h->step_kernel = e ? atoi(e) : 0; if (h->step_kernel < 0 || h->step_kernel > 3) h->step_kernel = 0; }
+  { const char *e = getenv("NPB_STEP_KERNEL"); h->step_kernel = e ? atoi(e) : 0; if (h->step_kernel < 0 || h->step_kernel > 4) h->step_kernel = 0; }
   h->n_plants = n_plants; h->device = device;
   h->pitch = ((size_t)n_plants + 63) / 64 * 64;
   h->storage = storage; h->real_bytes = real_bytes;
@@ -221,7 +221,7 @@ int npb_set_params(NpbHandle *h, const npb_params_t *params) {
 }
 
 int npb_set_step_kernel(NpbHandle *h, int variant) {
-  if (!h || variant < 0 || variant > 3) return NPB_EINVAL;
+  if (!h || variant < 0 || variant > 4) return NPB_EINVAL;
   h->step_kernel = variant;
   return NPB_OK;
 }

@@ -112,24 +112,25 @@ __device__ __forceinline__ uint32_t npd_narrow_bits(const S &s, int j) {
   return 0u;
 }
 /* store the narrow column c of a section instance (col = its arena column) from NPD_NPC 32-bit words */
+template <bool NT = false>
 __device__ __forceinline__ void npd_st_store_narrow(const npd_stage_t &st, int col, uint32_t w0, uint32_t w1) {
 #ifdef NPB_BUILD_F32
-  *NPD_NP(uint32_t, col, 0) = w0;
+  npd_gstore<NT>(NPD_NP(uint32_t, col, 0), w0);
 #else
   typedef uint32_t npd_u32x2 __attribute__((ext_vector_type(2)));
   npd_u32x2 v; v.x = w0; v.y = w1;
-  *NPD_RPO(npd_u32x2, col, st.laner) = v;
+  npd_gstore<NT>(NPD_RPO(npd_u32x2, col, st.laner), v);
 #endif
 }
-template <int NF, int NO, int NI, typename S>
+template <int NF, int NO, int NI, typename S, bool NT = false>
 __device__ __forceinline__ void npd_st_store(const S &s, const npd_stage_t &st, int col0) {
   const double *d = reinterpret_cast<const double *>(&s);
   constexpr int NC = NF - NO, NNC = (NO + NI + NPD_NPC - 1) / NPD_NPC;
 #pragma unroll
-  for (int k = 0; k < NC; k++) *NPD_RP(col0 + k) = (npd_real_t)d[k];
+  for (int k = 0; k < NC; k++) npd_gstore<NT>(NPD_RP(col0 + k), (npd_real_t)d[k]);
 #pragma unroll
   for (int c = 0; c < NNC; c++)
-    npd_st_store_narrow(st, col0 + NC + c, npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1));
+    npd_st_store_narrow<NT>(st, col0 + NC + c, npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1));
 }
 template <int NF, int NO, int NI, int SID, typename S>
 __device__ __forceinline__ void npd_st_load(S &s, const npd_stage_t &st, int col0) {
@@ -147,17 +148,17 @@ __device__ __forceinline__ void npd_st_load(S &s, const npd_stage_t &st, int col
 #define NPD_ST_LOAD(T, stype, s, inst) \
   npd_st_load<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, NPB_##T##_F64_BASE, stype>(s, st, NPD_SEC_COL(T, inst))
 #define NPD_ST_STORE(T, stype, s, inst) \
-  npd_st_store<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype>(s, st, NPD_SEC_COL(T, inst))
+  npd_st_store<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype, NPD_NT>(s, st, NPD_SEC_COL(T, inst))
 /* only the narrow columns of a section (its outputs and int32 members) */
-template <int NF, int NO, int NI, typename S>
+template <int NF, int NO, int NI, typename S, bool NT = false>
 __device__ __forceinline__ void npd_st_store_narrow_cols(const S &s, const npd_stage_t &st, int col0) {
   constexpr int NC = NF - NO, NNC = (NO + NI + NPD_NPC - 1) / NPD_NPC;
 #pragma unroll
   for (int c = 0; c < NNC; c++)
-    npd_st_store_narrow(st, col0 + NC + c, npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1));
+    npd_st_store_narrow<NT>(st, col0 + NC + c, npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1));
 }
 #define NPD_ST_STORE_NARROW(T, stype, s, inst) \
-  npd_st_store_narrow_cols<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype>(s, st, NPD_SEC_COL(T, inst))
+  npd_st_store_narrow_cols<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype, NPD_NT>(s, st, NPD_SEC_COL(T, inst))
 /* ---- unchanged-column elision.  Measured on the bench workload (and on a reactor-heat-source batch): about a
  * quarter of the carried columns keep their exact bits over a step for every plant of a wave -- flags, status
  * codes, protection timers at rest, pump pressures and cavitation state in normal operation, the spare pump,
@@ -175,7 +176,7 @@ __device__ __forceinline__ long long npd_real_bits(double v) {
 #endif
 }
 /* SKIP0 .. SKIP1: carried members that were not loaded this step and must not be stored (wave-uniform `skip`) */
-template <int NF, int NO, int NI, int SKIP0 = 0, int SKIP1 = 0, typename S>
+template <int NF, int NO, int NI, int SKIP0 = 0, int SKIP1 = 0, typename S, bool NT = false>
 __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, const npd_stage_t &st, int col0, uint64_t fmask, bool skip = false) {
   const double *d = reinterpret_cast<const double *>(&s), *od = reinterpret_cast<const double *>(&old);
   constexpr int NC = NF - NO, NNC = (NO + NI + NPD_NPC - 1) / NPD_NPC;
@@ -186,9 +187,9 @@ __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, con
 #pragma unroll
     for (int k = SKIP0; k < SKIP1; k++) {
       if ((fmask >> k) & 1) {
-        if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) *NPD_RP(col0 + k) = (npd_real_t)d[k];
+        if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) npd_gstore<NT>(NPD_RP(col0 + k), (npd_real_t)d[k]);
       } else {
-        *NPD_RP(col0 + k) = (npd_real_t)d[k];
+        npd_gstore<NT>(NPD_RP(col0 + k), (npd_real_t)d[k]);
       }
     }
   }
@@ -196,9 +197,9 @@ __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, con
   for (int k = 0; k < NC; k++) {
     if (k >= SKIP0 && k < SKIP1) continue;
     if ((fmask >> k) & 1) {
-      if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) *NPD_RP(col0 + k) = (npd_real_t)d[k];
+      if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) npd_gstore<NT>(NPD_RP(col0 + k), (npd_real_t)d[k]);
     } else {
-      *NPD_RP(col0 + k) = (npd_real_t)d[k];
+      npd_gstore<NT>(NPD_RP(col0 + k), (npd_real_t)d[k]);
     }
   }
   /* narrow columns (outputs as float, flags, status codes, counters): always compared */
@@ -206,19 +207,19 @@ __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, con
   for (int c = 0; c < NNC; c++) {
     const uint32_t w0 = npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), w1 = npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1);
 #ifdef NPB_PROBE
-    npd_st_store_narrow(st, col0 + NC + c, w0, w1);
+    npd_st_store_narrow<NT>(st, col0 + NC + c, w0, w1);
 #else
     const uint32_t o0 = npd_narrow_bits<NF, NO, NI>(old, c * NPD_NPC), o1 = npd_narrow_bits<NF, NO, NI>(old, c * NPD_NPC + 1);
-    if (__builtin_amdgcn_ballot_w64(NPD_NPC == 2 ? ((w0 != o0) | (w1 != o1)) : (w0 != o0)) != 0) npd_st_store_narrow(st, col0 + NC + c, w0, w1);
+    if (__builtin_amdgcn_ballot_w64(NPD_NPC == 2 ? ((w0 != o0) | (w1 != o1)) : (w0 != o0)) != 0) npd_st_store_narrow<NT>(st, col0 + NC + c, w0, w1);
 #endif
   }
 }
 #define NPD_ST_STORE_ELIDE(T, stype, s, old, inst) \
-  npd_st_store_elide<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, 0, 0, stype>(s, old, st, NPD_SEC_COL(T, inst), NPD_ELIDE_##T##_F)
+  npd_st_store_elide<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, 0, 0, stype, NPD_NT>(s, old, st, NPD_SEC_COL(T, inst), NPD_ELIDE_##T##_F)
 /* the primary section: the point-kinetics members move only under ReactorHeatSource (npb_fields.h, NPB_PRIM_NKIN) */
 #define NPD_PRIM_KIN0 (NPB_PRIM_NCARRY - NPB_PRIM_NKIN)
 #define NPD_ST_STORE_ELIDE_PRIM(s, old) \
-  npd_st_store_elide<NPB_PRIM_NF64, NPB_PRIM_NOUT, NPB_PRIM_NI32, NPD_PRIM_KIN0, NPB_PRIM_NCARRY, npb_prim_t>( \
+  npd_st_store_elide<NPB_PRIM_NF64, NPB_PRIM_NOUT, NPB_PRIM_NI32, NPD_PRIM_KIN0, NPB_PRIM_NCARRY, npb_prim_t, NPD_NT>( \
       s, old, st, NPD_SEC_COL(PRIM, 0), NPD_ELIDE_PRIM_F, !kinetics)
 #define NPD_FB(stype, m) (1ull << NPB_F64_SLOT(stype, m))
 #define NPD_FBN(stype, m, n) ((((1ull << (n)) - 1)) << NPB_F64_SLOT(stype, m))
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_primary_kernel(
   }
 }
 
+#define NPD_NT false      /* state stores of the kernels below are plain ... */
 #define NPD_STEP1_KERNEL npb_step_kernel
 #include "npd_step1.h"
 #undef NPD_STEP1_KERNEL
@@ -376,6 +378,16 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_primary_kernel(
 #include "npd_step1.h"
 #undef NPD_STEP1_DIAG
 #undef NPD_STEP1_KERNEL
+/* ... and streaming in this one, for batches whose sweep is far past the 256 MB Infinity Cache: nothing a step writes is still
+ * cached when the next step reads it, and stores that do not allocate leave the caches to the loads (131 072 plants: 0.218 ->
+ * 0.196 ms; at 65 536, where a tenth of the arena still hits, they cost 4 %: profiles/r2_ab_streaming_state_stores.txt) */
+#undef NPD_NT
+#define NPD_NT true
+#define NPD_STEP1_KERNEL npb_step_nt_kernel
+#include "npd_step1.h"
+#undef NPD_STEP1_KERNEL
+#undef NPD_NT
+#define NPD_NT false
 
 #include "npd_step2.h"
 
@@ -684,6 +696,9 @@ extern "C" void NPB_LAUNCHER(field_get)(const void *arena, size_t npad, int col,
 extern "C" void NPB_LAUNCHER(field_set)(void *arena, size_t npad, int col, int sub, int kind, const void *in, int n, hipStream_t stream) {
   hipLaunchKernelGGL(npb_field_set_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (npd_real_t *)arena, npad, col, sub, kind, in, n);
 }
+/* fp64-storage plants above which the sweep of a step (4 221 B per plant) is so far past the 256 MB Infinity Cache that streaming
+ * state stores win (measured: even at 81 920, -5 % at 98 304, -10 % at 131 072); fp32 storage moves half the bytes */
+#define NPB_NT_STORE_ABOVE ((size_t)90112)
 extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad, void *arena,
                                 const int32_t *action, const double *magnitude, const double *setpoint,
                                 const double *noise_z, const double *cw_temp, double *obs, double *reward, uint8_t *done,
@@ -698,14 +713,20 @@ extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t n
    * test_the_two_step_kernels_agree).  The two-wave kernel
    * (npd_step2.h) fills the chip from half the batch and has the shorter critical path; once the one-wave kernel has a
    * wave for every SIMD (> ~57 k plants) its LDS-DMA pipeline wins (measured crossover).
-   * variant: 0 = by batch size, 1 = one wave per 64 plants, 2 = two waves.  The primary + steam-generator mode
-   * always takes the one-wave kernel. */
+   * variant: 0 = by batch size, 1 = one wave per 64 plants, 2 = two waves, 3 = their two-per-SIMD build, 4 = one wave with
+   * streaming state stores (what 0 picks once the sweep is far past the Infinity Cache).  The primary + steam-generator
+   * mode always takes a one-wave kernel. */
   if (P->mode == NPB_MODE_PRIMARY) {
     hipLaunchKernelGGL(npb_step_primary_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, obs, reward, done, trip_flags, info);
     return;
   }
-  if (variant == 0) variant = npad <= 57344 ? 2 : 1;
+  if (variant == 0) variant = npad <= 57344 ? 2 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1);
+  if (variant == 4) {
+    hipLaunchKernelGGL(npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
+                       noise_z, cw_temp, obs, reward, done, trip_flags, info);
+    return;
+  }
   if (variant == 3 && P->mode == NPB_MODE_FULL) variant = 2;
   else if (variant == 2 && P->mode == NPB_MODE_FULL && npad <= 32768) variant = 4;   /* the whole register file while one wave per SIMD is all there is */
   if (variant == 4)

@@ -77,6 +77,13 @@ typedef struct npd_stage_t {
                            * diagnostics build of the step kernel sets it, everywhere else the stores below fold away */
   size_t diag_pitch;
 } npd_stage_t;
+/* a state store, with the non-temporal bit in the streaming build of the one-wave kernel (NPD_NT, npb_kernels.hip) -- a template
+ * argument, not a run-time flag: two stores that differ only in that bit get merged into a plain one before inlining could fold */
+template <bool NT, typename PTR, typename V>
+__device__ __forceinline__ void npd_gstore(PTR ptr, V v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, ptr);
+  else *ptr = v;
+}
 #define NPD_DIAG(st, col, v) do { if ((st).diag) (st).diag[(size_t)(col) * (st).diag_pitch] = (v); } while (0)
 
 __device__ __forceinline__ void npd_stage_init(npd_stage_t &st, void *lds, npd_real_t *arena, size_t N, size_t block_base) {

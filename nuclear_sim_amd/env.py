@@ -185,8 +185,9 @@ class BatchedPlantEnv:
 
     # ------------------------------------------------------------------ helpers
     def set_step_kernel(self, variant: int) -> None:
-        """0 = by batch size (default), 1 = one-wave kernel, 2 = two-wave kernel, 3 = its 256-register build at any size; same
-        results to the last bit or two (include/npb.h)"""
+        """0 = by batch size (default), 1 = one-wave kernel, 2 = two-wave kernel, 3 = its 256-register build at any size, 4 = the
+        one-wave kernel with streaming state stores (what 0 takes above ~90 000 plants); same results to the last bit or
+        two (include/npb.h)"""
         _lib.check(self.L.npb_set_step_kernel(self._h, int(variant)), self._h)
 
     def enable_diagnostics(self, on: bool = True):
