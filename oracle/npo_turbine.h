@@ -313,7 +313,7 @@ NPO_FN void npo_turbine_update(npb_turb_t *t, npb_tstg_t *g, double steam_pressu
   /* ================= EnhancedTurbinePhysics.update_state  enhanced_physics.py:694-890 ========= */
   t->load_demand = load_demand;
   double pressure_stability_factor = npo_pressure_stability_factor(sg_pressures);
-  npo_stagesys_out_t ss;
+  npo_stagesys_out_t ss = {0};
   npo_stage_system_update(g, steam_pressure, steam_temperature, steam_flow, load_demand, pressure_stability_factor, dt, &ss);
   double stage_power_mw = ss.total_power;
   double applied_torque = stage_power_mw * 1e6 / (2 * NPO_PI * 3600 / 60);
