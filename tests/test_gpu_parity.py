@@ -536,15 +536,15 @@ def test_full_size_properties():
     np.testing.assert_allclose(o1[:, 14], sf / 1665, rtol=2e-7, atol=0)   # an output member: kept as float in the arena
 
 
-@pytest.mark.parametrize("storage", ["f64", "f32"])
-def test_full_size_against_the_oracle_on_a_sample(oracle_lib, storage):
+@pytest.mark.parametrize("storage,n,T", [("f64", 65536, 60), ("f32", 65536, 60), ("f64", 131072, 30)])
+def test_full_size_against_the_oracle_on_a_sample(oracle_lib, storage, n, T):
     """BASELINE config 3 (and, with fp32 state storage, config 5's size) at its full size -- 65 536 plants, the bench's workload (per-plant load-following setpoints, per-plant
     noise), the kernel and the arena placement the bench runs with -- against the CPU oracle on 192 of the plants spread over
     the whole batch (first, last, and the wave boundaries included): plants are independent, so the oracle steps just
     those with their own inputs.  Every state member, observation, reward and flag of the sampled plants.  (fp32 storage: against
-    the oracle with its state rounded to float after every step, the same algorithm.)"""
+    the oracle with its state rounded to float after every step, the same algorithm.)  At 131 072 plants npb_step takes the
+    streaming build of the one-wave kernel (two rounds of waves, state stores past the caches)."""
     import torch
-    n, T = 65536, 60
     rng = np.random.default_rng(2024)
     sample = np.unique(np.concatenate([[0, 1, 63, 64, 65, 127, n - 65, n - 64, n - 1], rng.choice(n, 183, replace=False)]))
     env = _env(n=n, noise_enabled=True, storage=storage)
