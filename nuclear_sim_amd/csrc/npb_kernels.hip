@@ -112,25 +112,27 @@ __device__ __forceinline__ uint32_t npd_narrow_bits(const S &s, int j) {
   return 0u;
 }
 /* store the narrow column c of a section instance (col = its arena column) from NPD_NPC 32-bit words */
-template <bool NT = false>
+#define NPD_STORE_REAL(col, v) npd_store_real<SM>(st, (col), (v))
+template <int SM = 0>
 __device__ __forceinline__ void npd_st_store_narrow(const npd_stage_t &st, int col, uint32_t w0, uint32_t w1) {
 #ifdef NPB_BUILD_F32
-  npd_gstore<NT>(NPD_NP(uint32_t, col, 0), w0);
+  npd_gstore<SM == 2>(NPD_NP(uint32_t, col, 0), w0);
 #else
   typedef uint32_t npd_u32x2 __attribute__((ext_vector_type(2)));
   npd_u32x2 v; v.x = w0; v.y = w1;
-  npd_gstore<NT>(NPD_RPO(npd_u32x2, col, st.laner), v);
+  if constexpr (SM >= 1) npd_store8<SM == 2>(st, (uint32_t)col, v);
+  else npd_gstore<false>(NPD_RPO(npd_u32x2, col, st.laner), v);
 #endif
 }
-template <int NF, int NO, int NI, typename S, bool NT = false>
+template <int NF, int NO, int NI, typename S, int SM = 0>
 __device__ __forceinline__ void npd_st_store(const S &s, const npd_stage_t &st, int col0) {
   const double *d = reinterpret_cast<const double *>(&s);
   constexpr int NC = NF - NO, NNC = (NO + NI + NPD_NPC - 1) / NPD_NPC;
 #pragma unroll
-  for (int k = 0; k < NC; k++) npd_gstore<NT>(NPD_RP(col0 + k), (npd_real_t)d[k]);
+  for (int k = 0; k < NC; k++) NPD_STORE_REAL(col0 + k, d[k]);
 #pragma unroll
   for (int c = 0; c < NNC; c++)
-    npd_st_store_narrow<NT>(st, col0 + NC + c, npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1));
+    npd_st_store_narrow<SM>(st, col0 + NC + c, npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1));
 }
 template <int NF, int NO, int NI, int SID, typename S>
 __device__ __forceinline__ void npd_st_load(S &s, const npd_stage_t &st, int col0) {
@@ -148,17 +150,17 @@ __device__ __forceinline__ void npd_st_load(S &s, const npd_stage_t &st, int col
 #define NPD_ST_LOAD(T, stype, s, inst) \
   npd_st_load<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, NPB_##T##_F64_BASE, stype>(s, st, NPD_SEC_COL(T, inst))
 #define NPD_ST_STORE(T, stype, s, inst) \
-  npd_st_store<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype, NPD_NT>(s, st, NPD_SEC_COL(T, inst))
+  npd_st_store<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype, NPD_SM>(s, st, NPD_SEC_COL(T, inst))
 /* only the narrow columns of a section (its outputs and int32 members) */
-template <int NF, int NO, int NI, typename S, bool NT = false>
+template <int NF, int NO, int NI, typename S, int SM = 0>
 __device__ __forceinline__ void npd_st_store_narrow_cols(const S &s, const npd_stage_t &st, int col0) {
   constexpr int NC = NF - NO, NNC = (NO + NI + NPD_NPC - 1) / NPD_NPC;
 #pragma unroll
   for (int c = 0; c < NNC; c++)
-    npd_st_store_narrow<NT>(st, col0 + NC + c, npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1));
+    npd_st_store_narrow<SM>(st, col0 + NC + c, npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1));
 }
 #define NPD_ST_STORE_NARROW(T, stype, s, inst) \
-  npd_st_store_narrow_cols<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype, NPD_NT>(s, st, NPD_SEC_COL(T, inst))
+  npd_st_store_narrow_cols<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, stype, NPD_SM>(s, st, NPD_SEC_COL(T, inst))
 /* ---- unchanged-column elision.  Measured on the bench workload (and on a reactor-heat-source batch): about a
  * quarter of the carried columns keep their exact bits over a step for every plant of a wave -- flags, status
  * codes, protection timers at rest, pump pressures and cavitation state in normal operation, the spare pump,
@@ -176,7 +178,7 @@ __device__ __forceinline__ long long npd_real_bits(double v) {
 #endif
 }
 /* SKIP0 .. SKIP1: carried members that were not loaded this step and must not be stored (wave-uniform `skip`) */
-template <int NF, int NO, int NI, int SKIP0 = 0, int SKIP1 = 0, typename S, bool NT = false>
+template <int NF, int NO, int NI, int SKIP0 = 0, int SKIP1 = 0, typename S, int SM = 0>
 __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, const npd_stage_t &st, int col0, uint64_t fmask, bool skip = false) {
   const double *d = reinterpret_cast<const double *>(&s), *od = reinterpret_cast<const double *>(&old);
   constexpr int NC = NF - NO, NNC = (NO + NI + NPD_NPC - 1) / NPD_NPC;
@@ -187,9 +189,9 @@ __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, con
 #pragma unroll
     for (int k = SKIP0; k < SKIP1; k++) {
       if ((fmask >> k) & 1) {
-        if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) npd_gstore<NT>(NPD_RP(col0 + k), (npd_real_t)d[k]);
+        if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) NPD_STORE_REAL(col0 + k, d[k]);
       } else {
-        npd_gstore<NT>(NPD_RP(col0 + k), (npd_real_t)d[k]);
+        NPD_STORE_REAL(col0 + k, d[k]);
       }
     }
   }
@@ -197,9 +199,9 @@ __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, con
   for (int k = 0; k < NC; k++) {
     if (k >= SKIP0 && k < SKIP1) continue;
     if ((fmask >> k) & 1) {
-      if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) npd_gstore<NT>(NPD_RP(col0 + k), (npd_real_t)d[k]);
+      if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) NPD_STORE_REAL(col0 + k, d[k]);
     } else {
-      npd_gstore<NT>(NPD_RP(col0 + k), (npd_real_t)d[k]);
+      NPD_STORE_REAL(col0 + k, d[k]);
     }
   }
   /* narrow columns (outputs as float, flags, status codes, counters): always compared */
@@ -207,19 +209,19 @@ __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, con
   for (int c = 0; c < NNC; c++) {
     const uint32_t w0 = npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), w1 = npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1);
 #ifdef NPB_PROBE
-    npd_st_store_narrow<NT>(st, col0 + NC + c, w0, w1);
+    npd_st_store_narrow<SM>(st, col0 + NC + c, w0, w1);
 #else
     const uint32_t o0 = npd_narrow_bits<NF, NO, NI>(old, c * NPD_NPC), o1 = npd_narrow_bits<NF, NO, NI>(old, c * NPD_NPC + 1);
-    if (__builtin_amdgcn_ballot_w64(NPD_NPC == 2 ? ((w0 != o0) | (w1 != o1)) : (w0 != o0)) != 0) npd_st_store_narrow<NT>(st, col0 + NC + c, w0, w1);
+    if (__builtin_amdgcn_ballot_w64(NPD_NPC == 2 ? ((w0 != o0) | (w1 != o1)) : (w0 != o0)) != 0) npd_st_store_narrow<SM>(st, col0 + NC + c, w0, w1);
 #endif
   }
 }
 #define NPD_ST_STORE_ELIDE(T, stype, s, old, inst) \
-  npd_st_store_elide<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, 0, 0, stype, NPD_NT>(s, old, st, NPD_SEC_COL(T, inst), NPD_ELIDE_##T##_F)
+  npd_st_store_elide<NPB_##T##_NF64, NPB_##T##_NOUT, NPB_##T##_NI32, 0, 0, stype, NPD_SM>(s, old, st, NPD_SEC_COL(T, inst), NPD_ELIDE_##T##_F)
 /* the primary section: the point-kinetics members move only under ReactorHeatSource (npb_fields.h, NPB_PRIM_NKIN) */
 #define NPD_PRIM_KIN0 (NPB_PRIM_NCARRY - NPB_PRIM_NKIN)
 #define NPD_ST_STORE_ELIDE_PRIM(s, old) \
-  npd_st_store_elide<NPB_PRIM_NF64, NPB_PRIM_NOUT, NPB_PRIM_NI32, NPD_PRIM_KIN0, NPB_PRIM_NCARRY, npb_prim_t, NPD_NT>( \
+  npd_st_store_elide<NPB_PRIM_NF64, NPB_PRIM_NOUT, NPB_PRIM_NI32, NPD_PRIM_KIN0, NPB_PRIM_NCARRY, npb_prim_t, NPD_SM>( \
       s, old, st, NPD_SEC_COL(PRIM, 0), NPD_ELIDE_PRIM_F, !kinetics)
 #define NPD_FB(stype, m) (1ull << NPB_F64_SLOT(stype, m))
 #define NPD_FBN(stype, m, n) ((((1ull << (n)) - 1)) << NPB_F64_SLOT(stype, m))
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_primary_kernel(
   }
 }
 
-#define NPD_NT false      /* state stores of the kernels below are plain ... */
+#define NPD_SM 1          /* store mode of the kernels below (npd_store_real): the one-wave kernel's own 8-byte stores ... */
 #define NPD_STEP1_KERNEL npb_step_kernel
 #include "npd_step1.h"
 #undef NPD_STEP1_KERNEL
@@ -378,16 +380,16 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_primary_kernel(
 #include "npd_step1.h"
 #undef NPD_STEP1_DIAG
 #undef NPD_STEP1_KERNEL
-/* ... and streaming in this one, for batches whose sweep is far past the 256 MB Infinity Cache: nothing a step writes is still
+/* ... with the non-temporal bit in this one, for batches whose sweep is far past the 256 MB Infinity Cache: nothing a step writes is still
  * cached when the next step reads it, and stores that do not allocate leave the caches to the loads (131 072 plants: 0.218 ->
  * 0.196 ms; at 65 536, where a tenth of the arena still hits, they cost 4 %: profiles/r2_ab_streaming_state_stores.txt) */
-#undef NPD_NT
-#define NPD_NT true
+#undef NPD_SM
+#define NPD_SM 2
 #define NPD_STEP1_KERNEL npb_step_nt_kernel
 #include "npd_step1.h"
 #undef NPD_STEP1_KERNEL
-#undef NPD_NT
-#define NPD_NT false
+#undef NPD_SM
+#define NPD_SM 0          /* ... and the two-wave kernels leave theirs to the compiler */
 
 #include "npd_step2.h"
 

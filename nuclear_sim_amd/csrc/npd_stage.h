@@ -77,7 +77,7 @@ typedef struct npd_stage_t {
                            * diagnostics build of the step kernel sets it, everywhere else the stores below fold away */
   size_t diag_pitch;
 } npd_stage_t;
-/* a state store, with the non-temporal bit in the streaming build of the one-wave kernel (NPD_NT, npb_kernels.hip) -- a template
+/* a state store, with the non-temporal bit in the streaming build of the one-wave kernel (NPD_SM, npb_kernels.hip) -- a template
  * argument, not a run-time flag: two stores that differ only in that bit get merged into a plain one before inlining could fold */
 template <bool NT, typename PTR, typename V>
 __device__ __forceinline__ void npd_gstore(PTR ptr, V v) {
@@ -105,6 +105,28 @@ __device__ __forceinline__ uint32_t npd_voff(uint32_t col, uint32_t pitch, uint3
 #define NPD_RPO(type, col, off) ((__attribute__((address_space(1))) type *)(st.f64b + npd_voff((uint32_t)(col), st.nr, (off))))
 #define NPD_RP(col) NPD_RPO(npd_real_t, col, st.laner)
 #define NPD_NP(type, col, sub) NPD_RPO(type, col, st.laner + (uint32_t)(sub) * 4u)
+
+/* an 8-byte state store to this lane's element of arena column `col`, written out in the SGPR-base form the addressing above is
+ * made for (measured -1 % against the compiler's own selection at 65 536 plants: profiles/r2_ab_state_store_form.txt); NT: with
+ * the non-temporal bit (the streaming build) */
+template <bool NT, typename V>
+__device__ __forceinline__ void npd_store8(const npd_stage_t &st, uint32_t col, V v) {
+  static_assert(sizeof(V) == 8, "8-byte stores only");
+  const uint32_t vo = npd_voff(col, st.nr, st.laner);
+  if constexpr (NT) asm volatile("global_store_dwordx2 %0, %1, %2 nt" :: "v"(vo), "v"(v), "s"(st.f64b) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(vo), "v"(v), "s"(st.f64b) : "memory");
+}
+
+/* a carried real of this lane to arena column col.  SM, the store mode of the kernel being compiled (NPD_SM below): 0 = left to the
+ * compiler (the two-wave kernels, fp32 storage), 1 = npd_store8 (the one-wave kernel: -1.2 % at 65 536 plants, where the two-wave
+ * builds lose 0.3-0.9 %: profiles/r2_ab_state_store_form.txt), 2 = npd_store8 with the non-temporal bit (its streaming build) */
+template <int SM>
+__device__ __forceinline__ void npd_store_real(const npd_stage_t &st, int col, double v) {
+#ifndef NPB_BUILD_F32
+  if constexpr (SM >= 1) { npd_store8<SM == 2>(st, (uint32_t)col, v); return; }
+#endif
+  npd_gstore<SM == 2>(NPD_RP(col), (npd_real_t)v);
+}
 
 #ifdef NPB_STAMPS
 /* diagnostic build: ticks this wave spent inside the staging pipeline's waits (lane 0 keeps the sum in LDS) */

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     NPD_ST_LOAD(CHEM, npb_chem_t, ch0, 0);
     NPD_ST_LOAD(PH, npb_ph_t, ph, 0);
     const npb_cond_t cd_old = cd; const npb_chem_t ch_old = ch, ch0_old = ch0; const npb_ph_t ph_old = ph;
-    npd_turbine_update<NPD_NT>(&t, st, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
+    npd_turbine_update<NPD_SM>(&t, st, sg_avg_pressure, sg_avg_temperature, sg_total_steam, sg_pressures, sg_system_availability,
                        load_demand, 0.007, dt / 60.0, &tr);
     NPD_STAMP(18);
     /* ================= phase 4: condenser (:591-621) ================= */

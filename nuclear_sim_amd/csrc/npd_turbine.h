@@ -174,13 +174,13 @@ typedef struct npd_stagesys_out_t {
  * updated value is written straight to its SoA column; every column is read before it is written and
  * never re-read within a step, so the staged copy does not need the update */
 #define NPD_TSTG_RD(member, k) NPD_LDS_REAL(0, NPB_F64_SLOT(npb_tstg_t, member) + (k))
-#define NPD_TSTG_WR(member, k, v) npd_gstore<NT>(NPD_RP(NPD_SEC_COL(TSTG, 0) + NPB_F64_SLOT(npb_tstg_t, member) + (k)), (npd_real_t)(v))
+#define NPD_TSTG_WR(member, k, v) npd_store_real<SM>(st, NPD_SEC_COL(TSTG, 0) + NPB_F64_SLOT(npb_tstg_t, member) + (k), (v))
 
 /* one stage's share of TurbineStage.update_degradation (stage_system.py:294-339) and of
  * MetalTemperatureTracker.update_temperatures (enhanced_physics.py:73-166, time constant 1 h, ambient 25 C);
  * both only touch stage k's own state, so running them right after stage k's expansion is the
  * reference's result */
-template <bool NT = false>
+template <int SM = 0>
 NPD_FN void npd_stage_post(const npd_stage_t &st, const double *stg, int k, double loading_factor,
                            double outlet_temperature, double dt, npd_stagesys_out_t *out) {
   NPD_TSTG_WR(stage_efficiency_degradation, k, NPD_TSTG_RD(stage_efficiency_degradation, k) + 1e-05 * dt);
@@ -232,7 +232,7 @@ NPD_FN double npd_stage_requested_outlet(int k, double current_pressure, double 
 
 /* TurbineStageSystem.update_state  stage_system.py:928-1016, reference order, one stage at a time.
  * Exact for every input; used when a lane of the wave leaves the fast path's assumptions. */
-template <bool NT = false>
+template <int SM = 0>
 NPD_FN void npd_stage_system_update_seq(const npd_stage_t &st, const double *stg, double inlet_pressure,
                                         double inlet_temperature, double inlet_flow, double load_demand,
                                         double pressure_stability_factor, double dt, npd_stagesys_out_t *out) {
@@ -257,7 +257,7 @@ NPD_FN void npd_stage_system_update_seq(const npd_stage_t &st, const double *stg
     NPD_DIAG(st, NPB_DIAG_STAGE_INLET_PRESSURE + k, current_pressure); NPD_DIAG(st, NPB_DIAG_STAGE_INLET_TEMPERATURE + k, current_temperature);
     NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_PRESSURE + k, so.outlet_pressure); NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_TEMPERATURE + k, so.outlet_temperature);
     NPD_DIAG(st, NPB_DIAG_STAGE_POWER_OUTPUT + k, so.power_output); NPD_DIAG(st, NPB_DIAG_STAGE_LOADING_FACTOR + k, so.loading_factor);
-    npd_stage_post<NT>(st, stg, k, so.loading_factor, so.outlet_temperature, dt, out);
+    npd_stage_post<SM>(st, stg, k, so.loading_factor, so.outlet_temperature, dt, out);
     current_pressure = so.outlet_pressure; current_temperature = so.outlet_temperature; current_flow = so.outlet_flow;
   }
   out->total_power = total_power * pressure_stability_factor;
@@ -279,7 +279,7 @@ NPD_FN void npd_stage_system_update_seq(const npd_stage_t &st, const double *stg
  *   pass C  walks the temperature / enthalpy chain with plain arithmetic and streams each stage's
  *           degradation and metal-temperature state.
  * Lanes that would take a rare branch make the whole wave use npd_stage_system_update_seq. */
-template <bool NT = false>
+template <int SM = 0>
 NPD_FN void npd_stage_system_update(const npd_stage_t &st, const double *stg, double inlet_pressure,
                                     double inlet_temperature, double inlet_flow, double load_demand,
                                     double pressure_stability_factor, double dt, npd_stagesys_out_t *out) {
@@ -319,7 +319,7 @@ NPD_FN void npd_stage_system_update(const npd_stage_t &st, const double *stg, do
     }
   }
   if (__builtin_amdgcn_ballot_w64(rare) != 0) { /* wave-uniform: any lane off the fast path */
-    npd_stage_system_update_seq<NT>(st, stg, inlet_pressure, inlet_temperature, inlet_flow, load_demand,
+    npd_stage_system_update_seq<SM>(st, stg, inlet_pressure, inlet_temperature, inlet_flow, load_demand,
                                 pressure_stability_factor, dt, out);
     return;
   }
@@ -383,7 +383,7 @@ NPD_FN void npd_stage_system_update(const npd_stage_t &st, const double *stg, do
     NPD_DIAG(st, NPB_DIAG_STAGE_INLET_PRESSURE + k, p_in); NPD_DIAG(st, NPB_DIAG_STAGE_INLET_TEMPERATURE + k, T_in);
     NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_PRESSURE + k, p_self[k]); NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_TEMPERATURE + k, T_out);
     NPD_DIAG(st, NPB_DIAG_STAGE_POWER_OUTPUT + k, main_power + extraction_power); NPD_DIAG(st, NPB_DIAG_STAGE_LOADING_FACTOR + k, loading_factor);
-    npd_stage_post<NT>(st, stg, k, loading_factor, T_out, dt, out);
+    npd_stage_post<SM>(st, stg, k, loading_factor, T_out, dt, out);
     T_in = T_out; sat_in = sat_self[k]; hg_in = hg_self[k];
   }
   NPD_STAMP(28);
@@ -604,7 +604,7 @@ NPD_FN void npd_turbine_protect(npb_turb_t *t, double stage_power_mw, double max
 
 }
 
-template <bool NT = false>
+template <int SM = 0>
 NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double steam_pressure,
                                double steam_temperature, double steam_flow,
                                const double *sg_pressures, int sg_system_availability, double load_demand,
@@ -616,7 +616,7 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
   t->load_demand = load_demand;
   double pressure_stability_factor = npd_pressure_stability_factor(sg_pressures);
   npd_stagesys_out_t ss;
-  npd_stage_system_update<NT>(st, (const double *)0, steam_pressure, steam_temperature, steam_flow, load_demand,
+  npd_stage_system_update<SM>(st, (const double *)0, steam_pressure, steam_temperature, steam_flow, load_demand,
                           pressure_stability_factor, dt, &ss);
   NPD_STAMP(15);
   double stage_power_mw = ss.total_power;
