@@ -730,8 +730,8 @@ extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t n
     return;
   }
   if (variant == 3 && P->mode == NPB_MODE_FULL) variant = 2;
-  else if (variant == 2 && P->mode == NPB_MODE_FULL && npad <= 32768) variant = 4;   /* the whole register file while one wave per SIMD is all there is */
-  if (variant == 4)
+  const bool wide = variant == 2 && P->mode == NPB_MODE_FULL && npad <= 32768;   /* the whole register file while one wave per SIMD is all there is */
+  if (wide)
     hipLaunchKernelGGL(npb_step2_wide_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
                        setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info);
   else if (variant == 2 && P->mode == NPB_MODE_FULL)

@@ -107,3 +107,30 @@ def test_create_storage_validates_its_argument():
     assert b"4 GiB" in L.npb_last_error(None)
     L.npb_handle_step_bytes_per_plant.restype = ctypes.c_size_t
     assert L.npb_handle_step_bytes_per_plant(None) == L.npb_step_bytes_per_plant()
+
+
+def test_bench_names_the_kernel_the_launcher_picks():
+    """bench.py labels its roofline with the step kernel npb_step launches for the batch size; the thresholds live in the
+    launcher (npb_kernels.hip, NPB_LAUNCHER(step)) and must not drift apart."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "nuclear_sim_amd", "csrc", "npb_kernels.hip")).read()
+    two_wave_up_to = int(re.search(r"variant = npad <= (\d+) \? 2", src).group(1))
+    nt_above = int(re.search(r"#define NPB_NT_STORE_ABOVE \(\(size_t\)(\d+)\)", src).group(1))
+    wide_up_to = int(re.search(r"const bool wide = .* npad <= (\d+);", src).group(1))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    old = os.environ.pop("NPB_STEP_KERNEL", None)
+    try:
+        assert bench.step_kernel_name(wide_up_to) == "npb_step2_wide_kernel"
+        assert bench.step_kernel_name(wide_up_to + 64) == "npb_step2_kernel"
+        assert bench.step_kernel_name(two_wave_up_to) == "npb_step2_kernel"
+        assert bench.step_kernel_name(two_wave_up_to + 64) == "npb_step_kernel"
+        assert bench.step_kernel_name(65536) == "npb_step_kernel"
+        assert bench.step_kernel_name(nt_above) == "npb_step_kernel"
+        assert bench.step_kernel_name(nt_above + 64) == "npb_step_nt_kernel"
+        assert bench.step_kernel_name(2 * nt_above, "f32") == "npb_step_kernel" and bench.step_kernel_name(2 * nt_above + 64, "f32") == "npb_step_nt_kernel"
+    finally:
+        if old is not None:
+            os.environ["NPB_STEP_KERNEL"] = old
