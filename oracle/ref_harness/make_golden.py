@@ -145,6 +145,14 @@ def scenarios():
     # dt = 1 run reaches (turbine/enhanced_physics.py:348-436); latched reasons recorded as a bit mask
     S.append(dict(name="c4_turbine_vibration_trip", steps=50, noise=True, noise_seed=9, every=1,
                   pokes={8: [("secondary_physics.turbine.rotor_dynamics.thermal_bow", 2.0)]}))
+    # C7: the turbine protection's remaining reachable trip (turbine/enhanced_physics.py:348-436): thermal stress (> 800 MPa needs a
+    # rotor 3 300 K over ambient -- unphysical, it is the branch that is wanted), and an overspeed excursion that the rotor model
+    # clamps.  Unreachable by construction: overspeed (the speed is clamped AT the 3 780 rpm the trip asks to exceed,
+    # rotor_dynamics.py), bearing metal temperature (40 C inlet + 1.5 x a rise capped at 50 K = 115 C against 120 C), low vacuum
+    # (the secondary side hands the protection the literal 0.007 MPa).
+    S.append(dict(name="c7_turbine_trips", steps=55, noise=True, noise_seed=9, every=1,
+                  pokes={6: [("secondary_physics.turbine.rotor_dynamics.rotor_speed", 5000.0)],
+                         40: [("secondary_physics.turbine.thermal_tracker.rotor_temperatures[0]", 3600.0)]}))
     # C5: NaN poked into the primary state THROUGH THE REFERENCE: check_for_nan_values resets five fields
     # (thermal_hydraulics.py:247-270); what the NaN did to the step it entered is part of the fixture
     S.append(dict(name="c5_nan_reset", steps=40, heat_source="reactor", equilibrium=(100.0, 95.0), every=1,
