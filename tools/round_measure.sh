@@ -14,6 +14,8 @@ python3 bench.py --maintenance --plants-per-gpu 32768 --no-cpu-baseline > "$OUT/
 echo "bench lines done"
 bash tools/profile_round.sh "$OUT/prof_64k" > "$OUT/prof_64k.log" 2>&1
 NPB_PROFILE_PLANTS=32768 bash tools/profile_round.sh "$OUT/prof_32k" > "$OUT/prof_32k.log" 2>&1
+# the streaming build of the one-wave kernel (what npb_step takes at 131 072 plants): kernel-trace stats only
+( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_131k" -- python3 "$OLDPWD/bench.py" --steps 100 --warmup 5 --no-cpu-baseline --plants-per-gpu 131072 > "$OUT/prof_131k.log" 2>&1 )
 echo "profiles done"
 NPB_STEP_KERNEL=1 python3 tools/phase_stamps.py 65536 10 > "$OUT/stamps1_64k.txt" 2>&1
 python3 tools/phase_stamps2.py 32768 5 > "$OUT/stamps2_32k.txt" 2>&1
