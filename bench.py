@@ -120,15 +120,24 @@ def c3_noise(lo, n, total):
     return np.ascontiguousarray(z.T)
 
 
-def step_kernel_name(n, storage="f64"):
-    """which step kernel npb_step launches for n plants (npb_kernels.hip, NPB_LAUNCHER(step)); NPB_STEP_KERNEL overrides"""
-    forced = os.environ.get("NPB_STEP_KERNEL", "0")
+def step_kernel_name(n, storage="f64", forced=None, mode="full"):
+    """which step kernel npb_step launches for n plants -- the selection rule of the launcher (npb_kernels.hip,
+    NPB_LAUNCHER(step)) restated, for labels made before anything ran; NPB_STEP_KERNEL / npb_set_step_kernel (`forced`)
+    override the choice by batch size.  The JSON line itself names what npb_debug_last_step_kernel reports after the run;
+    tests/test_abi.py and the GPU tests hold the two together."""
+    if forced is None:
+        forced = os.environ.get("NPB_STEP_KERNEL", "0")
+    variant = int(forced) if str(forced) in ("1", "2", "3", "4") else 0
     npad = (n + 63) // 64 * 64
-    if forced == "4" or (forced not in ("1", "2", "3") and npad > 57344 and npad * (8 if storage == "f64" else 4) > 90112 * 8):
+    if mode == "primary":
+        return "npb_step_primary_kernel"
+    if variant == 0:
+        variant = 2 if npad <= 57344 else (4 if npad * (8 if storage == "f64" else 4) > 90112 * 8 else 1)
+    if variant == 4:
         return "npb_step_nt_kernel"
-    if forced == "1" or (forced not in ("2", "3") and npad > 57344):
-        return "npb_step_kernel"
-    return "npb_step2_wide_kernel" if (npad <= 32768 and forced != "3") else "npb_step2_kernel"
+    if variant in (2, 3) and mode == "full":
+        return "npb_step2_wide_kernel" if (variant == 2 and npad <= 32768) else "npb_step2_kernel"
+    return "npb_step_kernel"
 
 
 def past_the_knee(n, device, storage, bytes_per_plant, K=40):
@@ -154,7 +163,8 @@ def past_the_knee(n, device, storage, bytes_per_plant, K=40):
     torch.cuda.synchronize(dev)
     ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     achieved = bytes_per_plant * n / (ms * 1e-3) / 1e9
-    return {"plants": n, "kernel": step_kernel_name(n, storage), "kernel_ms": ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS}
+    assert env.last_step_kernel() == step_kernel_name(n, storage), (env.last_step_kernel(), step_kernel_name(n, storage))
+    return {"plants": n, "kernel": env.last_step_kernel(), "kernel_ms": ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS}
 
 
 def main():
@@ -288,6 +298,8 @@ def main():
         ends[k].record()
     torch.cuda.synchronize(dev)
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    launched_kernel = env.last_step_kernel()       # what npb_step launched, asked of the library (npb_debug_last_step_kernel)
+    assert launched_kernel == step_kernel_name(n, args.storage), (launched_kernel, step_kernel_name(n, args.storage))
     # self-check: the same loop as the timed region over >= 0.6 s of launches (the driver's --steps 20 is a 2 ms
     # timed region; one scheduling hiccup there is a 10 % error), inputs cycled
     K_long = max(K, int(np.ceil(0.6 / max(elapsed / K, 1e-6))))
@@ -341,7 +353,7 @@ def main():
                                             "(measured writes ~200 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "
                                             "of the reads is served by the 256 MB Infinity Cache; NULL inputs (20 B/plant) are "
                                             "already excluded",
-                         "kernel": step_kernel_name(n, args.storage) + (" + npb_maint_screen_kernel + npb_maint_kernel" if args.maintenance else ""),
+                         "kernel": launched_kernel + (" + npb_maint_screen_kernel + npb_maint_kernel" if args.maintenance else ""),
                          "kernel_ms": kernel_ms},
             "preconditioning": {"ms": precondition_ms, "what": "a scratch handle of the same size stepped on the same inputs before the %d warm-up "
                                 "steps of the benchmarked one (whose state is not advanced), so that the timed steps run at the GPU's "

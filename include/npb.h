@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPB_VERSION 134 /* 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
+#define NPB_VERSION 140 /* 0.1.4: npb_debug_last_step_kernel, npb_info_dim / npb_obs_dim / npb_diag_dim, maintenance catalogs by index; 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
 #ifndef NPB_API
 #define NPB_API __attribute__((visibility("default")))
 #endif
@@ -82,6 +82,20 @@ NPB_API int npb_version(void);
 /* schema sizes (must equal NPB_TOTAL_F64 / NPB_TOTAL_I32 the caller was compiled against) */
 NPB_API int npb_num_f64(void);
 NPB_API int npb_num_i32(void);
+/* widths of the row-major output blocks of npb_step the library was built with (NPB_OBS_DIM / NPB_INFO_DIM / NPB_INFO_NRHO /
+ * NPB_DIAG_DIM).  A binding that allocates those buffers checks them at load: a caller sized for fewer info columns than the
+ * library writes would be overrun (the round-2 host crash). */
+NPB_API int npb_obs_dim(void);
+NPB_API int npb_info_dim(void);
+NPB_API int npb_info_nrho(void);
+NPB_API int npb_diag_dim(void);
+/* the catalogs of include/npb_maint.h by index (NULL past the end): threshold parameter names as the state log spells them,
+ * MaintenanceActionType values */
+NPB_API int npb_maint_num_params(void);
+NPB_API int npb_maint_num_actions(void);
+NPB_API const char *npb_maint_param_name(int k);
+NPB_API const char *npb_maint_action_name(int a);
+NPB_API int npb_maint_action_has_handler(int a);
 /* arena bytes per plant (fp64 storage): 8 * (carried fp64 members + ceil(narrow members / 2) per section instance) */
 NPB_API size_t npb_state_bytes(void);
 /* algorithmic HBM bytes of one plant-step: carried fp64 members read and written (16 B), int32 members read and
@@ -180,6 +194,21 @@ NPB_API int npb_set_diagnostics(NpbHandle *h, double *buf, size_t pitch);
  * 256-register build at any size, 4 = the one-wavefront kernel with streaming (non-temporal) state stores, which 0 takes
  * above ~90 000 plants of fp64 storage, where nothing a step writes is still cached when the next step reads it. */
 NPB_API int npb_set_step_kernel(NpbHandle *h, int variant);
+/* Which kernel the handle's last npb_step actually launched (NPB_KERNEL_NONE before the first step): the selection above is by
+ * batch size, mode, storage and override, and a test or a benchmark that means to exercise one kernel asserts it here instead
+ * of trusting the selection rule.  npb_step_kernel_name(id) = the kernel's symbol as rocprofv3 lists it. */
+enum {
+  NPB_KERNEL_NONE = 0,
+  NPB_KERNEL_STEP = 1,         /* npb_step_kernel: one wavefront per 64 plants */
+  NPB_KERNEL_STEP2_WIDE = 2,   /* npb_step2_wide_kernel: two wavefronts, the whole register file (<= 32 768 plants) */
+  NPB_KERNEL_STEP2 = 3,        /* npb_step2_kernel: two wavefronts, 256 registers (two waves per SIMD) */
+  NPB_KERNEL_STEP_NT = 4,      /* npb_step_nt_kernel: one wavefront, streaming state stores */
+  NPB_KERNEL_STEP_DIAG = 5,    /* npb_step_diag_kernel: one wavefront, step-internal diagnostics written (npb_set_diagnostics) */
+  NPB_KERNEL_STEP_PRIMARY = 6, /* npb_step_primary_kernel: NPB_MODE_PRIMARY */
+  NPB_KERNEL_COUNT_
+};
+NPB_API int npb_debug_last_step_kernel(const NpbHandle *h);
+NPB_API const char *npb_step_kernel_name(int kernel_id);
 
 /* NuclearPlantSimulator.get_observation (sim.py:290-333) */
 NPB_API int npb_observe(NpbHandle *h, double *obs, void *stream);

@@ -18,6 +18,7 @@ NPB_KIND_F64, NPB_KIND_I32 = 0, 1
 HEAT_CONSTANT, HEAT_REACTOR = 0, 1
 STORAGE_F64, STORAGE_F32 = 0, 1
 MODE_FULL, MODE_PRIMARY_SG, MODE_PRIMARY = 0, 1, 2
+OBS_DIM, INFO_DIM = 22, 17   # include/npb.h NPB_OBS_DIM / NPB_INFO_DIM; checked against the library in load()
 INFO_NRHO = 10   # include/npb.h NPB_INFO_NRHO
 # include/npb.h NPB_DIAG_*: step-internal diagnostics, fourteen turbine stages each (TurbineStage.get_state_dict, stage_system.py:379-393)
 DIAG_STAGE_VALUES = ("inlet_pressure", "inlet_temperature", "outlet_pressure", "outlet_temperature", "power_output", "loading_factor")
@@ -51,16 +52,21 @@ class NpbMaintTable(ctypes.Structure):
                 ("bearing", ctypes.c_int * MAINT_NPARAM)]
 
 
-def _maint_catalog():
-    import re
-    text = open(os.path.join(os.path.dirname(_HERE), "include", "npb_maint.h")).read()
-    params = re.findall(r'^\s*X\(\w+,\s*"(\w+)"\)', text, flags=re.M)
-    actions = re.findall(r'^\s*X\(\w+,\s*"(\w+)",\s*[01]\)', text, flags=re.M)
-    assert len(params) == MAINT_NPARAM and len(actions) == MAINT_NACT
-    return params, actions
+def __getattr__(name):
+    """MAINT_PARAMS / MAINT_ACTIONS: the catalogs of include/npb_maint.h, read from the library itself (npb_maint_param_name /
+    npb_maint_action_name) the first time they are asked for -- the package needs no header beside it."""
+    if name in ("MAINT_PARAMS", "MAINT_ACTIONS"):
+        L = load()
+        params = [L.npb_maint_param_name(k).decode() for k in range(L.npb_maint_num_params())]
+        actions = [L.npb_maint_action_name(a).decode() for a in range(L.npb_maint_num_actions())]
+        if len(params) != MAINT_NPARAM or len(actions) != MAINT_NACT:
+            raise NpbError("libnpb.so's maintenance catalogs (%d parameters, %d actions) are not the %d / %d this binding's "
+                           "NpbMaintTable is laid out for: rebuild" % (len(params), len(actions), MAINT_NPARAM, MAINT_NACT))
+        globals()["MAINT_PARAMS"], globals()["MAINT_ACTIONS"] = params, actions
+        return globals()[name]
+    raise AttributeError(name)
 
 
-MAINT_PARAMS, MAINT_ACTIONS = _maint_catalog()
 MAINT_COMPARISONS = ("greater_than", "less_than", "greater_equal", "less_equal", "equals", "not_equals")
 MAINT_PRIORITIES = {"LOW": 1, "MEDIUM": 2, "HIGH": 3, "CRITICAL": 4, "EMERGENCY": 5}
 MAINT_BEARINGS = {None: 0, "all": 0, "motor_bearings": 1, "pump_bearings": 2, "thrust_bearing": 3}
@@ -71,6 +77,7 @@ def maint_table_from_thresholds(thresholds: dict) -> "NpbMaintTable":
     the configuration, = StateManager.maintenance_thresholds['FWP-1'], in ITS order) -> table.  Names that do not
     resolve in a pump's state log are dropped, as the reference's scan drops them (state_manager.py:1371-1411)."""
     t = NpbMaintTable()
+    MAINT_PARAMS, MAINT_ACTIONS = __getattr__("MAINT_PARAMS"), __getattr__("MAINT_ACTIONS")
     for k in range(MAINT_NPARAM):
         t.rank[k] = -1
     for rank, (name, cfg) in enumerate(thresholds.items()):
@@ -123,6 +130,19 @@ def load():
     L.npb_set_params.argtypes = [vp, ctypes.POINTER(NpbParams)]
     L.npb_reset.argtypes = [vp, vp, vp]
     L.npb_set_step_kernel.argtypes = [vp, ci]
+    if hasattr(L, "npb_debug_last_step_kernel"):    # ABI 140
+        L.npb_debug_last_step_kernel.argtypes = [vp]
+        L.npb_step_kernel_name.argtypes = [ci]
+        L.npb_step_kernel_name.restype = ctypes.c_char_p
+        for f in ("npb_maint_param_name", "npb_maint_action_name"):
+            getattr(L, f).argtypes = [ci]
+            getattr(L, f).restype = ctypes.c_char_p
+        # the widths this binding allocates its output blocks with must be the library's: a library that writes more info
+        # columns than the caller allocated overruns the buffer (what crashed a round-2 test run on the host side)
+        got = (L.npb_obs_dim(), L.npb_info_dim(), L.npb_info_nrho(), L.npb_diag_dim())
+        if got != (OBS_DIM, INFO_DIM, INFO_NRHO, DIAG_DIM):
+            raise NpbError("libnpb.so writes obs / info / reactivity / diagnostics blocks of width %r, this binding allocates %r: "
+                           "rebuild the library or update nuclear_sim_amd/_lib.py" % (got, (OBS_DIM, INFO_DIM, INFO_NRHO, DIAG_DIM)))
     if hasattr(L, "npb_set_diagnostics"):     # (absent from builds older than ABI 133: tools/ab_kernel.py loads those)
         L.npb_set_diagnostics.argtypes = [vp, vp, ctypes.c_size_t]
     L.npb_set_maintenance_table.argtypes = [vp, ctypes.POINTER(NpbMaintTable)]

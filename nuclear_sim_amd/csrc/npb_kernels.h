@@ -7,11 +7,12 @@
 #include <stdint.h>
 #include "../../include/npb_params.h"
 #include "../../include/npb_maint.h"
+#include "../../include/npb.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
 #define NPB__DECL(prefix) \
-  void prefix##step(const npb_params_t *P, int n_plants, size_t npad, void *arena, const int32_t *action, \
+  int prefix##step(const npb_params_t *P, int n_plants, size_t npad, void *arena, const int32_t *action, \
                     const double *magnitude, const double *setpoint, const double *noise_z, const double *cw_temp, \
                     double *obs, double *reward, uint8_t *done, uint32_t *trip_flags, double *info, int variant, double *diag, size_t diag_pitch, \
                     hipStream_t stream); \

@@ -701,7 +701,7 @@ extern "C" void NPB_LAUNCHER(field_set)(void *arena, size_t npad, int col, int s
 /* fp64-storage plants above which the sweep of a step (4 221 B per plant) is so far past the 256 MB Infinity Cache that streaming
  * state stores win (measured: even at 81 920, -5 % at 98 304, -10 % at 131 072); fp32 storage moves half the bytes */
 #define NPB_NT_STORE_ABOVE ((size_t)90112)
-extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad, void *arena,
+extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad, void *arena,
                                 const int32_t *action, const double *magnitude, const double *setpoint,
                                 const double *noise_z, const double *cw_temp, double *obs, double *reward, uint8_t *done,
                                 uint32_t *trip_flags, double *info, int variant, double *diag, size_t diag_pitch, hipStream_t stream) {
@@ -709,7 +709,7 @@ extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t n
   if (diag && P->mode == NPB_MODE_FULL) {   /* npb_set_diagnostics: the diagnostics build of the one-wave kernel at any size */
     hipLaunchKernelGGL(npb_step_diag_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, cw_temp, obs, reward, done, trip_flags, info, diag, diag_pitch);
-    return;
+    return NPB_KERNEL_STEP_DIAG;
   }
   /* two kernels, one result (the same device functions in the same order per plant; tests/test_gpu_parity.py,
    * test_the_two_step_kernels_agree).  The two-wave kernel
@@ -717,29 +717,33 @@ extern "C" void NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t n
    * wave for every SIMD (> ~57 k plants) its LDS-DMA pipeline wins (measured crossover).
    * variant: 0 = by batch size, 1 = one wave per 64 plants, 2 = two waves, 3 = their two-per-SIMD build, 4 = one wave with
    * streaming state stores (what 0 picks once the sweep is far past the Infinity Cache).  The primary + steam-generator
-   * mode always takes a one-wave kernel. */
+   * mode always takes a one-wave kernel.  The return value names the kernel that was launched (npb_debug_last_step_kernel). */
   if (P->mode == NPB_MODE_PRIMARY) {
     hipLaunchKernelGGL(npb_step_primary_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, obs, reward, done, trip_flags, info);
-    return;
+    return NPB_KERNEL_STEP_PRIMARY;
   }
   if (variant == 0) variant = npad <= 57344 ? 2 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1);
   if (variant == 4) {
     hipLaunchKernelGGL(npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, cw_temp, obs, reward, done, trip_flags, info);
-    return;
+    return NPB_KERNEL_STEP_NT;
   }
-  if (variant == 3 && P->mode == NPB_MODE_FULL) variant = 2;
-  const bool wide = variant == 2 && P->mode == NPB_MODE_FULL && npad <= 32768;   /* the whole register file while one wave per SIMD is all there is */
-  if (wide)
+  const bool two_wave = (variant == 2 || variant == 3) && P->mode == NPB_MODE_FULL;
+  const bool wide = two_wave && variant == 2 && npad <= 32768;   /* the whole register file while one wave per SIMD is all there is; variant 3 = never */
+  if (wide) {
     hipLaunchKernelGGL(npb_step2_wide_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
                        setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info);
-  else if (variant == 2 && P->mode == NPB_MODE_FULL)
+    return NPB_KERNEL_STEP2_WIDE;
+  }
+  if (two_wave) {
     hipLaunchKernelGGL(npb_step2_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
                        setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info);
-  else
-    hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
-                       noise_z, cw_temp, obs, reward, done, trip_flags, info);
+    return NPB_KERNEL_STEP2;
+  }
+  hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
+                     noise_z, cw_temp, obs, reward, done, trip_flags, info);
+  return NPB_KERNEL_STEP;
 }
 extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, const npb_maint_table_t *T, size_t npad, void *arena, unsigned *wave_flags, hipStream_t stream) {
   dim3 block(NPB_WAVE);

@@ -47,6 +47,9 @@ INFO_COLUMNS = ("thermal_power", "reactivity", "electrical_power", "thermal_effi
                 "turbine_efficiency", "turbine_hp_power", "turbine_lp_power")
 
 
+assert len(INFO_COLUMNS) == _lib.INFO_DIM     # the info block's width, checked against the library itself in _lib.load()
+
+
 class HeatSourceNoise:
     """Per-plant pre-drawn heat-source noise, bit-identical to the reference's
     ``np.random.RandomState(seed).normal(0, sigma)`` stream (constant_heat_source.py:58-62,178):
@@ -134,9 +137,11 @@ class BatchedPlantEnv:
         self.mode = mode
         # info["reactivity_components"] (sim.py:205) exists under the reactor heat source only; asked for, the step writes the
         # ten terms behind the info columns (include/npb.h NPB_RHO_*)
-        # integrator="rk4" (BASELINE config 2; reactor heat source): the point-kinetics equations by classical RK4 sub-steps inside
-        # the step kernel instead of the reference's clipped explicit Euler -- no reference counterpart.  Explicit RK4 is stable on
-        # the prompt mode for a sub-step below 2.78 * Lambda / beta = 4.3 ms; 2 ms is taken.
+        # integrator="rk4" (BASELINE config 2; reactor heat source): the point-kinetics equations by fourth-order Runge-Kutta sub-steps
+        # of 2 ms inside the step kernel instead of the reference's clipped explicit Euler -- no reference counterpart.  Classical
+        # explicit RK4 while it is stable on the plant's prompt mode (h |rho - beta| / Lambda < 2, i.e. above about -350 pcm); a
+        # plant below that -- deep rod insertion, every scram -- takes the L-stable implicit method of the same order for that
+        # step (npd_primary.h), so the mode is stable over the whole clipped reactivity range [-0.9, 0.1].
         p.kinetics_rk4_substeps = {"reference": 0, "rk4": max(1, int(np.ceil(float(dt) / 0.002)))}[integrator]
         self._with_rho = bool(reactivity_components) and heat_source == "reactor"
         p.info_reactivity_components = int(self._with_rho)
@@ -189,6 +194,10 @@ class BatchedPlantEnv:
         one-wave kernel with streaming state stores (what 0 takes above ~90 000 plants); same results to the last bit or
         two (include/npb.h)"""
         _lib.check(self.L.npb_set_step_kernel(self._h, int(variant)), self._h)
+
+    def last_step_kernel(self) -> str:
+        """the kernel the last step() actually launched, by the name rocprofv3 lists it under ("" before the first step)"""
+        return self.L.npb_step_kernel_name(self.L.npb_debug_last_step_kernel(self._h)).decode()
 
     def enable_diagnostics(self, on: bool = True):
         """Have every following step also write the step-internal diagnostics (include/npb.h NPB_DIAG_*: per turbine stage inlet /

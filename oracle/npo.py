@@ -10,8 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-import re as _re
-INFO_DIM = int(_re.search(r"NPB_INFO_DIM = (\d+)", open(os.path.join(_HERE, "..", "include", "npb.h")).read()).group(1))
+INFO_DIM = None     # width of the info block, asked of the library itself in lib() (npo_info_dim)
 _LIB = None
 
 
@@ -38,6 +37,8 @@ def lib():
         L.npo_observe_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.npo_set_maint_table.argtypes = [ctypes.c_void_p]
         L.npo_reset_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        global INFO_DIM
+        INFO_DIM = L.npo_info_dim()
         _LIB = L
     return _LIB
 

@@ -16,6 +16,9 @@
 NPO_API int npo_plant_size(void) { return (int)sizeof(npo_plant_t); }
 NPO_API int npo_num_f64(void) { return NPB_TOTAL_F64; }
 NPO_API int npo_num_i32(void) { return NPB_TOTAL_I32; }
+/* width of the info block npo_step_batch writes per plant: the binding sizes its buffer with it (a binding that assumed
+ * fewer columns than the library writes is a host heap overrun, which is what crashed a round-2 test run) */
+NPO_API int npo_info_dim(void) { return NPB_INFO_DIM; }
 NPO_API int npo_params_size(void) { return (int)sizeof(npb_params_t); }
 NPO_API void npo_params_default(npb_params_t *p) { npb_params_default(p); }
 

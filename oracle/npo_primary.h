@@ -90,25 +90,69 @@ NPO_FN void npo_reactor_heat_source(npb_prim_t *s, const npb_params_t *P, double
   double rho = npo_clip(reactivity, -0.9, 0.1);
   if (P->kinetics_rk4_substeps > 0) {
     /* BASELINE config 2's "rk4" mode (no reference counterpart): dn/dt = (rho - beta) / Lambda * n + sum lambda_i C_i,
-     * dC_i/dt = beta_i / Lambda * n - lambda_i C_i, classical RK4, kinetics_rk4_substeps sub-steps per dt, reactivity held over
-     * the step as the reference holds it; no rate clips, the flux kept inside the reference's physical band at the end */
+     * dC_i/dt = beta_i / Lambda * n - lambda_i C_i, fourth-order Runge-Kutta, kinetics_rk4_substeps sub-steps per dt, reactivity
+     * held over the step as the reference holds it; no rate clips, the flux kept below the reference's ceiling.
+     * The system is linear with constant coefficients over a step, y' = A y, so any Runge-Kutta method advances it by a
+     * rational function of hA and only two things matter: the order on the slow (precursor) modes and what the function
+     * does to the prompt mode a = (rho - beta) / Lambda, up to -9e4 / s (rho is clipped to [-0.9, 0.1]; a scram is -0.5).
+     *   h a >= -2  classical explicit RK4 (R = the degree-4 Taylor polynomial, stable for h |a| < 2.78);
+     *   h a <  -2  (an insertion below about -350 pcm at the 2-ms sub-step, every scram) explicit RK4 would amplify the prompt
+     *              mode by up to 4e6 per sub-step, so the plant takes the L-stable singly diagonally implicit method of the same
+     *              order (five stages, gamma = 1/4: Hairer & Wanner, Solving ODEs II, table IV.6.5), whose stability
+     *              function is R(z) = P(z) / (1 - z / 4)^5 with P = the degree-4 truncation of (1 - z / 4)^5 e^z
+     *              = 1 - z/4 - z^2/8 + z^3/96 + 7 z^4/768: |R| < 1 on the whole left half plane, R(-inf) = 0.  A is an arrow
+     *              matrix (the groups couple only through the flux), so (I - gamma h A) x = r is solved in closed form.
+     * Both agree with the matrix exponential of the same system to 1e-12 after a step (tests/test_rk4_cpu.py, from +300 pcm down
+     * to the clip at -90 000 pcm). */
     const int ns = P->kinetics_rk4_substeps;
     const double h = dt / ns, a = (rho - BETA) / LAMBDA_PROMPT, b = (BETA / 6) / LAMBDA_PROMPT;
+    const double FLUX_CEILING = 1e14;   /* the reference's band (point_kinetics.py:100), applied per sub-step: a prompt-supercritical
+                                         * plant saturates there instead of overflowing to inf - inf inside the step */
     double n = s->neutron_flux, C[6];
     for (int i = 0; i < 6; i++) C[i] = s->precursors[i];
-    for (int it = 0; it < ns; it++) {
-      double kn[4], kc[4][6], yn = n, yc[6];
-      for (int i = 0; i < 6; i++) yc[i] = C[i];
-      for (int st = 0; st < 4; st++) {
-        double src = 0.0;
-        for (int i = 0; i < 6; i++) src += LAMBDA[i] * yc[i];
-        kn[st] = a * yn + src;
-        for (int i = 0; i < 6; i++) kc[st][i] = b * yn - LAMBDA[i] * yc[i];
-        const double w = (st == 2) ? h : 0.5 * h;
-        if (st < 3) { yn = n + w * kn[st]; for (int i = 0; i < 6; i++) yc[i] = C[i] + w * kc[st][i]; }
+    if (h * a < -2.0) {
+      const double gh = 0.25 * h;
+      double d[6], sld = 0.0;
+      for (int i = 0; i < 6; i++) { d[i] = 1.0 / (1.0 + gh * LAMBDA[i]); sld += LAMBDA[i] * d[i]; }
+      const double inv_pivot = 1.0 / (1.0 - gh * a - gh * gh * b * sld);   /* Schur complement of the arrow's head */
+      const double PC[5] = {1.0, -1.0 / 4.0, -1.0 / 8.0, 1.0 / 96.0, 7.0 / 768.0};
+      for (int it = 0; it < ns; it++) {
+        /* w = P(hA) y by Horner */
+        double wn = PC[4] * n, wc[6];
+        for (int i = 0; i < 6; i++) wc[i] = PC[4] * C[i];
+        for (int k = 3; k >= 0; k--) {
+          double src = 0.0;
+          for (int i = 0; i < 6; i++) src += LAMBDA[i] * wc[i];
+          const double tn = h * (a * wn + src);
+          for (int i = 0; i < 6; i++) wc[i] = PC[k] * C[i] + h * (b * wn - LAMBDA[i] * wc[i]);
+          wn = PC[k] * n + tn;
+        }
+        /* y <- (I - gamma h A)^-5 w */
+        for (int st = 0; st < 5; st++) {
+          double r = wn;
+          for (int i = 0; i < 6; i++) r += gh * (LAMBDA[i] * d[i] * wc[i]);
+          wn = r * inv_pivot;
+          for (int i = 0; i < 6; i++) wc[i] = (wc[i] + gh * b * wn) * d[i];
+        }
+        n = npo_pymin(wn, FLUX_CEILING);
+        for (int i = 0; i < 6; i++) C[i] = wc[i];
       }
-      n += h / 6.0 * (kn[0] + 2.0 * kn[1] + 2.0 * kn[2] + kn[3]);
-      for (int i = 0; i < 6; i++) C[i] += h / 6.0 * (kc[0][i] + 2.0 * kc[1][i] + 2.0 * kc[2][i] + kc[3][i]);
+    } else {
+      for (int it = 0; it < ns; it++) {
+        double kn[4], kc[4][6], yn = n, yc[6];
+        for (int i = 0; i < 6; i++) yc[i] = C[i];
+        for (int st = 0; st < 4; st++) {
+          double src = 0.0;
+          for (int i = 0; i < 6; i++) src += LAMBDA[i] * yc[i];
+          kn[st] = a * yn + src;
+          for (int i = 0; i < 6; i++) kc[st][i] = b * yn - LAMBDA[i] * yc[i];
+          const double w = (st == 2) ? h : 0.5 * h;
+          if (st < 3) { yn = n + w * kn[st]; for (int i = 0; i < 6; i++) yc[i] = C[i] + w * kc[st][i]; }
+        }
+        n += h / 6.0 * (kn[0] + 2.0 * kn[1] + 2.0 * kn[2] + kn[3]);
+        n = npo_pymin(n, FLUX_CEILING);
+        for (int i = 0; i < 6; i++) C[i] += h / 6.0 * (kc[0][i] + 2.0 * kc[1][i] + 2.0 * kc[2][i] + kc[3][i]);
+      }
     }
     s->neutron_flux = npo_clip(n, 1e8, 1e14);
     for (int i = 0; i < 6; i++) s->precursors[i] = npo_pymax(C[i], 0.0);

@@ -119,6 +119,7 @@ def test_bench_names_the_kernel_the_launcher_picks():
     two_wave_up_to = int(re.search(r"variant = npad <= (\d+) \? 2", src).group(1))
     nt_above = int(re.search(r"#define NPB_NT_STORE_ABOVE \(\(size_t\)(\d+)\)", src).group(1))
     wide_up_to = int(re.search(r"const bool wide = .* npad <= (\d+);", src).group(1))
+    assert re.search(r"const bool wide = two_wave && variant == 2 && npad <= \d+;", src)      # variant 3 never takes the wide build
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     old = os.environ.pop("NPB_STEP_KERNEL", None)
@@ -131,6 +132,16 @@ def test_bench_names_the_kernel_the_launcher_picks():
         assert bench.step_kernel_name(nt_above) == "npb_step_kernel"
         assert bench.step_kernel_name(nt_above + 64) == "npb_step_nt_kernel"
         assert bench.step_kernel_name(2 * nt_above, "f32") == "npb_step_kernel" and bench.step_kernel_name(2 * nt_above + 64, "f32") == "npb_step_nt_kernel"
+        # forced variants (npb_set_step_kernel / NPB_STEP_KERNEL): 1 and 4 at any size, 2 = the wide build only while it fits,
+        # 3 = the 256-register build at ANY size (the round-2 launcher folded 3 into 2 before deciding `wide`)
+        for n in (64, wide_up_to, wide_up_to + 64, 65536, 131072):
+            assert bench.step_kernel_name(n, forced="1") == "npb_step_kernel"
+            assert bench.step_kernel_name(n, forced="4") == "npb_step_nt_kernel"
+            assert bench.step_kernel_name(n, forced="3") == "npb_step2_kernel"
+            assert bench.step_kernel_name(n, forced="2") == ("npb_step2_wide_kernel" if n <= wide_up_to else "npb_step2_kernel")
+        os.environ["NPB_STEP_KERNEL"] = "3"
+        assert bench.step_kernel_name(64) == "npb_step2_kernel"
     finally:
+        os.environ.pop("NPB_STEP_KERNEL", None)
         if old is not None:
             os.environ["NPB_STEP_KERNEL"] = old

@@ -50,14 +50,40 @@ def test_construction_state_matches_reference():
     assert obs.shape == (1, 22) and np.all(np.isfinite(obs))
 
 
+# which kernel npb_step must have launched for a forced variant (include/npb.h npb_set_step_kernel) at a batch of <= 32 768
+# plants in full mode; 0 = by batch size
+KERNEL_OF_VARIANT = {0: "npb_step2_wide_kernel", 1: "npb_step_kernel", 2: "npb_step2_wide_kernel", 3: "npb_step2_kernel", 4: "npb_step_nt_kernel"}
+# fixtures replayed on EVERY shipped step kernel: reactor and constant heat sources, load following, pump trips, the data-gen
+# runner with maintenance, handler promotion, fuzzed states (flags flipped, maintenance under fire), reset(), pump start / stop,
+# pump trip reasons, turbine trips
+EVERY_KERNEL_FIXTURES = ("s2_reactor_actions", "s5_load_following", "s7_pump_trips", "m1_oil_top_off_staggered",
+                         "m8_handlers_inspection_overhaul_promotion", "z3_fuzzed_state_constant", "z13_fuzzed_state_running",
+                         "z22_fuzzed_maintenance", "r1_reset_steady", "c1_pump_stopping_starting", "c6_pump_trip_reasons", "c7_turbine_trips")
+
+
 @pytest.mark.parametrize("name", fixture_names())
 def test_hip_replays_golden(name):
     """Every reference-generated fixture replayed on the GPU (all 64 lanes of a wave run copies;
-    lane 0 and lane 63 are checked)."""
+    lane 0 and lane 63 are checked) with the kernel npb_step picks for the batch."""
+    _replay_golden(name, 0)
+
+
+@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("name", EVERY_KERNEL_FIXTURES)
+def test_hip_replays_golden_on_every_step_kernel(name, variant):
+    """The reference's fixtures against each shipped step kernel, not only the one a 64-plant batch selects: the one-wave
+    kernel (the headline's), the 256-register two-wave build (32 769 .. 57 344 plants) and the streaming-store build
+    (> 90 112 plants) forced on the same replay; which kernel really ran is asked of the library."""
+    _replay_golden(name, variant)
+
+
+def _replay_golden(name, variant):
     import torch
     g = Golden(name)
     n = 64
     env = _env(g, n=n)
+    env.set_step_kernel(variant)
+    want_kernel = KERNEL_OF_VARIANT[variant] if g.meta.get("enable_secondary", True) else "npb_step_primary_kernel"
     f0, i0 = _host_state(env)
     f, i, fm, im = g.split_state(g.state[0])
     f0[fm, :] = f[fm, None]; i0[im, :] = i[im, None]
@@ -87,6 +113,7 @@ def test_hip_replays_golden(name):
         cw = None if np.isnan(g.cooling[t]) else g.cooling[t]
         obs, rew, done, info = env.step(action=int(g.action[t]), magnitude=float(g.magnitude[t]), power_setpoint=sp,
                                         cooling_water_temp=cw, noise_z=float(g.noise_z[t]))
+        assert env.last_step_kernel() == want_kernel, (env.last_step_kernel(), want_kernel)
         obs = obs.cpu().numpy(); rew = rew.cpu().numpy(); done = done.cpu().numpy()
         for lane in (0, n - 1):
             np.testing.assert_allclose(obs[lane], g.obs[t], rtol=RTOL, atol=1e-12, err_msg="%s obs step %d" % (name, t))
@@ -200,14 +227,25 @@ def test_config2_reactor_and_sg_only_at_4096(oracle_lib, integrator):
     for key, v in equilibrium_state().items():
         name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
         ora.set(name, v, instance=inst, k=k)
-    rods = rng.uniform(85, 100, n)
+    # rk4 mode: rods down to 40 % (about -3 000 pcm) so that lanes of one wave sit on both sides of the explicit / implicit
+    # switch at h a = -2, and a tenth of the plants scrammed by hand at step 10 (rho = -0.5: h a = -101)
+    rods = rng.uniform(40 if integrator == "rk4" else 85, 100, n)
     env.set_field("prim.control_rod_position", rods); ora.set("prim.control_rod_position", rods)
+    scrammed = (rng.random(n) < 0.1).astype(np.int32)
     for t in range(T):
+        if t == 10 and integrator == "rk4":
+            env.set_field("prim.scram_status", scrammed); ora.set("prim.scram_status", scrammed)
         acts = rng.choice([0, 1, 2, 3, 4, 5, 8, 9, 10], size=n).astype(np.int32); mags = rng.uniform(0, 1, n)
         o_obs, o_rew, o_done, o_flags, o_info = ora.step(action=acts, magnitude=mags)
         obs, rew, done, info = env.step(action=acts, magnitude=mags)
         np.testing.assert_allclose(obs.cpu().numpy(), o_obs, rtol=RTOL, atol=1e-12, err_msg="obs step %d" % t)
         assert np.array_equal(done.cpu().numpy(), o_done)
+        assert np.array_equal(info["trip_flags"].cpu().numpy().astype(np.uint32), o_flags)
+        if integrator == "rk4":
+            assert not (o_flags & 4).any(), "NaN reset in rk4 mode at step %d" % t     # what an unstable sub-step ends in
+    if integrator == "rk4":
+        flux = env.get_field("prim.neutron_flux").cpu().numpy()
+        assert (flux[scrammed == 1] < 0.02e13).all() and (flux[scrammed == 1] > 1e8).all()      # prompt drop, then delayed decay
     f, i = _host_state(env)
     of, oi = ora.state_all()
     for kind, slot, label, _p in env_cols():
@@ -383,6 +421,7 @@ def test_the_two_step_kernels_agree(heat_source, storage):
         env = _env(n=n, dt=5.0 if heat_source == "constant" else 1.0, heat_source=heat_source, noise_enabled=True,
                    maintenance=heat_source == "constant", storage=storage)
         env.set_step_kernel(variant)
+        launched = set()
         r = np.random.default_rng(11)
         if heat_source == "reactor":
             from nuclear_sim_amd.env import equilibrium_state
@@ -397,7 +436,9 @@ def test_the_two_step_kernels_agree(heat_source, storage):
         outs = []
         for t in range(T):
             obs, rew, done, info = env.step(action=acts[t], magnitude=np.ones(n), power_setpoint=sp[t], noise_z=z[t])
+            launched.add(env.last_step_kernel())
             outs.append([x.cpu().numpy().copy() for x in (obs, rew, done, info["trip_flags"], info["electrical_power"], info["condenser_pressure"])])
+        assert launched == {KERNEL_OF_VARIANT[variant]}, (variant, launched)      # the kernel that was meant is the kernel that ran
         f, i = _host_state(env)
         return outs, f, i
 
@@ -536,15 +577,20 @@ def test_full_size_properties():
     np.testing.assert_allclose(o1[:, 14], sf / 1665, rtol=2e-7, atol=0)   # an output member: kept as float in the arena
 
 
-@pytest.mark.parametrize("storage,n,T", [("f64", 65536, 60), ("f32", 65536, 60), ("f64", 131072, 30)])
+@pytest.mark.parametrize("storage,n,T", [("f64", 65536, 60), ("f32", 65536, 60), ("f64", 131072, 30), ("f64", 40960, 60), ("f64", 32768, 40)])
 def test_full_size_against_the_oracle_on_a_sample(oracle_lib, storage, n, T):
     """BASELINE config 3 (and, with fp32 state storage, config 5's size) at its full size -- 65 536 plants, the bench's workload (per-plant load-following setpoints, per-plant
     noise), the kernel and the arena placement the bench runs with -- against the CPU oracle on 192 of the plants spread over
     the whole batch (first, last, and the wave boundaries included): plants are independent, so the oracle steps just
     those with their own inputs.  Every state member, observation, reward and flag of the sampled plants.  (fp32 storage: against
     the oracle with its state rounded to float after every step, the same algorithm.)  At 131 072 plants npb_step takes the
-    streaming build of the one-wave kernel (two rounds of waves, state stores past the caches)."""
+    streaming build of the one-wave kernel (two rounds of waves, state stores past the caches), at 40 960 the 256-register
+    build of the two-wave kernel (32 769 .. 57 344 plants), at 32 768 -- BASELINE config 4's share per GPU -- its
+    whole-register-file build; each run asserts that kernel."""
     import torch
+    import bench
+    want_kernel = {65536: "npb_step_kernel", 131072: "npb_step_nt_kernel", 40960: "npb_step2_kernel", 32768: "npb_step2_wide_kernel"}[n]
+    assert bench.step_kernel_name(n, storage, forced="0") == want_kernel
     rng = np.random.default_rng(2024)
     sample = np.unique(np.concatenate([[0, 1, 63, 64, 65, 127, n - 65, n - 64, n - 1], rng.choice(n, 183, replace=False)]))
     env = _env(n=n, noise_enabled=True, storage=storage)
@@ -562,6 +608,7 @@ def test_full_size_against_the_oracle_on_a_sample(oracle_lib, storage, n, T):
         sp = 90.0 + 10.0 * np.sin(2.0 * np.pi * t / period)
         z = rng.standard_normal(n)
         obs, rew, done, info = env.step(power_setpoint=sp, noise_z=z)
+        assert env.last_step_kernel() == want_kernel
         o_obs, o_rew, o_done, o_flags, _ = ora.step(setpoint=sp[sample], noise_z=z[sample])
         if narrow:
             ora.round_state_f32()

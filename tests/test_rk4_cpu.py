@@ -1,8 +1,9 @@
 """CPU: BASELINE config 2's "rk4" mode (params.kinetics_rk4_substeps) on the oracle.  The reference has no such integrator, so
 there is nothing to pin it against; what can be checked is that it integrates the point-kinetics equations it claims to:
-agreement of a step with the closed-form solution of the same linear system (prompt jump and delayed rise included), and
-the stability bound of the sub-step."""
+agreement of a step with the closed-form solution of the same linear system (prompt jump and delayed rise included) over the
+whole clipped reactivity range -- rod withdrawal, deep insertion, SCRAM -- and that nothing overflows above prompt critical."""
 import numpy as np
+import pytest
 
 BETA, LAMBDA_PROMPT = 0.0065, 1e-5
 LAMBDA = [0.077, 0.311, 1.40, 3.87, 1.40, 0.195]
@@ -54,12 +55,93 @@ def test_one_step_against_the_matrix_exponential(oracle_lib):
     assert 0.0 < rho < 0.5 * BETA and 0.0 < o.get("prim.neutron_flux") / n0 - BETA / (BETA - rho) < 0.02
 
 
-def test_sub_step_below_the_stability_bound_is_needed(oracle_lib):
-    """explicit RK4 on the prompt mode ((beta - rho) / Lambda ~ 650 / s) is stable for h < 2.78 / 650 = 4.3 ms: 40 sub-steps of a
-    0.1-s step are inside the bound and agree with 3 200 to rounding; the caller picks the count (BatchedPlantEnv does: ceil(dt / 2 ms))"""
+def test_sub_step_count_does_not_matter_once_it_resolves_the_slow_modes(oracle_lib):
+    """40 sub-steps of a 0.1-s step agree with 3 200 to rounding (explicit RK4 inside its stability bound h |a| < 2.78)"""
     def flux(ns):
         o = _plant(oracle_lib, ns, 0.1, rods=97.0); o.step(); return o.get("prim.neutron_flux")
     assert abs(flux(40) / flux(3200) - 1.0) < 1e-11
+
+
+def _poke_rho(o, want_pcm):
+    """move the plant's total reactivity to want_pcm by the boron term alone (-10 pcm per ppm, reactivity_model.py:144-160)"""
+    o2 = o.get("prim.boron_concentration")
+    have = o.get("prim.total_reactivity_pcm")
+    return o2 + (have - want_pcm) / 10.0
+
+
+@pytest.mark.parametrize("dt", [0.1, 1.0])
+@pytest.mark.parametrize("case", ["-1000pcm", "-5000pcm", "-50000pcm", "clip", "scram", "+300pcm", "switch"])
+def test_deep_insertion_and_scram_against_the_matrix_exponential(oracle_lib, case, dt):
+    """Rod insertion and SCRAM: below about -350 pcm (h a < -2 at the 2-ms sub-step) explicit RK4 is past its stability bound --
+    at a scram (rho = -0.5) it would amplify the prompt mode 4e6-fold per sub-step, run the flux into the 1e14 ceiling on an
+    INSERTION and trip the NaN reset -- so those plants take the L-stable implicit method of the same order (npo_primary.h).
+    Each case against the closed-form solution of the same linear system over one step, prompt drop included."""
+    ns = int(np.ceil(dt / 0.002))
+    o = _plant(oracle_lib, ns, dt, rods=95.0)
+    # a first step at rho = 0 settles total_reactivity_pcm; then the reactivity is moved where the case wants it
+    o.step()
+    if case == "scram":
+        o.set("prim.scram_status", 1)
+        want = -0.5
+    else:
+        pcm = {"-1000pcm": -1000.0, "-5000pcm": -5000.0, "-50000pcm": -50000.0, "clip": -120000.0, "+300pcm": 300.0,
+               "switch": -349.0}[case]      # "switch": just on the explicit side of h a = -2 (dt / ns = 2 ms: -350 pcm)
+        # boron moves the Doppler / moderator terms by nothing: one poke lands within a pcm; iterate twice for the exact value
+        for _ in range(3):
+            o.set("prim.boron_concentration", _poke_rho(o, pcm))
+            probe = oracle_lib.OraclePlants(1, o.params)
+            f, i = o.state()
+            probe.set_state(f, i)
+            probe.step()
+            o.set("prim.total_reactivity_pcm", probe.get("prim.total_reactivity_pcm"))
+        want = None
+    n0 = o.get("prim.neutron_flux"); c0 = np.array([o.get("prim.precursors", k=i) for i in range(6)])
+    o.step()
+    flags_nan_reset = 4
+    rho = o.get("prim.reactivity")
+    if want is not None:
+        rho = want          # ReactorState.reactivity keeps the model's total; the kinetics saw the scram's -0.5 (reactor_heat_source.py:77-79)
+    elif case != "clip":
+        assert abs(rho * 1e5 - pcm) < abs(pcm) * 0.02 + 2.0, (rho, pcm)
+    n, c = _exact(n0, c0, min(max(rho, -0.9), 0.1), dt)
+    got_n = o.get("prim.neutron_flux"); got_c = np.array([o.get("prim.precursors", k=i) for i in range(6)])
+    assert np.isfinite(got_n)
+    if case not in ("+300pcm",):
+        assert got_n < n0, "an insertion must lower the flux"
+    np.testing.assert_allclose(got_n, max(n, 1e8), rtol=1e-9)
+    np.testing.assert_allclose(got_c, c, rtol=1e-9)
+
+
+def test_scram_in_rk4_mode_does_not_trip_the_nan_reset(oracle_lib):
+    """what the explicit integrator did on a scram: flux to the ceiling, NaN reset on the following step (flags SCRAM | NAN_RESET,
+    flux back at 1e12, fuel temperature 600).  Twenty steps after a scram: monotone decay on the delayed-neutron time scale."""
+    o = _plant(oracle_lib, 500, 1.0, rods=95.0)
+    o.step()
+    o.set("prim.scram_status", 1)
+    last = o.get("prim.neutron_flux")
+    for t in range(20):
+        _obs, _rew, _done, flags, _info = o.step()
+        assert int(flags[0]) & 4 == 0, "NaN reset at step %d" % t
+        now = o.get("prim.neutron_flux")
+        assert now < last and now > 1e8
+        last = now
+    assert last < 0.01 * 1e13        # prompt drop to beta / (beta + 0.5) = 1.3 %, then the slowest group's 13-s period
+
+
+def test_prompt_supercritical_saturates_instead_of_overflowing(oracle_lib):
+    """rho well above beta: e^(a dt) is beyond fp64 inside one step; the flux is held at the reference's ceiling per sub-step, so
+    the step ends at 1e14 with finite precursors -- not at inf - inf"""
+    o = _plant(oracle_lib, 50, 0.1, rods=95.0)
+    o.step()
+    o.set("prim.boron_concentration", o.get("prim.boron_concentration") - 900.0)    # about +9 000 pcm
+    _obs, _rew, done, flags, _info = o.step()
+    assert o.get("prim.neutron_flux") == 1e14 and int(flags[0]) == 3 and done[0] == 1      # saturated; over-power scram fired (scram_logic.py:24-61)
+    assert all(np.isfinite(o.get("prim.precursors", k=i)) for i in range(6))
+    last = 1e14
+    for _ in range(5):       # the scrammed plant decays from there, with the precursors the excursion left
+        _obs, _rew, _done, flags, _info = o.step()
+        assert int(flags[0]) & 4 == 0 and o.get("prim.neutron_flux") < last
+        last = o.get("prim.neutron_flux")
 
 
 def test_zero_substeps_is_the_reference_update(oracle_lib):
