@@ -236,7 +236,10 @@ class BatchedPlantEnv:
             t = x.to(device=self.device, dtype=dtype).expand(self.n).contiguous()
         else:
             a = np.asarray(x)
-            t = torch.as_tensor(np.array(np.broadcast_to(a, (self.n,))), dtype=dtype).to(self.device)
+            if a.size == 1:      # the same value for every plant: filled on the device, nothing to copy
+                t = torch.full((self.n,), a.reshape(()).item(), dtype=dtype, device=self.device)
+            else:
+                t = torch.as_tensor(np.array(np.broadcast_to(a, (self.n,))), dtype=dtype).to(self.device)
         self._keep.append(t)
         return t
 

@@ -8,7 +8,7 @@ dictionaries into object state (feedwater/physics.py:185-437, feedwater/pump_sys
 For 10^5 - 10^6 plants that dictionary shuffling dominates set-up, so this module produces the same
 state directly as struct-of-arrays columns for ``BatchedPlantEnv.set_fields``:
 
-    fields = action_test_fields("oil_top_off", seeds)        # {column: array[n]}
+    fields = action_test_fields("oil_top_off", seeds)        # {column: array [n], or [1] where every plant has the same value}
     env = BatchedPlantEnv(n, dt=5.0, noise_enabled=True, maintenance=True); env.set_fields(fields)
 
 All ten actions the composer maps to the feedwater subsystem are covered (``FEEDWATER_ACTIONS``); their catalog
@@ -88,24 +88,9 @@ def randomized_oil_top_off_levels(seeds: Sequence[int]) -> np.ndarray:
     """pump_oil_levels[n, 4] of ``get_randomized_feedwater_conditions("oil_top_off", seed)`` for every seed
     (randomization_utils.py:799-841, 844-895, 897-917).  The reference draws from the stdlib generator seeded
     with the scenario seed: one ``random()`` picks the weighted scenario, one ``uniform()`` the first pump's
-    level, and "preserve_pattern" scales all four levels by the same factor.  The stdlib generator is used
-    here too, so the draws are the reference's by construction (~10 us per seed)."""
-    base = OIL_TOP_OFF_CONDITIONS["pump_oil_levels"]
-    total = sum(p for p, _lo, _hi in OIL_TOP_OFF_SCENARIOS)
-    out = np.empty((len(seeds), NUM_PUMPS))
-    for row, seed in enumerate(seeds):
-        r = random.Random(int(seed))
-        rand_val = r.random()
-        cumulative, pick = 0.0, OIL_TOP_OFF_SCENARIOS[-1]
-        for sc in OIL_TOP_OFF_SCENARIOS:
-            cumulative += sc[0] / total
-            if rand_val <= cumulative:
-                pick = sc
-                break
-        value = r.uniform(pick[1], pick[2])
-        scale_factor = value / base[0]
-        out[row] = [v * scale_factor for v in base]
-    return out
+    level, and "preserve_pattern" scales all four levels by the same factor.  The generator's streams come from
+    libnpb.so for all seeds at once (include/npb_seeds.h; checked against random.Random itself)."""
+    return np.ascontiguousarray(randomized_conditions_columns("oil_top_off", seeds)["pump_oil_levels"])
 
 
 def _col(v, n):
@@ -120,8 +105,15 @@ def feedwater_fields(ic: Dict[str, object], n: int, lubrication_effectiveness: f
     the value the lubrication system computed at construction, before any initial condition is applied
     (pump_lubrication.py:204-222) -- it enters the performance factors."""
     g = dict(FEEDWATER_IC_DEFAULTS); g.update(ic)
-    per_pump = lambda k: np.broadcast_to(np.asarray(g[k], dtype=np.float64), (n, NUM_PUMPS))
-    scalar = lambda k: np.broadcast_to(np.asarray(g[k], dtype=np.float64), (n,))            # one value per plant
+    # a value that is the same for every plant stays ONE row here and ONE element in the result (shape (1,) instead of (n,)):
+    # set_fields fills such a column on the device, and a batch of 10^5 plants does not spend its set-up time copying constants
+    def per_pump(k):
+        a = np.asarray(g[k], dtype=np.float64)
+        return np.broadcast_to(a, (1, NUM_PUMPS)) if a.ndim <= 1 else a
+    def scalar(k):                                                                           # one value per plant
+        a = np.asarray(g[k], dtype=np.float64)
+        return a.reshape(1) if a.ndim == 0 else a
+    lubrication_effectiveness = np.asarray(lubrication_effectiveness, dtype=np.float64)
     f: Dict[object, np.ndarray] = {}
     motor, pumpb, thrust, seals = (per_pump(k) for k in ("motor_bearing_wear", "pump_bearing_wear", "thrust_bearing_wear", "seal_face_wear"))
     # _calculate_pump_performance_factors(cavitation_damage=0.0)  pump_lubrication.py:1412-1478
@@ -136,7 +128,8 @@ def feedwater_fields(ic: Dict[str, object], n: int, lubrication_effectiveness: f
     # _initialize_pumps: demand from the SG steam flows, shared over the three duty pumps, speed from the pump law
     flow_factor = np.maximum(0.5, 1.0 - flow_degradation / 100.0)                     # pump_lubrication.py:230-233
     degradation_factor = np.maximum(0.5, (0.0 + flow_factor[:, 0] + flow_factor[:, 1] + flow_factor[:, 2] + flow_factor[:, 3]) / NUM_PUMPS)
-    sg_flows = np.broadcast_to(np.asarray(g["sg_steam_flows"], dtype=np.float64), (n, NUM_SG))
+    sg_flows = np.asarray(g["sg_steam_flows"], dtype=np.float64)
+    sg_flows = np.broadcast_to(sg_flows, (1, NUM_SG)) if sg_flows.ndim <= 1 else sg_flows
     total_steam_flow = 0.0 + sg_flows[:, 0] + sg_flows[:, 1] + sg_flows[:, 2]
     flow_per_pump = ((total_steam_flow * 1.02) / MIN_PUMPS_REQUIRED) / degradation_factor
     for k in range(NUM_PUMPS):
@@ -170,7 +163,12 @@ def feedwater_fields(ic: Dict[str, object], n: int, lubrication_effectiveness: f
     f["fw.total_flow_rate"] = total_steam_flow                                                    # physics.py:196-197
     icd = per_pump("impeller_cavitation_damage")
     f["fw.cav_accumulated_damage"] = ((0.0 + icd[:, 0] + icd[:, 1] + icd[:, 2] + icd[:, 3]) / NUM_PUMPS) * 10.0
-    return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in f.items()}
+    out = {}
+    for k, v in f.items():
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        assert v.shape in ((1,), (n,)), (k, v.shape)
+        out[k] = v
+    return out
 
 
 def feedwater_reset_fields(ic: Dict[str, object], n: int, lubrication_effectiveness, start_at_steady_state: bool) -> Dict[object, np.ndarray]:
@@ -314,6 +312,216 @@ def randomized_conditions(action: str, seed: Optional[int]) -> Dict[str, object]
     return base if _violates(out, jit["feedwater_safety_rules"]) else out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# The same randomisers for a whole array of seeds (SURVEY.md 8f-2: "SoA IC arrays for 10^5 - 10^6 plants").  The functions
+# above follow the reference one plant at a time and are kept as the readable statement (and as the check of what follows,
+# tests/test_scenarios.py); below, the two generators' streams come from libnpb.so for all seeds at once
+# (include/npb_seeds.h) and the control flow of the functions above is walked ONCE per scenario with whole columns in place
+# of the scalars: which draws are consumed, and in which order, depends only on the catalog entry's structure, never on a
+# drawn value, so every seed of a scenario takes the same path.
+def _seed_streams(kind: str, seeds: np.ndarray, k: int) -> np.ndarray:
+    """[n, k]: the first k values of random.Random(seed).random() ("py"), numpy.random.RandomState(seed).random_sample()
+    ("np") or .standard_normal() ("gauss") for every seed"""
+    import ctypes
+    from . import _lib
+    L = _lib.load()
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+    out = np.empty((len(seeds), max(k, 1)))
+    if k <= 0 or len(seeds) == 0:
+        return out[:, :0]
+    fn = getattr(L, {"py": "npb_seed_py_random", "np": "npb_seed_np_random", "gauss": "npb_seed_np_gauss"}[kind])
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    if fn(seeds.ctypes.data, len(seeds), int(k), out.ctypes.data) != 0:
+        raise ValueError("scenario seeds must be non-negative integers (below 2**32 for numpy's generator)")
+    return out
+
+
+def _is_value(v) -> bool:
+    """a number, or a column of them"""
+    return _is_number(v) or (isinstance(v, np.ndarray) and v.ndim == 1)
+
+
+def _columns(struct, m: int):
+    """a conditions dictionary whose leaves are numbers, columns [m] or lists of either -> {key: array [m] / [m, len]}
+    (numeric entries only: the only ones that can reach plant state)"""
+    out = {}
+    for k, v in struct.items():
+        if _is_value(v):
+            out[k] = np.broadcast_to(np.asarray(v, dtype=np.float64), (m,))
+        elif isinstance(v, list) and v and all(_is_value(e) for e in v):
+            out[k] = np.stack([np.broadcast_to(np.asarray(e, dtype=np.float64), (m,)) for e in v], axis=1)
+    return out
+
+
+def _violates_columns(conditions: Dict[str, object], rules: Dict[str, dict], m: int) -> np.ndarray:
+    """_violates for columns: bool [m]"""
+    bad = np.zeros(m, dtype=bool)
+    for key, value in conditions.items():
+        if key in rules:
+            lim, less = rules[key]["safety_limit"], rules[key].get("safety_direction", "greater_than") == "less_than"
+            for v in (value if isinstance(value, list) else [value]):
+                if _is_value(v):
+                    bad |= (np.asarray(v) < lim) if less else (np.asarray(v) > lim)
+        elif isinstance(value, dict):
+            bad |= _violates_columns(value, rules, m)
+    return bad
+
+
+def _jitter_columns(conditions: Dict[str, object], rules: Dict[str, dict], default_scale: float, seeds: np.ndarray) -> Dict[str, object]:
+    """_jitter for every seed: the same traversal, each numeric leaf's draw being column j of the numpy stream"""
+    def count(obj):                                        # how many draws the traversal consumes
+        c = 0
+        if isinstance(obj, dict):
+            for key, value in obj.items():
+                if key in rules:
+                    c += len(value) if isinstance(value, list) else 1
+                elif _is_number(value):
+                    c += 1
+                elif isinstance(value, list):
+                    c += len(value) if (value and isinstance(value[0], (int, float))) else 0
+                else:
+                    c += count(value)
+        elif isinstance(obj, list):
+            for item in obj:
+                c += count(item)
+        return c
+
+    U = _seed_streams("np", seeds, count(conditions))
+    cursor = [0]
+
+    def uniform(scale):                                    # RandomState.uniform(-scale, scale) = low + (high - low) * u
+        u = U[:, cursor[0]]; cursor[0] += 1
+        return -scale + (scale - -scale) * u
+
+    def single(value, rule):
+        new = value * (1.0 + uniform(rule.get("scale_factor", 0.1)))
+        if rule.get("min_value") is not None:
+            new = np.maximum(new, rule["min_value"])
+        if rule.get("max_value") is not None:
+            new = np.minimum(new, rule["max_value"])
+        return new
+
+    def default(value):
+        return value * (1.0 + uniform(default_scale))
+
+    def rec(obj):
+        if isinstance(obj, dict):
+            for key, value in obj.items():
+                if key in rules:
+                    obj[key] = [single(v, rules[key]) for v in value] if isinstance(value, list) else single(value, rules[key])
+                elif _is_number(value):
+                    obj[key] = default(value)
+                elif isinstance(value, list):
+                    if value and isinstance(value[0], (int, float)):
+                        obj[key] = [default(v) for v in value]
+                else:
+                    rec(value)
+        elif isinstance(obj, list):
+            for item in obj:
+                rec(item)
+
+    out = copy.deepcopy(conditions)
+    rec(out)
+    assert cursor[0] == U.shape[1]
+    return out
+
+
+def randomized_conditions_columns(action: str, seeds: Sequence[int], keys: Optional[Sequence[str]] = None) -> Dict[str, np.ndarray]:
+    """``randomized_conditions(action, seed)`` for every seed at once: {parameter: array [n] or [n, len]} of the numeric
+    entries; a parameter that no draw of the action's table reaches comes back as the catalog entry's number or [len] array,
+    the same for every seed (``keys``: only these -- every draw is still consumed in its turn, but a parameter nobody asked for and no safety
+    limit looks at is not evaluated).  Bit-identical to the per-seed function (tests/test_scenarios.py), at about a million
+    seeds per second."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+    n = len(seeds)
+    base = catalog_conditions(action)
+    wanted = None if keys is None else set(keys) | set(_CATALOG["jitter"]["feedwater_safety_rules"])
+    base_cols = _columns(base if wanted is None else {k: v for k, v in base.items() if k in wanted}, n)
+    table = _CATALOG["scenarios"].get(action)
+    jit = _CATALOG["jitter"]
+    if not table:
+        out = _jitter_columns(jit["full_conditions"][action], jit["default_rules"], jit["default_scale"], seeds)
+        bad = _violates_columns(out, jit["feedwater_safety_rules"], n)
+        cols = _columns(out, n)
+    else:
+        n_uniform = max(sum(1 for nm, c in sc["parameters"].items() if nm in base and c["distribution"] != "normal") for sc in table)
+        n_normal = max(sum(1 for nm, c in sc["parameters"].items() if nm in base and c["distribution"] == "normal") for sc in table)
+        U = _seed_streams("py", seeds, 1 + n_uniform)
+        G = _seed_streams("gauss", seeds, n_normal)
+        total = sum(sc["probability"] for sc in table)
+        pick = np.full(n, len(table) - 1, dtype=np.int64)
+        undecided = np.ones(n, dtype=bool)
+        cumulative = 0.0
+        for s_i, sc in enumerate(table):
+            cumulative += sc["probability"] / total
+            hit = undecided & (U[:, 0] <= cumulative)
+            pick[hit] = s_i
+            undecided &= ~hit
+        touched = set()
+        for sc in table:
+            touched |= {nm for nm in sc["parameters"] if nm in base}
+        touched |= {nm for nm in _CATALOG["array_parameters"] if nm in base and _is_number(base[nm])}
+        # parameters no scenario draws keep the catalog entry's value for every seed: they stay what they are (a number or a
+        # list), and only the drawn ones become columns
+        cols = {k: np.array(v) for k, v in base_cols.items() if k in touched}
+        bad = np.zeros(n, dtype=bool)
+        for s_i, sc in enumerate(table):
+            rows = np.nonzero(pick == s_i)[0]
+            if not len(rows):
+                continue
+            out = copy.deepcopy(base)
+            iu, ig = 1, 0
+            for name, cfg in sc["parameters"].items():
+                if name not in out:
+                    continue
+                lo, hi = cfg["range"]
+                skip = wanted is not None and name not in wanted
+                if cfg["distribution"] == "normal":
+                    ig += 1
+                    if skip:
+                        continue
+                    value = (lo + hi) / 2 + ((hi - lo) / 4) * G[rows, ig - 1]          # RandomState.normal: loc + scale * gauss
+                    value = np.maximum(lo, np.minimum(hi, value))
+                else:
+                    iu += 1
+                    if skip:
+                        continue
+                    value = lo + (hi - lo) * U[rows, iu - 1]                           # Random.uniform: a + (b - a) * random()
+                if isinstance(out[name], list):
+                    out[name] = _apply_to_array(out[name], value, cfg["array_handling"] or "preserve_pattern")
+                else:
+                    out[name] = value
+            for name, (handling, default) in _CATALOG["array_parameters"].items():
+                if name in out and _is_value(out[name]):
+                    out[name] = _apply_to_array(base.get(name, default), out[name], handling)
+            bad[rows] = _violates_columns(out, jit["feedwater_safety_rules"], len(rows))
+            for k, v in _columns({k: v for k, v in out.items() if k in touched and (wanted is None or k in wanted)}, len(rows)).items():
+                if k not in cols or cols[k].shape[1:] != v.shape[1:]:
+                    cols[k] = np.array(np.broadcast_to(np.zeros(1), (n,) + v.shape[1:]))   # (a parameter the entry holds as a scalar, made an array)
+                    if k in base_cols and base_cols[k].shape[1:] == v.shape[1:]:
+                        cols[k][...] = base_cols[k]
+                cols[k][rows] = v
+        for k, v in base.items():
+            if k not in cols and (wanted is None or k in wanted) and (_is_number(v) or (isinstance(v, list) and v and all(_is_number(e) for e in v))):
+                cols[k] = np.asarray(v, dtype=np.float64)          # shape () or (len,): the same for every seed
+    if bad.any():       # a draw beyond a safety limit: the reference raises and the composer uses the plain catalog entry
+        for k in cols:
+            if k in base_cols and base_cols[k].shape == cols[k].shape:
+                cols[k] = np.where(bad.reshape((n,) + (1,) * (cols[k].ndim - 1)), base_cols[k], cols[k])
+    return cols
+
+
+def composed_feedwater_ic_columns(cols: Dict[str, np.ndarray]) -> Dict[str, object]:
+    """composed_feedwater_ic for columns"""
+    tpl = _CATALOG["template_ic"]["feedwater"]
+    ic = {k: copy.deepcopy(tpl[k]) for k in FEEDWATER_IC_DEFAULTS if k in tpl}
+    ic["sg_steam_flows"] = list(ACTION_TEST_TEMPLATE["feedwater"]["sg_steam_flows"])
+    for k, v in cols.items():
+        if k in tpl and k in FEEDWATER_IC_DEFAULTS:
+            ic[k] = v
+    return ic
+
+
 def composed_feedwater_ic(conditions: Dict[str, object]) -> Dict[str, object]:
     """The feedwater initial_conditions the composer hands to the simulator: the template's section with the catalog
     parameters that exist in it overwritten (comprehensive_composer.py:284-293), reduced to the keys that reach state."""
@@ -404,12 +612,9 @@ def _sg_randomized_fields(action: str, seeds: Sequence[int]) -> Dict[object, np.
     template's steam_generator section."""
     jit = _CATALOG["jitter"]
     tpl = _CATALOG["template_ic"]["steam_generator"]
-    vals = {}
-    for sd in seeds:
-        cond = _jitter(jit["full_conditions"][action], jit["sg_rules"], jit["sg_scale"], int(sd))
-        for key in list(_SG_DIRECT) + ["tsp_fouling_thicknesses", "scale_thicknesses"]:
-            if key in cond and key in tpl:
-                vals.setdefault(key, []).append(cond[key])
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+    cond = _columns(_jitter_columns(jit["full_conditions"][action], jit["sg_rules"], jit["sg_scale"], seeds), len(seeds))
+    vals = {key: cond[key] for key in list(_SG_DIRECT) + ["tsp_fouling_thicknesses", "scale_thicknesses"] if key in cond and key in tpl}
     f: Dict[object, np.ndarray] = _sg_deposit_fields(
         np.asarray(vals.pop("tsp_fouling_thicknesses"), dtype=np.float64) if "tsp_fouling_thicknesses" in vals else None,
         np.asarray(vals.pop("scale_thicknesses"), dtype=np.float64) if "scale_thicknesses" in vals else None)
@@ -442,24 +647,25 @@ def action_test_fields(action: str, seeds: Sequence[int], lubrication_effectiven
         n = len(seeds)
         f = feedwater_fields(composed_feedwater_ic({}), n, lubrication_effectiveness)
         for k in range(NUM_SG):
-            f[("sg.steam_flow_rate", k)] = np.full(n, ACTION_TEST_TEMPLATE["steam_generator"]["sg_steam_flows"][k])
-        f["turb.rotor_temperature"] = np.full(n, ACTION_TEST_TEMPLATE["turbine"]["rotor_temperature"])
+            f[("sg.steam_flow_rate", k)] = np.full(1, ACTION_TEST_TEMPLATE["steam_generator"]["sg_steam_flows"][k])
+        f["turb.rotor_temperature"] = np.full(1, ACTION_TEST_TEMPLATE["turbine"]["rotor_temperature"])
         for k in range(4):
-            f[("turb.bearing_metal_temp", 0, k)] = np.full(n, ACTION_TEST_TEMPLATE["turbine"]["bearing_temperatures"][k])
+            f[("turb.bearing_metal_temp", 0, k)] = np.full(1, ACTION_TEST_TEMPLATE["turbine"]["bearing_temperatures"][k])
         for label, value in info["delta"].items():
-            f[_label_key(label)] = np.full(n, value)
+            f[_label_key(label)] = np.full(1, value)
         if sg_rand:
             f.update(_sg_randomized_fields(action, seeds))
         return f
     n = len(seeds)
     if randomize:
-        ics = [composed_feedwater_ic(randomized_conditions(action, int(sd))) for sd in seeds]
+        tpl = _CATALOG["template_ic"]["feedwater"]
+        ic = composed_feedwater_ic_columns(randomized_conditions_columns(action, seeds, keys=[k for k in FEEDWATER_IC_DEFAULTS if k in tpl]))
     else:
-        ics = [composed_feedwater_ic(catalog_conditions(action))] * n
-    f = feedwater_fields(_stack(ics), n, lubrication_effectiveness)
+        ic = composed_feedwater_ic(catalog_conditions(action))
+    f = feedwater_fields(ic, n, lubrication_effectiveness)
     for k in range(NUM_SG):
-        f[("sg.steam_flow_rate", k)] = np.full(n, ACTION_TEST_TEMPLATE["steam_generator"]["sg_steam_flows"][k])
-    f["turb.rotor_temperature"] = np.full(n, ACTION_TEST_TEMPLATE["turbine"]["rotor_temperature"])
+        f[("sg.steam_flow_rate", k)] = np.full(1, ACTION_TEST_TEMPLATE["steam_generator"]["sg_steam_flows"][k])
+    f["turb.rotor_temperature"] = np.full(1, ACTION_TEST_TEMPLATE["turbine"]["rotor_temperature"])
     for k in range(4):
-        f[("turb.bearing_metal_temp", 0, k)] = np.full(n, ACTION_TEST_TEMPLATE["turbine"]["bearing_temperatures"][k])
+        f[("turb.bearing_metal_temp", 0, k)] = np.full(1, ACTION_TEST_TEMPLATE["turbine"]["bearing_temperatures"][k])
     return f

@@ -153,3 +153,58 @@ def test_scenario_mix_follows_the_catalog_probabilities():
     lv = scenarios.randomized_oil_top_off_levels(range(4000))[:, 0]
     low, mid, high = (lv < 60.0).mean(), ((lv > 60.0) & (lv < 61.3)).mean(), (lv > 61.4).mean()
     assert abs(low - 0.3) < 0.03 and abs(mid - 0.4) < 0.03 and abs(high - 0.3) < 0.03
+
+
+@pytest.mark.parametrize("action", scenarios.FEEDWATER_ACTIONS)
+def test_columns_are_the_per_seed_randomiser(action):
+    """randomized_conditions_columns (streams of all seeds at once from libnpb.so, the randomiser's control flow walked once per
+    scenario on whole columns) against randomized_conditions (the reference's flow one seed at a time on the interpreter's own
+    generators): every numeric parameter of every seed, bit for bit -- 3 000 seeds per action, so every scenario of every table,
+    both distributions, and the safety-limit fall-back are visited."""
+    seeds = np.concatenate([np.arange(2500), np.random.default_rng(1).integers(0, 2**32, 500)])
+    cols = scenarios.randomized_conditions_columns(action, seeds)
+    fell_back = 0
+    base = scenarios.catalog_conditions(action)
+    for j, sd in enumerate(seeds):
+        want = scenarios.randomized_conditions(action, int(sd))
+        fell_back += want == base
+        for k, v in want.items():
+            if scenarios._is_number(v) or (isinstance(v, list) and v and all(scenarios._is_number(e) for e in v)):
+                got = cols[k][j] if cols[k].shape[:1] == (len(seeds),) and cols[k].ndim == np.ndim(v) + 1 else cols[k]    # a column, or the same for every seed
+                assert np.array_equal(np.asarray(got, dtype=np.float64), np.asarray(v, dtype=np.float64)), (action, int(sd), k)
+    ic = scenarios.composed_feedwater_ic_columns(cols)
+    one = scenarios.composed_feedwater_ic(scenarios.randomized_conditions(action, int(seeds[17])))
+    for k, v in one.items():
+        got = ic[k][17] if isinstance(ic[k], np.ndarray) and ic[k].shape[:1] == (len(seeds),) and ic[k].ndim == np.ndim(v) + 1 else ic[k]
+        assert v is None and got is None or np.array_equal(np.asarray(got, dtype=np.float64), np.asarray(v, dtype=np.float64)), k
+
+
+def test_steam_generator_jitter_columns_are_the_per_seed_jitter():
+    import json, os
+    cat = scenarios._CATALOG["jitter"]
+    seeds = np.arange(400)
+    for action in ("tsp_chemical_cleaning", "scale_removal", "level_control_check", "steam_system_check"):
+        cols = scenarios._columns(scenarios._jitter_columns(cat["full_conditions"][action], cat["sg_rules"], cat["sg_scale"], seeds), len(seeds))
+        for j in (0, 1, 77, 399):
+            want = scenarios._jitter(cat["full_conditions"][action], cat["sg_rules"], cat["sg_scale"], int(seeds[j]))
+            for k, v in want.items():
+                if k in cols:
+                    assert np.array_equal(cols[k][j], np.asarray(v, dtype=np.float64)), (action, k)
+
+
+def test_a_quarter_million_plants_take_under_a_second():
+    """initial conditions for 10^5 - 10^6 plants must not dominate set-up (BASELINE config 4: 262 144 plants).
+    The per-seed loop this replaces took 80 s for oil_top_off and 140 s for seal_replacement."""
+    import time
+    seeds = np.arange(262144)
+    scenarios.action_test_fields("oil_top_off", seeds[:1000], 0.93)         # library load, thread start
+    worst = 0.0
+    for action in ("oil_top_off", "seal_replacement", "oil_change", "motor_inspection", "tsp_chemical_cleaning"):
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            f = scenarios.action_test_fields(action, seeds, 0.93)
+            best = min(best, time.perf_counter() - t)
+        assert all(len(v) in (1, len(seeds)) for v in f.values()) and sum(len(v) == len(seeds) for v in f.values()) >= 4
+        worst = max(worst, best)
+        assert best < 2.0, (action, best)       # ~0.1-0.4 s on 8 cores; the bound leaves room for a loaded test host
