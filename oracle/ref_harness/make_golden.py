@@ -425,6 +425,44 @@ def make_ic_all_actions(seeds=(0,)):
     print("ic_all_actions: %d rows, %d failed" % (len(rows), len(failed)))
 
 
+def _c4_run(job):
+    """worker of make_c4_counts: one runner-built oil_top_off simulator per seed, stepped as run_reference steps a runner fixture"""
+    seed, steps = job
+    cols = SCHEMA.columns()
+    sc = dict(name="c4", steps=steps, dt=5.0, noise=True, noise_seed=42,
+              runner=dict(action="oil_top_off", duration_hours=steps * 5.0 / 60.0, randomization_seed=int(seed)))
+    ref, _sim = trace.run_reference(sc, cols)
+    return seed, ref["setpoint"], ref["noise_z"], ref["state"], ref["obs"][-1], ref["done"]
+
+
+def make_c4_counts(seeds=tuple(range(64)), steps=48, procs=8):
+    """tests/golden/c4_counts_64seeds.npz -- BASELINE config 4's headline quantity held by the reference itself: 64 simulators
+    as MaintenanceScenarioRunner builds them for compose_action_test_scenario("oil_top_off", randomize=True,
+    randomization_seed=s) (maintenance_scenario_runner.py:210-244; seeds 0..63 fall into all three catalog scenarios,
+    randomization_utils.py:770-797), each run for `steps` steps of 5 minutes under the runner's own power profile
+    (:349-411, :651-671) with state management and AutoMaintenanceSystem on.  Recorded per seed: the inputs (set-point trace;
+    the heat-source noise is the same stream for every plant), the initial and the final value of every schema column
+    (oil levels, every maint.* / mpump.* member: work orders created, maintenance actions performed, executions by action,
+    open orders, cooldown stamps) and the two counters after every step."""
+    import multiprocessing as mp
+    cols = SCHEMA.columns()
+    labels = [c[2] for c in cols]
+    with mp.get_context("fork").Pool(procs) as pool:
+        results = pool.map(_c4_run, [(s, steps) for s in seeds], chunksize=1)
+    results.sort(key=lambda r: r[0])
+    created_col = labels.index("maint.work_orders_created"); performed_col = labels.index("maint.maintenance_actions_performed")
+    np.savez_compressed(os.path.join(OUT, "c4_counts_64seeds.npz"),
+                        seeds=np.array([r[0] for r in results]), setpoint=np.array([r[1] for r in results]), noise_z=results[0][2],
+                        initial_state=np.array([r[3][0] for r in results]), final_state=np.array([r[3][-1] for r in results]),
+                        created=np.array([r[3][1:, created_col] for r in results]).astype(np.int32),
+                        performed=np.array([r[3][1:, performed_col] for r in results]).astype(np.int32),
+                        final_obs=np.array([r[4] for r in results]), done=np.array([r[5] for r in results]),
+                        labels=np.array(labels), kinds=np.array([c[0] for c in cols]), paths=np.array([c[3] for c in cols]),
+                        meta=json.dumps(dict(action="oil_top_off", steps=steps, dt=5.0, noise_seed=42, noise_std_percent=0.1)))
+    perf = np.array([r[3][-1, performed_col] for r in results])
+    print("c4_counts: %d seeds x %d steps; executions per plant: %s" % (len(results), steps, np.bincount(perf.astype(int)).tolist()))
+
+
 def make_maint_table():
     """tests/golden/maint_table.json: StateManager.maintenance_thresholds['FWP-1'] of the data-gen action-test simulator, in
     its dict order, with the state-log key each threshold name resolves to (None = never resolves, never fires), plus the
@@ -461,6 +499,8 @@ if __name__ == "__main__":
         make_maint_table()
     elif sys.argv[1:] == ["ic_check"]:
         make_ic_check()
+    elif sys.argv[1:] == ["c4_counts"]:
+        make_c4_counts()
     elif sys.argv[1:] == ["ic"]:
         make_ic_fixture()
     elif sys.argv[1:] == ["ic_actions"]:

@@ -98,3 +98,30 @@ def compare_state(g, f64, i32, row, where):
             if not (abs(mine - v) <= RTOL * abs(v) + ATOL_SMALL):
                 bad.append((label, mine, float(v)))
     assert not bad, "%s %s: %d mismatching columns, first: %s" % (g.name, where, len(bad), bad[:5])
+
+
+class Config4Counts:
+    """tests/golden/c4_counts_64seeds.npz (oracle/ref_harness/make_golden.py make_c4_counts): 64 simulators as the data-gen
+    runner builds them for the randomised oil_top_off action test, run by the REFERENCE for 48 steps of 5 minutes -- BASELINE
+    config 4's per-plant quantities: work orders created / maintenance actions performed after every step, and the initial
+    and final value of every schema column (oil levels, executions by action, open orders, cooldown stamps)."""
+
+    def __init__(self):
+        z = np.load(os.path.join(GOLDEN_DIR, "c4_counts_64seeds.npz"), allow_pickle=False)
+        self.name = "c4_counts_64seeds"
+        self.meta = json.loads(str(z["meta"]))
+        self.seeds = [int(s) for s in z["seeds"]]
+        self.setpoint, self.noise_z = z["setpoint"], z["noise_z"]
+        self.created, self.performed = z["created"], z["performed"]
+        self.final_obs = z["final_obs"]
+        self.T = self.setpoint.shape[1]
+        self.cols = SCHEMA.columns()
+        idx = {str(p): j for j, p in enumerate(z["paths"]) if str(p)}
+
+        def rows(raw):
+            st = np.full((raw.shape[0], len(self.cols)), np.nan)
+            for j, c in enumerate(self.cols):
+                if c[3] in idx:
+                    st[:, j] = raw[:, idx[c[3]]]
+            return st
+        self.initial_state, self.final_state = rows(z["initial_state"]), rows(z["final_state"])

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from golden_util import GOLDEN_DIR
+from golden_util import GOLDEN_DIR, Config4Counts, compare_state
 from nuclear_sim_amd.schema import SCHEMA
 from nuclear_sim_amd import scenarios
 
@@ -208,3 +208,30 @@ def test_a_quarter_million_plants_take_under_a_second():
         assert all(len(v) in (1, len(seeds)) for v in f.values()) and sum(len(v) == len(seeds) for v in f.values()) >= 4
         worst = max(worst, best)
         assert best < 2.0, (action, best)       # ~0.1-0.4 s on 8 cores; the bound leaves room for a loaded test host
+
+
+def test_config4_counts_held_by_the_reference(oracle_lib):
+    """BASELINE config 4's event counts against the reference itself on 64 seeds (all three catalog scenarios): the plants
+    scenarios.action_test_fields builds for the seeds, stepped by the oracle under the recorded inputs -- initial state, both
+    counters after EVERY step, and every column at the end (executions by action, final oil levels, open orders, stamps)."""
+    c4 = Config4Counts()
+    n = len(c4.seeds)
+    P = oracle_lib.Params(); P.dt = 5.0; P.hs_noise_enabled = 1; P.maint_enabled = 1
+    o = oracle_lib.OraclePlants(n, P)
+    eff = float(o.get("pump.lubrication_effectiveness"))
+    for key, v in scenarios.action_test_fields("oil_top_off", c4.seeds, eff).items():
+        name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
+        o.set(name, v, instance=inst, k=k)
+    F, I = o.state_all()
+    for j in range(n):
+        compare_state(c4, F[j], I[j], c4.initial_state[j], "seed %d initial state" % c4.seeds[j])
+    kc = SCHEMA.slot("maint.work_orders_created")[1]; kp = SCHEMA.slot("maint.maintenance_actions_performed")[1]
+    for t in range(c4.T):
+        o.step(setpoint=c4.setpoint[:, t], noise_z=np.full(n, c4.noise_z[t]))
+        _F, I = o.state_all()
+        assert np.array_equal(I[:, kc], c4.created[:, t]), "work_orders_created after step %d" % t
+        assert np.array_equal(I[:, kp], c4.performed[:, t]), "maintenance_actions_performed after step %d" % t
+    F, I = o.state_all()
+    for j in range(n):
+        compare_state(c4, F[j], I[j], c4.final_state[j], "seed %d after %d steps" % (c4.seeds[j], c4.T))
+    assert 0 < (c4.performed[:, -1] == 0).sum() < n        # the seed mix has plants that top off within 4 h and plants that never do
