@@ -353,7 +353,7 @@ def main():
                                             "(measured writes ~200 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "
                                             "of the reads is served by the 256 MB Infinity Cache; NULL inputs (20 B/plant) are "
                                             "already excluded",
-                         "kernel": launched_kernel + (" + npb_maint_screen_kernel + npb_maint_kernel" if args.maintenance else ""),
+                         "kernel": launched_kernel + (" + npb_maint_kernel" if args.maintenance else ""),
                          "kernel_ms": kernel_ms},
             "preconditioning": {"ms": precondition_ms, "what": "a scratch handle of the same size stepped on the same inputs before the %d warm-up "
                                 "steps of the benchmarked one (whose state is not advanced), so that the timed steps run at the GPU's "

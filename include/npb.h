@@ -163,6 +163,9 @@ NPB_API int npb_gather_fields(NpbHandle *h, int n_fields, const int *kinds, cons
 /* raw arena (checkpointing, external kernels): one allocation of equally wide columns, column-major with `pitch`
  * plants per column; the members of the schema are mapped onto columns as include/npb_fields.h describes */
 NPB_API int npb_state_arena(NpbHandle *h, void **arena, size_t *pitch, int *storage);
+/* (With params.maint_enabled the step kernels consult a cache of which maintenance thresholds are inside their cooldown; every
+ * entry point that can change state, the table or the clock invalidates it, this one included.  A caller that keeps the pointer
+ * and writes the arena between later steps calls npb_state_arena again after each such write.) */
 /* where a field lives: arena column, position of a narrow member inside the column (0/1), and how it is stored
  * (0 = carried real of the column width, 1 = output real stored as float, 2 = int32); element address =
  * arena + (column * pitch + plant) * width + sub * 4, width = 8 (NPB_STORAGE_F64) or 4 (NPB_STORAGE_F32) */

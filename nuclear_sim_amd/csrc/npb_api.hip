@@ -20,8 +20,9 @@ struct NpbHandle {
   size_t real_bytes;   /* 8 | 4 */
   void *f64;           /* the arena: [NPB_TOTAL_COL64][pitch] 8-byte columns, or [NPB_TOTAL_COL32][pitch] 4-byte ones */
   double *convert;     /* one staging column (pitch doubles) used by get/set_field with host buffers */
-  unsigned *maint_flags; /* NPB_NUM_PUMPS words per wave of plants: the maintenance screen's verdict (behind the staging column) */
+  unsigned *maint_flags; /* the step kernel's maintenance flag words, per wave of plants (npd_maintenance.h; behind the staging column) */
   double *diag; size_t diag_pitch; /* npb_set_diagnostics: the caller's [NPB_DIAG_DIM][diag_pitch] buffer, or NULL */
+  bool maint_cache_stale;          /* the cooldown cache of the step kernels' maintenance screen must be zeroed before the next step */
   int last_kernel;                 /* NPB_KERNEL_*: what the last npb_step launched */
   int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel, 3 = its two-waves-per-SIMD build, 4 = one-wave with streaming stores (npb_set_step_kernel) */
   npb_maint_table_t maint_table;   /* thresholds of the automatic maintenance (include/npb_maint.h) */
@@ -107,7 +108,7 @@ static void probe_placement(NpbHandle *h, size_t step_columns) {
   (narrow ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, h->pitch, cand[0], nullptr, nullptr);
   for (int k = 0; k < 200; k++)
     (void)(narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, cand[0], nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                         nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr);
+                                                         nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr, nullptr, nullptr);
   if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(a); (void)hipEventDestroy(b); return; }
   int n = 0;
   for (; n < max_candidates; n++) {
@@ -117,7 +118,7 @@ static void probe_placement(NpbHandle *h, size_t step_columns) {
     for (int k = 0; k < launches; k++) {
       (void)hipEventRecord(a, nullptr);
       (void)(narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, cand[n], nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                           nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr);
+                                                           nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr, nullptr, nullptr);
       (void)hipEventRecord(b, nullptr);
       if (hipEventSynchronize(b) != hipSuccess) { best = 1e30f; break; }
       float t = 0;
@@ -216,7 +217,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   h->f64 = nullptr; h->convert = nullptr; h->plan_dev = nullptr;
   e = hipMalloc(&h->f64, arena_columns(storage) * h->pitch * real_bytes);
   if (e == hipSuccess) probe_placement(h, step_columns);
-  if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double) + h->pitch / 64 * NPB_NUM_PUMPS * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double) + npb_launch_maint_flag_bytes(h->pitch));
   if (e != hipSuccess) {
     if (h->f64) (void)hipFree(h->f64);
     delete h;
@@ -224,6 +225,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
     return fail(nullptr, NPB_ENOMEM, "npb_create: hipMalloc of the state arena failed", e);
   }
   h->maint_flags = (unsigned *)(h->convert + h->pitch);
+  h->maint_cache_stale = true;
   (storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, n_plants, h->pitch, h->f64, nullptr, nullptr);
   e = hipDeviceSynchronize();
   if (caller_device >= 0 && caller_device != device) (void)hipSetDevice(caller_device); /* the caller's current device is left as it was */
@@ -250,6 +252,7 @@ int npb_destroy(NpbHandle *h) {
 int npb_set_params(NpbHandle *h, const npb_params_t *params) {
   if (!h || !params) return NPB_EINVAL;
   h->params = *params;
+  h->maint_cache_stale = true;
   return NPB_OK;
 }
 
@@ -284,6 +287,7 @@ int npb_set_maintenance_table(NpbHandle *h, const npb_maint_table_t *table) {
   }
   h->maint_table = *table;
   h->maint_table_custom = true;
+  h->maint_cache_stale = true;
   return NPB_OK;
 }
 void npb_default_maintenance_table(npb_maint_table_t *table) { if (table) npb_maint_table_default(table); }
@@ -291,6 +295,7 @@ void npb_default_maintenance_table(npb_maint_table_t *table) { if (table) npb_ma
 int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream) {
   if (!h) return NPB_EINVAL;
   NPB_USE_DEVICE(h);
+  h->maint_cache_stale = true;
   (h->storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, h->pitch, h->f64, mask, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
   return NPB_OK;
@@ -299,6 +304,7 @@ int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream) {
 int npb_reset_reference(NpbHandle *h, const uint8_t *mask, int start_at_steady_state, void *stream) {
   if (!h) return NPB_EINVAL;
   NPB_USE_DEVICE(h);
+  h->maint_cache_stale = true;
   (h->storage == NPB_STORAGE_F32 ? npb32_launch_reset : npb_launch_reset)(&h->params, h->n_plants, h->pitch, h->f64, mask, start_at_steady_state != 0, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
   return NPB_OK;
@@ -335,6 +341,7 @@ int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int buf_is_
   int rc = field_args(h, kind, slot, &col, &sub, &akind, &bytes);
   if (rc) return rc;
   NPB_USE_DEVICE(h);
+  h->maint_cache_stale = true;      /* a stamp, a pump member or the clock may just have been written */
   const void *src = buf;
   if (!buf_is_device) {
     NPB_HIP(h, hipMemcpyAsync(h->convert, buf, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -368,6 +375,7 @@ int npb_gather_fields(NpbHandle *h, int n_fields, const int *kinds, const int *s
 
 int npb_state_arena(NpbHandle *h, void **arena, size_t *pitch, int *storage) {
   if (!h) return NPB_EINVAL;
+  h->maint_cache_stale = true;      /* the caller may write the arena through this pointer (before the next step) */
   if (arena) *arena = h->f64;
   if (pitch) *pitch = h->pitch;
   if (storage) *storage = h->storage;
@@ -390,17 +398,25 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
   if (!h) return NPB_EINVAL;
   NPB_USE_DEVICE(h);
   const bool narrow = h->storage == NPB_STORAGE_F32;
-  h->last_kernel = (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, action, magnitude, power_setpoint,
-                                                 noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, h->step_kernel, h->diag, h->diag_pitch,
-                                                 (hipStream_t)stream);
-  if (h->params.maint_enabled) {
-    npb_maint_table_t table = h->maint_table;
+  npb_maint_table_t table;
+  const bool maint = h->params.maint_enabled != 0;
+  if (maint) {
+    if (h->maint_cache_stale) {    /* zero = nothing known: every wave is looked at once and its entries rebuilt */
+      NPB_HIP(h, hipMemsetAsync(h->maint_flags, 0, (narrow ? npb32_launch_maint_flag_bytes : npb_launch_maint_flag_bytes)(h->pitch), (hipStream_t)stream));
+      h->maint_cache_stale = false;
+    }
+    table = h->maint_table;
     if (!h->maint_table_custom) {   /* with the default table the two oil_level params of ABI version 1 still set their row */
       table.threshold[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_threshold;
       table.cooldown_hours[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_cooldown_hours;
     }
-    (narrow ? npb32_launch_maint : npb_launch_maint)(&h->params, &table, h->pitch, h->f64, h->maint_flags, (hipStream_t)stream);
   }
+  h->last_kernel = (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, action, magnitude, power_setpoint,
+                                                 noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, h->step_kernel, h->diag, h->diag_pitch,
+                                                 maint ? &table : nullptr, maint ? h->maint_flags : nullptr, (hipStream_t)stream);
+  if (maint)   /* the pump phase of a full-mode step kernel has answered "is any threshold crossed" into the flag words */
+    (narrow ? npb32_launch_maint : npb_launch_maint)(&h->params, &table, h->pitch, h->f64, h->maint_flags, h->params.mode == NPB_MODE_FULL,
+                                                     (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_step: kernel launch failed", e);
   return NPB_OK;

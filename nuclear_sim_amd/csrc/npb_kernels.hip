@@ -500,33 +500,30 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_reset_kernel(npb_params_t P, siz
 }
 
 /* automatic maintenance after a step (params.maint_enabled): AutoMaintenanceSystem.update, then the state manager's
- * threshold scan with work-order creation (npd_maintenance.h), for the four feedwater pumps.  Two launches:
- *   npb_maint_screen_kernel  what nearly every step of nearly every plant ends with: nothing to do.  HBM-bound and
- *     small -- per plant sim_time, three members of the maintenance section, and per pump the 15 members thresholds
- *     look at (~0.5 KB, issued at once, evaluated without a branch), plus that pump's 16 last-violation stamps where a wave
- *     has any violated row at all; one wave per (64 plants, pump).  It moves last_check_time where a check fell due with no order open, and
- *     writes one flag word per wave: some plant has a check falling on open orders, or a fresh violation on this pump.
- *   npb_maint_kernel         the full rule, for the 64 plants of a flagged wave only: work orders, the orchestrator,
- *     the thirteen handlers.  Rare, so it is written for clarity, not for registers.
- * Kept apart so that the register and scalar pressure of the rule (every threshold row and most of npb_params_t live
- * in SGPRs) does not shape the code of the screen. */
+ * threshold scan with work-order creation (npd_maintenance.h), for the four feedwater pumps.
+ *   in the step kernels   what nearly every step of nearly every plant ends with: nothing to do.  The pump phase answers
+ *     "is any threshold of this pump crossed" from the registers it has just updated, the primary phase moves last_check_time
+ *     where a check fell due with no order open; five flag words per wave of 64 plants (npd_maintenance.h).
+ *   npb_maint_kernel      one launch behind the step: a fixed, small grid walks the flag words and leaves before it has
+ *     fetched a single constant when nothing is flagged.  For a flagged (wave, pump) it first looks properly -- the rows'
+ *     real comparisons on the stored state, then that pump's 16 last-violation stamps: a crossed threshold inside its
+ *     cooldown is no work -- and only then runs the full rule for the 64 plants: work orders, the orchestrator, the thirteen
+ *     handlers.  Rare, so it is written for clarity, not for registers. */
 #define NPD_MP_COL(inst, member, k) (NPD_SEC_COL(MPUMP, inst) + NPB_F64_SLOT(npb_mpump_t, member) + (k))
 #define NPD_MP_LOAD(inst, member, count) do { _Pragma("unroll") for (int q__ = 0; q__ < (count); q__++) \
     mp.member[q__] = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(inst, member, q__)); } while (0)
 #define NPD_MP_STORE(inst, member, count) do { _Pragma("unroll") for (int q__ = 0; q__ < (count); q__++) \
     *(npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(inst, member, q__)) = (npd_real_t)mp.member[q__]; } while (0)
-/* the screen's view of the table: scan membership folded into the comparison masks on the host side of the launch */
+/* the second look's view of the table: scan membership folded into the comparison masks on the host side of the launch */
 struct npd_maint_screen_t {
   double threshold[NPB_MAINT_NPARAM];
   double cooldown_minutes[NPB_MAINT_NPARAM];
   uint32_t want_gt, want_lt, want_eq, want_near, want_far;    /* bit q: row q fires on value > / < / == threshold, |value - threshold| < / >= 0.001 */
 };
-__global__ __launch_bounds__(NPB_WAVE) void npb_maint_screen_kernel(npd_maint_screen_t S, double check_interval_minutes, size_t N,
-                                                                    npd_real_t *__restrict__ f64, unsigned *__restrict__ wave_flags) {
-  /* one wave per (64 plants, pump): four times the waves of a launch that is far from filling the chip */
-  const int k = blockIdx.x % NPB_NUM_PUMPS;
-  const size_t p = (size_t)(blockIdx.x / NPB_NUM_PUMPS) * NPB_WAVE + threadIdx.x;
-  const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
+/* does pump k of this lane's plant have a crossed threshold outside its cooldown?  (StateManager._check_maintenance_thresholds up
+ * to the point where a violation is recorded, state_manager.py:1307-1369) */
+__device__ __forceinline__ bool npd_maint_second_look(const npd_maint_screen_t &S, const npd_real_t *f64c, size_t N, size_t p, int k, double t) {
+  npd_real_t *f64 = const_cast<npd_real_t *>(f64c);
   npb_pump_t pm;      /* only the members npd_maint_values reads are loaded */
 #define NPD_PM(member) pm.member = NPD_F64_COL(PUMP, npb_pump_t, member, k)
   NPD_PM(oil_level); NPD_PM(oil_contamination); NPD_PM(lubrication_effectiveness); NPD_PM(wear_impeller); NPD_PM(cavitation_damage);
@@ -535,19 +532,6 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_screen_kernel(npd_maint_sc
 #undef NPD_PM
   double values[NPB_MAINT_NPARAM];
   npd_maint_values(&pm, values);
-  bool work = false;
-  if (k == 0) {
-    /* AutoMaintenanceSystem.update as far as it needs no order: a check that falls due with nothing open only moves
-     * last_check_time; one that finds open orders is left, untouched, to the full rule */
-    const double last_check_time = NPD_F64_COL(MAINT, npb_maint_t, last_check_time, 0);
-    const int created = NPD_I32_COL(MAINT, npb_maint_t, work_orders_created, 0);
-    const int performed = NPD_I32_COL(MAINT, npb_maint_t, maintenance_actions_performed, 0);
-    const bool due = !(last_check_time > 0.0 && t - last_check_time < check_interval_minutes);    /* npd_maint_check_due */
-    work = due & (created > performed);
-    if (due & !work) *(npd_real_t *)npd_gaddr(f64, N, p, NPD_SEC_COL(MAINT, 0) + NPB_F64_SLOT(npb_maint_t, last_check_time)) = (npd_real_t)t;
-  }
-  /* first the comparisons alone; the 16 last-violation stamps (half of the screen's bytes) are fetched only by a wave in
-   * which some row is violated at all, to see whether it is still inside its cooldown */
   uint32_t hits = 0;
 #pragma unroll
   for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
@@ -558,37 +542,64 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_screen_kernel(npd_maint_sc
                      ((((S.want_far >> q) & 1u) != 0) & !near_eq);
     hits |= (uint32_t)hit << q;
   }
+  bool work = false;
   if (__any(hits != 0)) {
 #pragma unroll
-    for (int q = 0; q < NPB_MAINT_NPARAM; q++) {   /* read by nobody else in a step: non-temporal, so that they do not displace the step kernel's working set */
+    for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
       const double lv = (double)__builtin_nontemporal_load((const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q)));
       const bool cooling = (lv >= 0.0) & (t - lv < S.cooldown_minutes[q]);        /* _is_threshold_in_cooldown */
       work |= (((hits >> q) & 1u) != 0) & !cooling;
     }
   }
-  const bool wave_has_work = __any(work) != 0;
-  if (threadIdx.x == 0) wave_flags[blockIdx.x] = wave_has_work ? 1u : 0u;
+  return work;
+}
+
+/* the cooldown cache of the step kernels' screen (npd_maintenance.h) for the four pumps of this lane's plant, from the stamps as
+ * they are now: whenever the rule kernel has looked at a wave */
+__device__ __forceinline__ void npd_maint_refresh_cache(const npd_maint_screen_t &S, const npd_maint_cache_t &MC, const npd_real_t *f64c, size_t N, size_t p, double t) {
+  npd_real_t *f64 = const_cast<npd_real_t *>(f64c);
+  const uint32_t scan_mask = S.want_gt | S.want_lt | S.want_eq | S.want_near | S.want_far;
+#pragma unroll 1
+  for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+    double lv[NPB_MAINT_NPARAM];
+#pragma unroll
+    for (int q = 0; q < NPB_MAINT_NPARAM; q++) lv[q] = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q));
+    uint32_t mask; double until;
+    npd_maint_cache_entry(lv, S.cooldown_minutes, scan_mask, t, &mask, &until);
+    *npd_maint_cache_mask(MC, k, p) = mask;
+    *npd_maint_cache_until(MC, k, p) = until;
+  }
 }
 
 /* a fixed, small grid: each group walks the waves of plants it owns and works on the flagged ones */
-__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, npb_maint_table_t T, size_t N, npd_real_t *__restrict__ f64,
-                                                             const unsigned *__restrict__ wave_flags) {
+__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, npb_maint_table_t T, npd_maint_screen_t S, size_t N, npd_real_t *__restrict__ f64,
+                                                             const unsigned *__restrict__ wave_flags, npd_maint_cache_t MC) {
   const unsigned n_waves = (unsigned)(N / NPB_WAVE);
   /* nothing flagged among this group's waves -- the usual case -- and it is gone before the rule's constants (most of P
    * and T, which the compiler gathers into registers ahead of the loop) are even fetched */
   unsigned mine = 0;
 #pragma unroll 1
   for (unsigned w = blockIdx.x; w < n_waves; w += gridDim.x) {
-    const uint4 flagged = *(const uint4 *)(wave_flags + (size_t)w * NPB_NUM_PUMPS);
-    mine |= flagged.x | flagged.y | flagged.z | flagged.w;
+    const uint4 fa = *(const uint4 *)(wave_flags + (size_t)w * NPD_MAINT_FLAG_WORDS);
+    mine |= fa.x | fa.y | fa.z | fa.w | wave_flags[(size_t)w * NPD_MAINT_FLAG_WORDS + 4];
   }
   if (!mine) return;
 #pragma unroll 1
   for (unsigned w = blockIdx.x; w < n_waves; w += gridDim.x) {
-  const uint4 flagged = *(const uint4 *)(wave_flags + (size_t)w * NPB_NUM_PUMPS);
-  if (!(flagged.x | flagged.y | flagged.z | flagged.w)) continue;
+  const uint4 fa = *(const uint4 *)(wave_flags + (size_t)w * NPD_MAINT_FLAG_WORDS);
+  const unsigned due_with_orders = wave_flags[(size_t)w * NPD_MAINT_FLAG_WORDS + 4];
+  if (!(fa.x | fa.y | fa.z | fa.w | due_with_orders)) continue;
   const size_t p = (size_t)w * NPB_WAVE + threadIdx.x;
   const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
+  if (!due_with_orders) {   /* flagged by a crossed threshold alone: look properly before anything else is fetched */
+    bool work = false;
+#pragma unroll 1
+    for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+      const unsigned fk = k == 0 ? fa.x : (k == 1 ? fa.y : (k == 2 ? fa.z : fa.w));
+      if (fk) work |= npd_maint_second_look(S, f64, N, p, k, t);
+    }
+    if (!__any(work)) { npd_maint_refresh_cache(S, MC, f64, N, p, t); continue; }
+  }
   npb_maint_t m;
   NPD_LOAD(MAINT, npb_maint_t, m, 0);
   int dirty = 0;
@@ -632,6 +643,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, npb
     }
   }
   if (dirty) NPD_STORE(MAINT, npb_maint_t, m, 0);
+  npd_maint_refresh_cache(S, MC, f64, N, p, t);
   }
 }
 
@@ -701,14 +713,42 @@ extern "C" void NPB_LAUNCHER(field_set)(void *arena, size_t npad, int col, int s
 /* fp64-storage plants above which the sweep of a step (4 221 B per plant) is so far past the 256 MB Infinity Cache that streaming
  * state stores win (measured: even at 81 920, -5 % at 98 304, -10 % at 131 072); fp32 storage moves half the bytes */
 #define NPB_NT_STORE_ABOVE ((size_t)90112)
+/* the table as the step kernels' pump phase evaluates it (npd_maintenance.h): a strict comparison as the sign of fma(value, sgn, c);
+ * any other comparison kind in the scan makes every (wave, pump) "look properly" */
+static void npd_maint_fold_table(const npb_params_t *P, const npb_maint_table_t *T, npd_maint_hot_t *H) {
+  bool always = false;
+  for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
+    H->tab[q] = 0.0; H->tab[NPB_MAINT_NPARAM + q] = -1.0;
+    if (!T || T->rank[q] < 0) continue;
+    if (T->comparison[q] == NPB_CMP_GREATER_THAN) { H->tab[q] = 1.0; H->tab[NPB_MAINT_NPARAM + q] = -T->threshold[q]; }
+    else if (T->comparison[q] == NPB_CMP_LESS_THAN) { H->tab[q] = -1.0; H->tab[NPB_MAINT_NPARAM + q] = T->threshold[q]; }
+    else always = true;
+    if (!(T->threshold[q] == T->threshold[q]) || T->threshold[q] - T->threshold[q] != 0.0) always = true;   /* a NaN or infinite threshold: leave it to the real comparison */
+  }
+  H->tab[2 * NPB_MAINT_NPARAM] = always ? 1.0 : 0.0;
+  H->tab[2 * NPB_MAINT_NPARAM + 1] = P->maint_check_interval_hours * 60;
+}
+/* one allocation behind the flag words: [flags: n_waves x NPD_MAINT_FLAG_WORDS u32][until: 4 x npad f64][mask: 4 x npad u32] */
+static npd_maint_cache_t npd_maint_cache_of(unsigned *maint_flags, size_t npad) {
+  npd_maint_cache_t C;
+  C.pitch = npad;
+  C.until = maint_flags ? (double *)(maint_flags + npad / NPB_WAVE * NPD_MAINT_FLAG_WORDS) : nullptr;
+  C.mask = maint_flags ? (uint32_t *)(C.until + (size_t)NPB_NUM_PUMPS * npad) : nullptr;
+  return C;
+}
+/* maint_table / maint_flags: NULL unless the automatic maintenance is on (npb_step) */
 extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad, void *arena,
                                 const int32_t *action, const double *magnitude, const double *setpoint,
                                 const double *noise_z, const double *cw_temp, double *obs, double *reward, uint8_t *done,
-                                uint32_t *trip_flags, double *info, int variant, double *diag, size_t diag_pitch, hipStream_t stream) {
+                                uint32_t *trip_flags, double *info, int variant, double *diag, size_t diag_pitch,
+                                const npb_maint_table_t *maint_table, unsigned *maint_flags, hipStream_t stream) {
+  npd_maint_hot_t MH;
+  npd_maint_fold_table(P, maint_flags ? maint_table : nullptr, &MH);
+  const npd_maint_cache_t MC = npd_maint_cache_of(maint_flags, npad);
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
   if (diag && P->mode == NPB_MODE_FULL) {   /* npb_set_diagnostics: the diagnostics build of the one-wave kernel at any size */
     hipLaunchKernelGGL(npb_step_diag_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
-                       noise_z, cw_temp, obs, reward, done, trip_flags, info, diag, diag_pitch);
+                       noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_flags, MC, diag, diag_pitch);
     return NPB_KERNEL_STEP_DIAG;
   }
   /* two kernels, one result (the same device functions in the same order per plant; tests/test_gpu_parity.py,
@@ -726,26 +766,29 @@ extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t np
   if (variant == 0) variant = npad <= 57344 ? 2 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1);
   if (variant == 4) {
     hipLaunchKernelGGL(npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
-                       noise_z, cw_temp, obs, reward, done, trip_flags, info);
+                       noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_flags, MC);
     return NPB_KERNEL_STEP_NT;
   }
   const bool two_wave = (variant == 2 || variant == 3) && P->mode == NPB_MODE_FULL;
   const bool wide = two_wave && variant == 2 && npad <= 32768;   /* the whole register file while one wave per SIMD is all there is; variant 3 = never */
   if (wide) {
     hipLaunchKernelGGL(npb_step2_wide_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
-                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info);
+                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_flags, MC);
     return NPB_KERNEL_STEP2_WIDE;
   }
   if (two_wave) {
     hipLaunchKernelGGL(npb_step2_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
-                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info);
+                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_flags, MC);
     return NPB_KERNEL_STEP2;
   }
   hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
-                     noise_z, cw_temp, obs, reward, done, trip_flags, info);
+                     noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_flags, MC);
   return NPB_KERNEL_STEP;
 }
-extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, const npb_maint_table_t *T, size_t npad, void *arena, unsigned *wave_flags, hipStream_t stream) {
+/* flags_from_step: the step kernel that ran just before wrote this step's flag words (full mode); otherwise every wave is
+ * marked "look" here and the rule kernel decides everything itself (the modes that do not step the pumps) */
+extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, const npb_maint_table_t *T, size_t npad, void *arena, unsigned *wave_flags, int flags_from_step,
+                                    hipStream_t stream) {
   dim3 block(NPB_WAVE);
   npd_maint_screen_t S = {};
   for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
@@ -761,8 +804,13 @@ extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, const npb_maint_table
     if (c != NPB_CMP_GREATER_THAN && c != NPB_CMP_GREATER_EQUAL && c != NPB_CMP_LESS_THAN && c != NPB_CMP_LESS_EQUAL && c != NPB_CMP_EQUALS) S.want_far |= bit;
   }
   const unsigned n_waves = (unsigned)(npad / NPB_WAVE);
-  hipLaunchKernelGGL(npb_maint_screen_kernel, dim3(n_waves * NPB_NUM_PUMPS), block, 0, stream, S, P->maint_check_interval_hours * 60, npad, (npd_real_t *)arena, wave_flags);
-  hipLaunchKernelGGL(npb_maint_kernel, dim3(n_waves < 256u ? n_waves : 256u), block, 0, stream, *P, *T, npad, (npd_real_t *)arena, (const unsigned *)wave_flags);
+  if (!flags_from_step) (void)hipMemsetAsync(wave_flags, 0x01, (size_t)n_waves * NPD_MAINT_FLAG_WORDS * sizeof(unsigned), stream);
+  hipLaunchKernelGGL(npb_maint_kernel, dim3(n_waves < 256u ? n_waves : 256u), block, 0, stream, *P, *T, S, npad, (npd_real_t *)arena, (const unsigned *)wave_flags,
+                     npd_maint_cache_of(wave_flags, npad));
+}
+/* flag words + cooldown cache (npd_maint_cache_of); zero = "nothing known: look" */
+extern "C" size_t NPB_LAUNCHER(maint_flag_bytes)(size_t npad) {
+  return npad / NPB_WAVE * NPD_MAINT_FLAG_WORDS * sizeof(unsigned) + (size_t)NPB_NUM_PUMPS * npad * (sizeof(double) + sizeof(uint32_t));
 }
 extern "C" void NPB_LAUNCHER(observe)(int mode, int n_plants, size_t npad, const void *arena, double *obs, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);

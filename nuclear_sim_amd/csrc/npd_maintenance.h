@@ -297,6 +297,83 @@ NPD_FN int npd_maint_close_order(npb_mpump_t *mp, npb_maint_t *m, int action) {
   return bearing;
 }
 
+/* ---- the threshold screen INSIDE the step kernels.  What nearly every step of nearly every plant ends with is "nothing new":
+ * no threshold is crossed, or the crossed ones are inside their cooldown (a running pump's oil temperature sits above its
+ * 55 C row for the whole run, one violation per week).  The pump phase of the step holds the sixteen values the thresholds
+ * look at in registers when it has just updated a pump, so it answers that question there -- for (64 plants, pump) at a time,
+ * one flag word -- instead of a separate launch reading them back (0.5 KB per plant and step, which at 65 536 plants pushed
+ * the step's working set further past the Infinity Cache and slowed the step kernel itself by a quarter).
+ *   The table is folded by the host (npb_kernels.hip, npd_maint_fold_table) so that a strict comparison "value > threshold" /
+ * "value < threshold" is the sign of d = fma(value, sgn, c) with (sgn, c) = (+1, -threshold) / (-1, +threshold): exact -- the
+ * difference of two distinct doubles never rounds to zero, a NaN value gives a NaN that max() drops as `NaN > x` is false --
+ * and a row outside the scan has (0, -1).  Rows with any other comparison (>=, <=, ==, !=) make the whole table "always"
+ * flagged and leave the decision to the rule kernel's own evaluation.
+ *   Cooldowns: which rows of a (plant, pump) are inside their cooldown, and until when at the earliest, is kept in a side
+ * cache the handle owns (NOT plant state: it is a function of the mpump.last_violation_time stamps, the table and the clock,
+ * rebuilt by the rule kernel whenever it looks at a wave, and zeroed -- "look now" -- by every call that can change any of
+ * those).  A cooling row's d gets its sign bit set; the pump is flagged when a row outside the mask is crossed or when the
+ * earliest expiry has come (taken a hair early: the rule kernel then decides with the reference's own comparison).
+ * A flag only says "look": cooldowns, the orchestrator and the work orders are the rule kernel's (npb_maint_kernel), which
+ * re-evaluates the flagged waves from the stored state.
+ *   tab[0..15] sgn   tab[16..31] c   tab[32] != 0: always flagged   tab[33] check interval [min] */
+#define NPD_MH_N 34
+struct npd_maint_hot_t { double tab[NPD_MH_N]; };
+/* flag words per wave of 64 plants: [0..3] pump k has a lane with something new, [4] a lane whose check is due finds open
+ * work orders; [5..7] unused */
+#define NPD_MAINT_FLAG_WORDS 8
+/* the side cache: mask[pump][pitch] (uint32: bit q = row q of the table is inside its cooldown), until[pump][pitch] (double:
+ * no masked row leaves its cooldown before this time [min]; +inf with an empty mask; 0 = unknown, look) */
+struct npd_maint_cache_t { uint32_t *mask; double *until; size_t pitch; };
+__device__ __forceinline__ uint32_t *npd_maint_cache_mask(const npd_maint_cache_t &C, int k, size_t p) { return C.mask + (size_t)k * C.pitch + p; }
+__device__ __forceinline__ double *npd_maint_cache_until(const npd_maint_cache_t &C, int k, size_t p) { return C.until + (size_t)k * C.pitch + p; }
+/* tl: the table in LDS (every lane reads the same word: a broadcast).  (npd_real_t): the value as the arena will hold it
+ * (rounded to float under fp32 storage), which is what the rule kernel will see.  t: the plant's clock after this step */
+template <typename TL>
+__device__ __forceinline__ bool npd_maint_pump_hit(const npb_pump_t *pm, TL tl, uint32_t cooling_mask, double cooling_until, double t) {
+  double v[NPB_MAINT_NPARAM];
+  npd_maint_values(pm, v);
+  double m = -1.0;
+#pragma unroll
+  for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
+    const double d = __builtin_fma((double)(npd_real_t)v[q], tl[q], tl[NPB_MAINT_NPARAM + q]);
+    /* a row inside its cooldown cannot fire: its d is made negative (sign bit from bit q of the mask) */
+    const uint32_t hi = (uint32_t)__double2hiint(d) | ((cooling_mask << (31 - q)) & 0x80000000u);
+    m = __builtin_fmax(m, __hiloint2double((int)hi, __double2loint(d)));
+  }
+  return (m > 0.0) | (tl[2 * NPB_MAINT_NPARAM] != 0.0) | !(t < cooling_until);
+}
+/* the cache entry of one (plant, pump) from its stamps, as of time t (the rule kernel, after it has looked at a wave) */
+__device__ __forceinline__ void npd_maint_cache_entry(const double *last_violation_time, const double *cooldown_minutes, uint32_t scan_mask, double t,
+                                                      uint32_t *mask_out, double *until_out) {
+  uint32_t mask = 0; double until = __builtin_inf();
+#pragma unroll
+  for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
+    const double lv = last_violation_time[q];
+    const bool cooling = ((scan_mask >> q) & 1u) && (lv >= 0.0) && (t - lv < cooldown_minutes[q]);     /* _is_threshold_in_cooldown */
+    if (cooling) {
+      mask |= 1u << q;
+      const double ends = lv + cooldown_minutes[q];
+      until = fmin(until, ends - (fabs(ends) * 1e-9 + 1e-9));     /* a hair early: rounding of (t - lv) must never hide an expiry */
+    }
+  }
+  *mask_out = mask; *until_out = until;
+}
+/* AutoMaintenanceSystem.update as far as it needs no order (auto_maintenance.py:200-236): a check that falls due with nothing
+ * open only moves last_check_time; one that finds open orders is left, untouched, to the rule kernel.  Returns "work". */
+__device__ __forceinline__ bool npd_maint_due_check(npd_real_t *f64, size_t N, size_t p, double t, double check_interval_minutes) {
+  npd_real_t *lct_p = (npd_real_t *)((char *)(f64 + (size_t)(NPD_SEC_COL(MAINT, 0) + NPB_F64_SLOT(npb_maint_t, last_check_time)) * N + p));
+  const char *cnt = (const char *)(f64 + (size_t)(NPD_SEC_COL(MAINT, 0) + NPB_MAINT_NCARRY) * N + p);
+  const double last_check_time = (double)*lct_p;
+  const int created = *(const int32_t *)(cnt + ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, work_orders_created)) / NPD_NPC) * N * sizeof(npd_real_t) +
+                                         ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, work_orders_created)) % NPD_NPC) * 4);
+  const int performed = *(const int32_t *)(cnt + ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, maintenance_actions_performed)) / NPD_NPC) * N * sizeof(npd_real_t) +
+                                           ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, maintenance_actions_performed)) % NPD_NPC) * 4);
+  const bool due = !(last_check_time > 0.0 && t - last_check_time < check_interval_minutes);    /* npd_maint_check_due */
+  const bool work = due & (created > performed);
+  if (due & !work) *lct_p = (npd_real_t)t;
+  return work;
+}
+
 NPD_FN void npd_mpump_init(npb_mpump_t *mp) {
   memset(mp, 0, sizeof(*mp));
 #pragma unroll

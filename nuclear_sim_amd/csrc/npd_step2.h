@@ -65,7 +65,8 @@ enum {
   X_PUMP = 10, X_PUMP_N = 13,
   /* steam generators 1, 2 between their two parts: heat transfer, and the fp64 values of the two output members
    * (stored as float) that are still needed: TSP pressure-drop ratio, secondary temperature */
-  X_SGCARRY = 62, X_FLAG2 = 68,
+  X_SGCARRY = 62, X_FLAG2 = 68, X_MAINT_TAB = 69,
+  X_MAINT_TIME = 67,   /* the plants' clock after this step, wave A -> wave B's pump phase (the steam-generator carry region is not in use yet) */
   X_FWFLOW = 70, X_RUNCOUNT = 71, X_CIN0 = 72, X_COUT0 = 73, X_CIN1 = 79, X_COUT1 = 74,   /* (74: before the turbine phase) */
   /* SG 1, SG 2 -> wave A (reuses the pump region): 6 values each */
   X_SG1 = 10, X_SG2 = 16,
@@ -79,7 +80,7 @@ enum {
   /* transposes */
   X_OBS = 22, X_INFO = 46
 };
-static_assert(X_PUMP + 4 * X_PUMP_N <= X_SGCARRY && X_SGCARRY + 6 <= X_FLAG2 && X_OBS + NPB_OBS_PAD <= X_INFO && X_INFO + NPB_OBS_PAD <= X_TAIL2 && X_TAIL2 + 3 <= X_MAXSTRESS, "exchange slot plan");
+static_assert(NPD_MH_N <= NPB_WAVE && X_FLAG2 < X_MAINT_TAB && X_MAINT_TAB < X_FWFLOW && X_PUMP + 4 * X_PUMP_N <= X_SGCARRY && X_SGCARRY + 6 <= X_FLAG2 && X_OBS + NPB_OBS_PAD <= X_INFO && X_INFO + NPB_OBS_PAD <= X_TAIL2 && X_TAIL2 + 3 <= X_MAXSTRESS, "exchange slot plan");
 
 /* [64][W] block held one row per lane -> row-major global memory through a transpose buffer of this wave's own */
 template <int W>
@@ -298,7 +299,7 @@ __device__ __forceinline__ void npd_step2_body(
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
     const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,
     double *__restrict__ reward_out, uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out,
-    double *__restrict__ info_out) {
+    double *__restrict__ info_out, const npd_maint_hot_t &MH, unsigned *__restrict__ maint_flags, const npd_maint_cache_t &MC) {
   __shared__ __attribute__((aligned(16))) double xch[NPD2_SLOTS * NPB_WAVE];
   const int lane = threadIdx.x & (NPB_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform role: 0 = A, 1 = B */
@@ -316,9 +317,15 @@ __device__ __forceinline__ void npd_step2_body(
     st.grp16 = 0;
   }
 
+  /* automatic maintenance on: the folded threshold table (npd_maintenance.h, "the threshold screen inside the step kernels")
+   * goes to exchange slot X_MAINT_TAB, which nothing else uses, written by wave A before barrier #1 and read by both waves'
+   * pump phases behind it */
+  const bool maint = P.maint_enabled && maint_flags != nullptr;
+  double *const maint_tab = xch + X_MAINT_TAB * NPB_WAVE;
   NPD2_STAMP(0);
   if (wave == 0) {
     /* =========================================== wave A =========================================== */
+    if (maint && lane < NPD_MH_N) maint_tab[lane] = MH.tab[lane];
     npd_inputs_t in;
     in.action = (live && action) ? action[p] : 8;
     in.magnitude = (live && magnitude) ? magnitude[p] : 1.0;
@@ -371,6 +378,12 @@ __device__ __forceinline__ void npd_step2_body(
       thermal_power_info = s.thermal_power_mw; reactivity_info = s.total_reactivity_pcm; time_info = s.sim_time;
       s.has_heat_removal_factor = 1;
       NPD_ST_STORE_ELIDE_PRIM(s, s_old);
+      if (maint) {   /* sim.py:208-216 as far as no work order is involved; t = the clock after this step */
+        XW(X_MAINT_TIME, s.sim_time);
+        const bool work = npd_maint_due_check(f64, N, p, s.sim_time, MH.tab[2 * NPB_MAINT_NPARAM + 1]);
+        const bool any = __builtin_amdgcn_ballot_w64(work) != 0;
+        if (lane == 0) maint_flags[(size_t)blockIdx.x * NPD_MAINT_FLAG_WORDS + 4] = any ? 1u : 0u;
+      }
     }
     /* ---- secondary prelude (secondary/__init__.py:371-453) */
     cooling_water_temperature = (double)NPD_ST_F64(SEC, npb_sec_t, cooling_water_temperature, 0, 0);
@@ -425,9 +438,15 @@ __device__ __forceinline__ void npd_step2_body(
       npb_pump_t pm;
       NPD_ST_LOAD(PUMP, npb_pump_t, pm, i);
       const npb_pump_t pm_old = pm;
+      uint32_t cooling_mask = 0; double cooling_until = 0.0;     /* this (plant, pump)'s entry of the cooldown cache */
+      if (maint) { cooling_mask = *npd_maint_cache_mask(MC, i, p); cooling_until = *npd_maint_cache_until(MC, i, p); }
       npd2_pump(&pm, running_count < n_prev_running, n_prev_running, flow_per_pump, &sc, dt);
       running_count += pm.status == NPD_PUMP_RUNNING;
       npd2_publish_pump(xch, lane, i, pm);
+      if (maint) {   /* anything new at this pump, for any plant of the group?  (npd_maintenance.h) */
+        const bool any = __builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, time_info)) != 0;
+        if (lane == 0) maint_flags[(size_t)blockIdx.x * NPD_MAINT_FLAG_WORDS + i] = any ? 1u : 0u;
+      }
       NPD_ST_STORE_ELIDE(PUMP, npb_pump_t, pm, pm_old, i);
     }
     if (serial_pumps) { XW(X_RUNCOUNT, (double)running_count); NPD2_SYNC_(); }                       /* #1b */
@@ -691,16 +710,23 @@ __device__ __forceinline__ void npd_step2_body(
     npd_pump_sysconds_t sc;
     sc.feedwater_temperature = 40.0; sc.suction_pressure = 0.5; sc.discharge_pressure = 7.4; sc.max_sg_level = XR(X_MAXLVL);
     int running_count = 0;
+    const double maint_time_b = maint ? XR(X_MAINT_TIME) : 0.0;
     if (serial_pumps) { NPD2_SYNC_(); running_count = (int)XR(X_RUNCOUNT); }                         /* #1b */
 #pragma unroll 1
     for (int i = 2; i < NPB_NUM_PUMPS; i++) {
       npb_pump_t pm;
       NPD_ST_LOAD(PUMP, npb_pump_t, pm, i);
       const npb_pump_t pm_old = pm;
+      uint32_t cooling_mask = 0; double cooling_until = 0.0;
+      if (maint) { cooling_mask = *npd_maint_cache_mask(MC, i, p); cooling_until = *npd_maint_cache_until(MC, i, p); }
       /* parallel mode: the gate cannot close (serial_pumps is false for every lane), so its outcome needs no count */
       npd2_pump(&pm, serial_pumps ? (running_count < n_prev_running) : 1, n_prev_running, flow_per_pump, &sc, dt);
       running_count += pm.status == NPD_PUMP_RUNNING;
       npd2_publish_pump(xch, lane, i, pm);
+      if (maint) {
+        const bool any = __builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, maint_time_b)) != 0;
+        if (lane == 0) maint_flags[(size_t)blockIdx.x * NPD_MAINT_FLAG_WORDS + i] = any ? 1u : 0u;
+      }
       NPD_ST_STORE_ELIDE(PUMP, npb_pump_t, pm, pm_old, i);
     }
     NPD2_SYNCJ(2);                                                                                     /* #2 */
@@ -861,8 +887,8 @@ __device__ __forceinline__ void npd_step2_body(
     npb_params_t P, int n_plants, size_t N, npd_real_t *__restrict__ f64, const int32_t *__restrict__ action, \
     const double *__restrict__ magnitude, const double *__restrict__ setpoint, const double *__restrict__ noise_z, \
     const double *__restrict__ cw_temp, double *__restrict__ obs_out, double *__restrict__ reward_out, uint8_t *__restrict__ done_out, \
-    uint32_t *__restrict__ trip_out, double *__restrict__ info_out
-#define NPD2_KERNEL_PASS P, n_plants, N, f64, action, magnitude, setpoint, noise_z, cw_temp, obs_out, reward_out, done_out, trip_out, info_out
+    uint32_t *__restrict__ trip_out, double *__restrict__ info_out, npd_maint_hot_t MH, unsigned *__restrict__ maint_flags, npd_maint_cache_t MC
+#define NPD2_KERNEL_PASS P, n_plants, N, f64, action, magnitude, setpoint, noise_z, cw_temp, obs_out, reward_out, done_out, trip_out, info_out, MH, maint_flags, MC
 /* two waves per SIMD (256 registers each, part of the state spilled): for batches between one and two waves per SIMD */
 __global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(NPD2_KERNEL_ARGS) { npd_step2_body(NPD2_KERNEL_PASS); }
 /* one wave per SIMD and the whole register file: up to 32 768 plants (1 024 waves) nothing is gained by leaving room for a

@@ -436,7 +436,7 @@ def _c4_run(job):
 
 
 def make_c4_counts(seeds=tuple(range(64)), steps=48, procs=8):
-    """tests/golden/c4_counts_64seeds.npz -- BASELINE config 4's headline quantity held by the reference itself: 64 simulators
+    """tests/golden/counts_c4_64seeds.npz -- BASELINE config 4's headline quantity held by the reference itself: 64 simulators
     as MaintenanceScenarioRunner builds them for compose_action_test_scenario("oil_top_off", randomize=True,
     randomization_seed=s) (maintenance_scenario_runner.py:210-244; seeds 0..63 fall into all three catalog scenarios,
     randomization_utils.py:770-797), each run for `steps` steps of 5 minutes under the runner's own power profile
@@ -451,7 +451,7 @@ def make_c4_counts(seeds=tuple(range(64)), steps=48, procs=8):
         results = pool.map(_c4_run, [(s, steps) for s in seeds], chunksize=1)
     results.sort(key=lambda r: r[0])
     created_col = labels.index("maint.work_orders_created"); performed_col = labels.index("maint.maintenance_actions_performed")
-    np.savez_compressed(os.path.join(OUT, "c4_counts_64seeds.npz"),
+    np.savez_compressed(os.path.join(OUT, "counts_c4_64seeds.npz"),
                         seeds=np.array([r[0] for r in results]), setpoint=np.array([r[1] for r in results]), noise_z=results[0][2],
                         initial_state=np.array([r[3][0] for r in results]), final_state=np.array([r[3][-1] for r in results]),
                         created=np.array([r[3][1:, created_col] for r in results]).astype(np.int32),

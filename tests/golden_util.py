@@ -20,7 +20,7 @@ ATOL_SMALL = 1e-12
 def fixture_names():
     """trajectory fixtures (ic_*.npz hold initial states only, tests/test_scenarios.py)"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if not n.startswith(("ic_", "log_"))]     # log_*: the reference's own state log of a fixture's run
+    return [n for n in names if not n.startswith(("ic_", "log_", "counts_"))]     # log_*: the reference's own state log of a fixture's run
 
 
 class Golden:
@@ -101,14 +101,14 @@ def compare_state(g, f64, i32, row, where):
 
 
 class Config4Counts:
-    """tests/golden/c4_counts_64seeds.npz (oracle/ref_harness/make_golden.py make_c4_counts): 64 simulators as the data-gen
+    """tests/golden/counts_c4_64seeds.npz (oracle/ref_harness/make_golden.py make_c4_counts): 64 simulators as the data-gen
     runner builds them for the randomised oil_top_off action test, run by the REFERENCE for 48 steps of 5 minutes -- BASELINE
     config 4's per-plant quantities: work orders created / maintenance actions performed after every step, and the initial
     and final value of every schema column (oil levels, executions by action, open orders, cooldown stamps)."""
 
     def __init__(self):
-        z = np.load(os.path.join(GOLDEN_DIR, "c4_counts_64seeds.npz"), allow_pickle=False)
-        self.name = "c4_counts_64seeds"
+        z = np.load(os.path.join(GOLDEN_DIR, "counts_c4_64seeds.npz"), allow_pickle=False)
+        self.name = "counts_c4_64seeds"
         self.meta = json.loads(str(z["meta"]))
         self.seeds = [int(s) for s in z["seeds"]]
         self.setpoint, self.noise_z = z["setpoint"], z["noise_z"]

@@ -356,7 +356,7 @@ def test_config4_randomized_oil_top_off_scenario(oracle_lib):
 
 def test_config4_counts_held_by_the_reference():
     """BASELINE config 4's headline quantity against the REFERENCE, not the oracle: BatchedPlantEnv.action_test("oil_top_off",
-    seeds) for the 64 seeds of tests/golden/c4_counts_64seeds.npz (runner-built reference simulators, all three catalog
+    seeds) for the 64 seeds of tests/golden/counts_c4_64seeds.npz (runner-built reference simulators, all three catalog
     scenarios), 48 steps of 5 min under the recorded set-points -- work_orders_created and maintenance_actions_performed after
     every step bit-exact, and at the end every column: executions by action, final oil levels, open orders, cooldown stamps."""
     from golden_util import Config4Counts
