@@ -288,7 +288,7 @@ def main():
     from nuclear_sim_amd import _lib
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
-    def raw_step(t):  # the C-ABI call alone: npb_step_kernel (+ npb_maint_kernel with --maintenance), no host-side extras
+    def raw_step(t):  # the C-ABI call alone: one launch of the step kernel, no host-side extras
         _lib.check(env.L.npb_step(env._h, None, None, ctypes.c_void_p(setpoints[t % total].data_ptr()),
                                   ctypes.c_void_p(noise[t % total].data_ptr()), None, env._p(env._obs), env._p(env._reward),
                                   env._p(env._done), env._p(env._flags), env._p(env._info), stream), env._h)
@@ -353,7 +353,7 @@ def main():
                                             "(measured writes ~200 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "
                                             "of the reads is served by the 256 MB Infinity Cache; NULL inputs (20 B/plant) are "
                                             "already excluded",
-                         "kernel": launched_kernel + (" + npb_maint_kernel" if args.maintenance else ""),
+                         "kernel": launched_kernel + (" (automatic maintenance inside: threshold screen in the pump phase, rule by function call for flagged waves)" if args.maintenance else ""),
                          "kernel_ms": kernel_ms},
             "preconditioning": {"ms": precondition_ms, "what": "a scratch handle of the same size stepped on the same inputs before the %d warm-up "
                                 "steps of the benchmarked one (whose state is not advanced), so that the timed steps run at the GPU's "

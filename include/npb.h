@@ -138,6 +138,11 @@ NPB_API int npb_set_params(NpbHandle *h, const npb_params_t *params);
  * version 1 (params.maint_oil_level_threshold / _cooldown_hours); a table set here is taken exactly as given. */
 NPB_API int npb_set_maintenance_table(NpbHandle *h, const npb_maint_table_t *table);
 NPB_API void npb_default_maintenance_table(npb_maint_table_t *table);
+/* AutoMaintenanceSystem.maintenance_actions_performed of every plant as a column the caller owns (device, int32[n_plants]; NULL =
+ * none): with params.maint_enabled every npb_step leaves it current -- filled whole after any call that may have changed state,
+ * then kept by the maintenance rule kernel for the plants whose count it moves -- so a loop that wants the event counts after
+ * each step (the data-gen runner does, maintenance_scenario_runner.py:392-411) needs no npb_get_field launch per step. */
+NPB_API int npb_set_maintenance_count_buffer(NpbHandle *h, int32_t *counts);
 
 /* re-initialise plants to the construction-time state; mask (device, uint8[n], NULL = all) selects plants.
  * Stands in for constructing a fresh simulator (the data-gen runner's episode start,

@@ -146,6 +146,8 @@ def load():
     if hasattr(L, "npb_set_diagnostics"):     # (absent from builds older than ABI 133: tools/ab_kernel.py loads those)
         L.npb_set_diagnostics.argtypes = [vp, vp, ctypes.c_size_t]
     L.npb_set_maintenance_table.argtypes = [vp, ctypes.POINTER(NpbMaintTable)]
+    if hasattr(L, "npb_set_maintenance_count_buffer"):
+        L.npb_set_maintenance_count_buffer.argtypes = [vp, vp]
     L.npb_default_maintenance_table.argtypes = [ctypes.POINTER(NpbMaintTable)]
     L.npb_reset_reference.argtypes = [vp, vp, ci, vp]
     L.npb_get_field.argtypes = [vp, ci, ci, vp, ci, vp]

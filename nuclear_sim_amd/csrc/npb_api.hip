@@ -20,8 +20,10 @@ struct NpbHandle {
   size_t real_bytes;   /* 8 | 4 */
   void *f64;           /* the arena: [NPB_TOTAL_COL64][pitch] 8-byte columns, or [NPB_TOTAL_COL32][pitch] 4-byte ones */
   double *convert;     /* one staging column (pitch doubles) used by get/set_field with host buffers */
-  unsigned *maint_flags; /* the step kernel's maintenance flag words, per wave of plants (npd_maintenance.h; behind the staging column) */
+  void *maint_side;      /* automatic maintenance: the rule's constants as the device reads them + the screen's cooldown cache (npb_kernels.hip; behind the staging column) */
+  std::vector<char> maint_consts_host;
   double *diag; size_t diag_pitch; /* npb_set_diagnostics: the caller's [NPB_DIAG_DIM][diag_pitch] buffer, or NULL */
+  int32_t *maint_counts;           /* npb_set_maintenance_count_buffer: the caller's [n_plants] int32 column, or NULL */
   bool maint_cache_stale;          /* the cooldown cache of the step kernels' maintenance screen must be zeroed before the next step */
   int last_kernel;                 /* NPB_KERNEL_*: what the last npb_step launched */
   int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel, 3 = its two-waves-per-SIMD build, 4 = one-wave with streaming stores (npb_set_step_kernel) */
@@ -108,7 +110,7 @@ static void probe_placement(NpbHandle *h, size_t step_columns) {
   (narrow ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, h->pitch, cand[0], nullptr, nullptr);
   for (int k = 0; k < 200; k++)
     (void)(narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, cand[0], nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                         nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr, nullptr, nullptr);
+                                                         nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
   if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(a); (void)hipEventDestroy(b); return; }
   int n = 0;
   for (; n < max_candidates; n++) {
@@ -118,7 +120,7 @@ static void probe_placement(NpbHandle *h, size_t step_columns) {
     for (int k = 0; k < launches; k++) {
       (void)hipEventRecord(a, nullptr);
       (void)(narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, cand[n], nullptr, nullptr, nullptr, nullptr, nullptr,
-                                                           nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr, nullptr, nullptr);
+                                                           nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
       (void)hipEventRecord(b, nullptr);
       if (hipEventSynchronize(b) != hipSuccess) { best = 1e30f; break; }
       float t = 0;
@@ -217,14 +219,14 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   h->f64 = nullptr; h->convert = nullptr; h->plan_dev = nullptr;
   e = hipMalloc(&h->f64, arena_columns(storage) * h->pitch * real_bytes);
   if (e == hipSuccess) probe_placement(h, step_columns);
-  if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double) + npb_launch_maint_flag_bytes(h->pitch));
+  if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double) + npb_launch_maint_side_bytes(h->pitch));
   if (e != hipSuccess) {
     if (h->f64) (void)hipFree(h->f64);
     delete h;
     if (caller_device >= 0) (void)hipSetDevice(caller_device);
     return fail(nullptr, NPB_ENOMEM, "npb_create: hipMalloc of the state arena failed", e);
   }
-  h->maint_flags = (unsigned *)(h->convert + h->pitch);
+  h->maint_side = (void *)(h->convert + h->pitch);
   h->maint_cache_stale = true;
   (storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, n_plants, h->pitch, h->f64, nullptr, nullptr);
   e = hipDeviceSynchronize();
@@ -288,6 +290,12 @@ int npb_set_maintenance_table(NpbHandle *h, const npb_maint_table_t *table) {
   h->maint_table = *table;
   h->maint_table_custom = true;
   h->maint_cache_stale = true;
+  return NPB_OK;
+}
+int npb_set_maintenance_count_buffer(NpbHandle *h, int32_t *counts) {
+  if (!h) return NPB_EINVAL;
+  h->maint_counts = counts;
+  h->maint_cache_stale = true;     /* filled whole before the next step */
   return NPB_OK;
 }
 void npb_default_maintenance_table(npb_maint_table_t *table) { if (table) npb_maint_table_default(table); }
@@ -401,22 +409,33 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
   npb_maint_table_t table;
   const bool maint = h->params.maint_enabled != 0;
   if (maint) {
-    if (h->maint_cache_stale) {    /* zero = nothing known: every wave is looked at once and its entries rebuilt */
-      NPB_HIP(h, hipMemsetAsync(h->maint_flags, 0, (narrow ? npb32_launch_maint_flag_bytes : npb_launch_maint_flag_bytes)(h->pitch), (hipStream_t)stream));
-      h->maint_cache_stale = false;
-    }
     table = h->maint_table;
     if (!h->maint_table_custom) {   /* with the default table the two oil_level params of ABI version 1 still set their row */
       table.threshold[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_threshold;
       table.cooldown_hours[NPB_MP_OIL_LEVEL] = h->params.maint_oil_level_cooldown_hours;
     }
+    if (h->maint_cache_stale) {
+      /* parameters, table, state or clock may have changed since the last step: the rule's constants go to the device anew and
+       * the screen's cooldown cache is zeroed (= nothing known: every wave is looked at once and its entries rebuilt) */
+      h->maint_consts_host.resize(npb_launch_maint_consts_bytes());
+      npb_launch_maint_consts(&h->params, &table, h->maint_consts_host.data());
+      NPB_HIP(h, hipMemcpyAsync(h->maint_side, h->maint_consts_host.data(), h->maint_consts_host.size(), hipMemcpyHostToDevice, (hipStream_t)stream));
+      NPB_HIP(h, hipStreamSynchronize((hipStream_t)stream));      /* the host copy may change again before an asynchronous copy would read it */
+      NPB_HIP(h, hipMemsetAsync((char *)h->maint_side + npb_launch_maint_cache_offset(), 0, npb_launch_maint_side_bytes(h->pitch) - npb_launch_maint_cache_offset(),
+                                (hipStream_t)stream));
+      if (h->maint_counts) {       /* the caller's event-count column: whole once, then kept by the rule for the plants whose count it moves */
+        int col, sub, akind;
+        if (locate(h->storage, NPB_KIND_I32, NPB_MAINT_I32_BASE + NPB_I32_SLOT(npb_maint_t, MAINT, maintenance_actions_performed), &col, &sub, &akind))
+          (narrow ? npb32_launch_field_get : npb_launch_field_get)(h->f64, h->pitch, col, sub, akind, h->maint_counts, h->n_plants, (hipStream_t)stream);
+      }
+      h->maint_cache_stale = false;
+    }
   }
   h->last_kernel = (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, action, magnitude, power_setpoint,
                                                  noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, h->step_kernel, h->diag, h->diag_pitch,
-                                                 maint ? &table : nullptr, maint ? h->maint_flags : nullptr, (hipStream_t)stream);
-  if (maint)   /* the pump phase of a full-mode step kernel has answered "is any threshold crossed" into the flag words */
-    (narrow ? npb32_launch_maint : npb_launch_maint)(&h->params, &table, h->pitch, h->f64, h->maint_flags, h->params.mode == NPB_MODE_FULL,
-                                                     (hipStream_t)stream);
+                                                 maint ? &table : nullptr, maint ? h->maint_side : nullptr, maint ? h->maint_counts : nullptr, (hipStream_t)stream);
+  if (maint && h->params.mode != NPB_MODE_FULL)   /* a full-mode step kernel has run the rule itself, for the waves whose pump phase found something */
+    (narrow ? npb32_launch_maint : npb_launch_maint)(h->pitch, h->f64, h->maint_side, h->maint_counts, h->n_plants, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_step: kernel launch failed", e);
   return NPB_OK;

@@ -15,9 +15,12 @@ extern "C" {
   int prefix##step(const npb_params_t *P, int n_plants, size_t npad, void *arena, const int32_t *action, \
                     const double *magnitude, const double *setpoint, const double *noise_z, const double *cw_temp, \
                     double *obs, double *reward, uint8_t *done, uint32_t *trip_flags, double *info, int variant, double *diag, size_t diag_pitch, \
-                    const npb_maint_table_t *maint_table, unsigned *maint_flags, hipStream_t stream); \
-  void prefix##maint(const npb_params_t *P, const npb_maint_table_t *T, size_t npad, void *arena, unsigned *wave_flags, int flags_from_step, hipStream_t stream); \
-  size_t prefix##maint_flag_bytes(size_t npad); \
+                    const npb_maint_table_t *maint_table, void *maint_side, int32_t *maint_counts, hipStream_t stream); \
+  void prefix##maint(size_t npad, void *arena, void *maint_side, int32_t *counts, int n_plants, hipStream_t stream); \
+  void prefix##maint_consts(const npb_params_t *P, const npb_maint_table_t *T, void *host_out); \
+  size_t prefix##maint_consts_bytes(void); \
+  size_t prefix##maint_side_bytes(size_t npad); \
+  size_t prefix##maint_cache_offset(void); \
   void prefix##observe(int mode, int n_plants, size_t npad, const void *arena, double *obs, hipStream_t stream); \
   void prefix##init(const npb_params_t *P, int n_plants, size_t npad, void *arena, const uint8_t *mask, hipStream_t stream); \
   void prefix##reset(const npb_params_t *P, int n_plants, size_t npad, void *arena, const uint8_t *mask, int steady, hipStream_t stream); \

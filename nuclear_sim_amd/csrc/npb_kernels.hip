@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "npd_common.h"
 /* diagnostic build only (-DNPB_STAMPS, tools/phase_stamps.py): lane 0 of every wave records s_memtime
  * at phase boundaries so the kernel's time can be attributed to phases on the GPU */
@@ -370,12 +371,161 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_primary_kernel(
   }
 }
 
+/* automatic maintenance after a step (params.maint_enabled): AutoMaintenanceSystem.update, then the state manager's
+ * threshold scan with work-order creation (npd_maintenance.h), for the four feedwater pumps -- inside the step kernels:
+ *   the screen   what nearly every step of nearly every plant ends with is "nothing new".  The pump phase answers "is any
+ *     threshold of this pump crossed outside its cooldown" from the registers it has just updated, the primary phase moves
+ *     last_check_time where a check fell due with no order open (npd_maintenance.h).
+ *   the rule     a wave that did find something calls npd_maint_rule_for_wave before it ends: first a proper look -- the
+ *     rows' real comparisons on the stored state, then that pump's 16 last-violation stamps: a crossed threshold inside
+ *     its cooldown is no work -- and only then the full rule for its 64 plants: work orders, the orchestrator, the
+ *     thirteen handlers.  A real function call (noinline), so that its registers and its scratch are its own: rare, so it is
+ *     written for clarity, not for registers, and the step kernels' own allocation does not see it.  Its constants -- the
+ *     parameters, the table -- come from device memory (npd_maint_rule_consts_t, uploaded by npb_step when they change).
+ * No second launch: a separate rule kernel cost 4-5 us per step just to find nothing flagged (its code and arguments are
+ * cold behind the step kernel's 500 MB sweep), more than the whole screen.  npb_maint_kernel below is the same rule for the
+ * modes whose step kernels do not step the pumps. */
+#define NPD_MP_COL(inst, member, k) (NPD_SEC_COL(MPUMP, inst) + NPB_F64_SLOT(npb_mpump_t, member) + (k))
+#define NPD_MP_LOAD(inst, member, count) do { _Pragma("unroll") for (int q__ = 0; q__ < (count); q__++) \
+    mp.member[q__] = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(inst, member, q__)); } while (0)
+#define NPD_MP_STORE(inst, member, count) do { _Pragma("unroll") for (int q__ = 0; q__ < (count); q__++) \
+    *(npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(inst, member, q__)) = (npd_real_t)mp.member[q__]; } while (0)
+/* the proper look's view of the table: scan membership folded into the comparison masks on the host side */
+struct npd_maint_screen_t {
+  double threshold[NPB_MAINT_NPARAM];
+  double cooldown_minutes[NPB_MAINT_NPARAM];
+  uint32_t want_gt, want_lt, want_eq, want_near, want_far;    /* bit q: row q fires on value > / < / == threshold, |value - threshold| < / >= 0.001 */
+};
+struct npd_maint_rule_consts_t { npb_params_t P; npb_maint_table_t T; npd_maint_screen_t S; };
+/* does pump k of this lane's plant have a crossed threshold outside its cooldown?  (StateManager._check_maintenance_thresholds up
+ * to the point where a violation is recorded, state_manager.py:1307-1369) */
+__device__ __forceinline__ bool npd_maint_second_look(const npd_maint_screen_t &S, const npd_real_t *f64c, size_t N, size_t p, int k, double t) {
+  npd_real_t *f64 = const_cast<npd_real_t *>(f64c);
+  npb_pump_t pm;      /* only the members npd_maint_values reads are loaded */
+#define NPD_PM(member) pm.member = NPD_F64_COL(PUMP, npb_pump_t, member, k)
+  NPD_PM(oil_level); NPD_PM(oil_contamination); NPD_PM(lubrication_effectiveness); NPD_PM(wear_impeller); NPD_PM(cavitation_damage);
+  NPD_PM(cavitation_intensity); NPD_PM(npsh_available); NPD_PM(wear_motor_bearings); NPD_PM(wear_pump_bearings); NPD_PM(wear_thrust_bearing);
+  NPD_PM(wear_mechanical_seals); NPD_PM(vibration_level); NPD_PM(oil_temperature); NPD_PM(motor_temperature); NPD_PM(seal_leakage_rate);
+#undef NPD_PM
+  double values[NPB_MAINT_NPARAM];
+  npd_maint_values(&pm, values);
+  uint32_t hits = 0;
+#pragma unroll
+  for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
+    const double v = values[q], thr = S.threshold[q];
+    const bool near_eq = fabs(v - thr) < 0.001;                                  /* _check_threshold_condition */
+    const bool hit = ((((S.want_gt >> q) & 1u) != 0) & (v > thr)) | ((((S.want_lt >> q) & 1u) != 0) & (v < thr)) |
+                     ((((S.want_eq >> q) & 1u) != 0) & (v == thr)) | ((((S.want_near >> q) & 1u) != 0) & near_eq) |
+                     ((((S.want_far >> q) & 1u) != 0) & !near_eq);
+    hits |= (uint32_t)hit << q;
+  }
+  bool work = false;
+  if (__any(hits != 0)) {
+#pragma unroll
+    for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
+      const double lv = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q));
+      const bool cooling = (lv >= 0.0) & (t - lv < S.cooldown_minutes[q]);        /* _is_threshold_in_cooldown */
+      work |= (((hits >> q) & 1u) != 0) & !cooling;
+    }
+  }
+  return work;
+}
+/* the cooldown cache of the step kernels' screen (npd_maintenance.h) for the four pumps of this lane's plant, from the stamps as
+ * they are now: whenever the rule has looked at a wave */
+__device__ __forceinline__ void npd_maint_refresh_cache(const npd_maint_screen_t &S, npd_u32x4 *cache_entry, const npd_real_t *f64c, size_t N, size_t p, double t) {
+  npd_real_t *f64 = const_cast<npd_real_t *>(f64c);
+  const uint32_t scan_mask = S.want_gt | S.want_lt | S.want_eq | S.want_near | S.want_far;
+#pragma unroll 1
+  for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+    double lv[NPB_MAINT_NPARAM];
+#pragma unroll
+    for (int q = 0; q < NPB_MAINT_NPARAM; q++) lv[q] = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q));
+    uint32_t mask; float until;
+    npd_maint_cache_entry(lv, S.cooldown_minutes, scan_mask, t, &mask, &until);
+    uint32_t *e = (uint32_t *)(cache_entry + p * 2) + 2 * k;
+    e[0] = mask; e[1] = __float_as_uint(until);
+  }
+}
+/* one wave = the 64 plants p - lane .. p - lane + 63, whose step (all its stores) is complete.  hit_bits: bit k = the screen
+ * flagged pump k for some lane; due_with_orders: some lane's check falls on open orders (wave-uniform both) */
+/* WHO: one instantiation per calling kernel, so that each inherits its caller's register budget (the build of the two-wave
+ * kernel that shares a SIMD between two waves must not be dragged to one wave per SIMD by a callee with the whole file) */
+template <int WHO>
+__device__ __attribute__((noinline)) void npd_maint_rule_for_wave(const npd_maint_rule_consts_t *RC, npd_maint_cache_t MC, npd_real_t *f64, size_t N, size_t p,
+                                                                 unsigned hit_bits, unsigned due_with_orders) {
+  const npb_params_t &P = RC->P; const npb_maint_table_t &T = RC->T; const npd_maint_screen_t &S = RC->S;
+  const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
+  if (!due_with_orders) {   /* flagged by the screen alone: look properly before anything else is fetched */
+    bool work = false;
+#pragma unroll 1
+    for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+      if ((hit_bits >> k) & 1u) work |= npd_maint_second_look(S, f64, N, p, k, t);
+    }
+    if (!__any(work)) { npd_maint_refresh_cache(S, MC.entry, f64, N, p, t); return; }
+  }
+  npb_maint_t m;
+  NPD_LOAD(MAINT, npb_maint_t, m, 0);
+  int dirty = 0;
+  /* ---- AutoMaintenanceSystem.update: one due order, the earliest created, is carried out */
+  if (npd_maint_check_due(&m, &P, t)) {
+    dirty = 1;
+    if (m.work_orders_created > m.maintenance_actions_performed) {      /* some order is open */
+      double best = 0.0; int pick = -1, pick_action = -1;
+#pragma unroll 1
+      for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+        npb_mpump_t mp;
+        NPD_MP_LOAD(k, wo_order, NPB_MAINT_NACT); NPD_MP_LOAD(k, wo_planned_start, NPB_MAINT_NACT);
+        int a; const double o = npd_maint_first_due(&mp, t, &a);
+        if (o > 0.0 && (best == 0.0 || o < best)) { best = o; pick = k; pick_action = a; }
+      }
+      if (pick >= 0) {
+        npb_mpump_t mp;
+        NPD_MP_LOAD(pick, wo_order, NPB_MAINT_NACT); NPD_MP_LOAD(pick, wo_planned_start, NPB_MAINT_NACT);
+        mp.wo_bearing = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(pick, wo_bearing, 0));
+        const int bearing = npd_maint_close_order(&mp, &m, pick_action);
+        NPD_MP_STORE(pick, wo_order, NPB_MAINT_NACT); NPD_MP_STORE(pick, wo_planned_start, NPB_MAINT_NACT);
+        *(npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(pick, wo_bearing, 0)) = (npd_real_t)mp.wo_bearing;
+        npb_pump_t pm;
+        NPD_LOAD(PUMP, npb_pump_t, pm, pick);
+        npd_maint_execute(&pm, &P, pick_action, bearing);
+        NPD_STORE(PUMP, npb_pump_t, pm, pick);
+      }
+    }
+  }
+  /* ---- StateManager.collect_states: threshold scan, one orchestrated event per pump (after the work above, as the
+   * reference orders it) */
+#pragma unroll 1
+  for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+    npb_pump_t pm;
+    NPD_LOAD(PUMP, npb_pump_t, pm, k);
+    npb_mpump_t mp;
+    NPD_LOAD(MPUMP, npb_mpump_t, mp, k);
+    if (npd_maint_scan_pump(&mp, &m, &P, &T, &pm, t)) {
+      dirty = 1;
+      NPD_STORE(MPUMP, npb_mpump_t, mp, k);
+    }
+  }
+  if (dirty) {
+    NPD_STORE(MAINT, npb_maint_t, m, 0);
+    if (MC.counts && p < (size_t)MC.n_plants) MC.counts[p] = m.maintenance_actions_performed;
+  }
+  npd_maint_refresh_cache(S, MC.entry, f64, N, p, t);
+}
+/* the same rule as a launch of its own, every wave looked at in full: for the modes whose step kernels do not step the pumps
+ * (primary-only, primary + steam generators), where nothing has screened anything */
+__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(const npd_maint_rule_consts_t *RC, npd_maint_cache_t MC, size_t N, npd_real_t *__restrict__ f64) {
+  npd_maint_rule_for_wave<0>(RC, MC, f64, N, (size_t)blockIdx.x * NPB_WAVE + threadIdx.x, 0xFu, 1u);
+}
+
 #define NPD_SM 1          /* store mode of the kernels below (npd_store_real): the one-wave kernel's own 8-byte stores ... */
 #define NPD_STEP1_KERNEL npb_step_kernel
+#define NPD_STEP1_WHO 1
 #include "npd_step1.h"
 #undef NPD_STEP1_KERNEL
 /* the same step with the step-internal diagnostics written (npb_set_diagnostics): for state logging, not for throughput */
 #define NPD_STEP1_KERNEL npb_step_diag_kernel
+#undef NPD_STEP1_WHO
+#define NPD_STEP1_WHO 2
 #define NPD_STEP1_DIAG
 #include "npd_step1.h"
 #undef NPD_STEP1_DIAG
@@ -386,6 +536,8 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_primary_kernel(
 #undef NPD_SM
 #define NPD_SM 2
 #define NPD_STEP1_KERNEL npb_step_nt_kernel
+#undef NPD_STEP1_WHO
+#define NPD_STEP1_WHO 3
 #include "npd_step1.h"
 #undef NPD_STEP1_KERNEL
 #undef NPD_SM
@@ -499,154 +651,6 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_reset_kernel(npb_params_t P, siz
   /* the pH controller and its pending doses are not reset (secondary/__init__.py:1041-1072 never touches them) */
 }
 
-/* automatic maintenance after a step (params.maint_enabled): AutoMaintenanceSystem.update, then the state manager's
- * threshold scan with work-order creation (npd_maintenance.h), for the four feedwater pumps.
- *   in the step kernels   what nearly every step of nearly every plant ends with: nothing to do.  The pump phase answers
- *     "is any threshold of this pump crossed" from the registers it has just updated, the primary phase moves last_check_time
- *     where a check fell due with no order open; five flag words per wave of 64 plants (npd_maintenance.h).
- *   npb_maint_kernel      one launch behind the step: a fixed, small grid walks the flag words and leaves before it has
- *     fetched a single constant when nothing is flagged.  For a flagged (wave, pump) it first looks properly -- the rows'
- *     real comparisons on the stored state, then that pump's 16 last-violation stamps: a crossed threshold inside its
- *     cooldown is no work -- and only then runs the full rule for the 64 plants: work orders, the orchestrator, the thirteen
- *     handlers.  Rare, so it is written for clarity, not for registers. */
-#define NPD_MP_COL(inst, member, k) (NPD_SEC_COL(MPUMP, inst) + NPB_F64_SLOT(npb_mpump_t, member) + (k))
-#define NPD_MP_LOAD(inst, member, count) do { _Pragma("unroll") for (int q__ = 0; q__ < (count); q__++) \
-    mp.member[q__] = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(inst, member, q__)); } while (0)
-#define NPD_MP_STORE(inst, member, count) do { _Pragma("unroll") for (int q__ = 0; q__ < (count); q__++) \
-    *(npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(inst, member, q__)) = (npd_real_t)mp.member[q__]; } while (0)
-/* the second look's view of the table: scan membership folded into the comparison masks on the host side of the launch */
-struct npd_maint_screen_t {
-  double threshold[NPB_MAINT_NPARAM];
-  double cooldown_minutes[NPB_MAINT_NPARAM];
-  uint32_t want_gt, want_lt, want_eq, want_near, want_far;    /* bit q: row q fires on value > / < / == threshold, |value - threshold| < / >= 0.001 */
-};
-/* does pump k of this lane's plant have a crossed threshold outside its cooldown?  (StateManager._check_maintenance_thresholds up
- * to the point where a violation is recorded, state_manager.py:1307-1369) */
-__device__ __forceinline__ bool npd_maint_second_look(const npd_maint_screen_t &S, const npd_real_t *f64c, size_t N, size_t p, int k, double t) {
-  npd_real_t *f64 = const_cast<npd_real_t *>(f64c);
-  npb_pump_t pm;      /* only the members npd_maint_values reads are loaded */
-#define NPD_PM(member) pm.member = NPD_F64_COL(PUMP, npb_pump_t, member, k)
-  NPD_PM(oil_level); NPD_PM(oil_contamination); NPD_PM(lubrication_effectiveness); NPD_PM(wear_impeller); NPD_PM(cavitation_damage);
-  NPD_PM(cavitation_intensity); NPD_PM(npsh_available); NPD_PM(wear_motor_bearings); NPD_PM(wear_pump_bearings); NPD_PM(wear_thrust_bearing);
-  NPD_PM(wear_mechanical_seals); NPD_PM(vibration_level); NPD_PM(oil_temperature); NPD_PM(motor_temperature); NPD_PM(seal_leakage_rate);
-#undef NPD_PM
-  double values[NPB_MAINT_NPARAM];
-  npd_maint_values(&pm, values);
-  uint32_t hits = 0;
-#pragma unroll
-  for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
-    const double v = values[q], thr = S.threshold[q];
-    const bool near_eq = fabs(v - thr) < 0.001;                                  /* _check_threshold_condition */
-    const bool hit = ((((S.want_gt >> q) & 1u) != 0) & (v > thr)) | ((((S.want_lt >> q) & 1u) != 0) & (v < thr)) |
-                     ((((S.want_eq >> q) & 1u) != 0) & (v == thr)) | ((((S.want_near >> q) & 1u) != 0) & near_eq) |
-                     ((((S.want_far >> q) & 1u) != 0) & !near_eq);
-    hits |= (uint32_t)hit << q;
-  }
-  bool work = false;
-  if (__any(hits != 0)) {
-#pragma unroll
-    for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
-      const double lv = (double)__builtin_nontemporal_load((const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q)));
-      const bool cooling = (lv >= 0.0) & (t - lv < S.cooldown_minutes[q]);        /* _is_threshold_in_cooldown */
-      work |= (((hits >> q) & 1u) != 0) & !cooling;
-    }
-  }
-  return work;
-}
-
-/* the cooldown cache of the step kernels' screen (npd_maintenance.h) for the four pumps of this lane's plant, from the stamps as
- * they are now: whenever the rule kernel has looked at a wave */
-__device__ __forceinline__ void npd_maint_refresh_cache(const npd_maint_screen_t &S, const npd_maint_cache_t &MC, const npd_real_t *f64c, size_t N, size_t p, double t) {
-  npd_real_t *f64 = const_cast<npd_real_t *>(f64c);
-  const uint32_t scan_mask = S.want_gt | S.want_lt | S.want_eq | S.want_near | S.want_far;
-#pragma unroll 1
-  for (int k = 0; k < NPB_NUM_PUMPS; k++) {
-    double lv[NPB_MAINT_NPARAM];
-#pragma unroll
-    for (int q = 0; q < NPB_MAINT_NPARAM; q++) lv[q] = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(k, last_violation_time, q));
-    uint32_t mask; double until;
-    npd_maint_cache_entry(lv, S.cooldown_minutes, scan_mask, t, &mask, &until);
-    *npd_maint_cache_mask(MC, k, p) = mask;
-    *npd_maint_cache_until(MC, k, p) = until;
-  }
-}
-
-/* a fixed, small grid: each group walks the waves of plants it owns and works on the flagged ones */
-__global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(npb_params_t P, npb_maint_table_t T, npd_maint_screen_t S, size_t N, npd_real_t *__restrict__ f64,
-                                                             const unsigned *__restrict__ wave_flags, npd_maint_cache_t MC) {
-  const unsigned n_waves = (unsigned)(N / NPB_WAVE);
-  /* nothing flagged among this group's waves -- the usual case -- and it is gone before the rule's constants (most of P
-   * and T, which the compiler gathers into registers ahead of the loop) are even fetched */
-  unsigned mine = 0;
-#pragma unroll 1
-  for (unsigned w = blockIdx.x; w < n_waves; w += gridDim.x) {
-    const uint4 fa = *(const uint4 *)(wave_flags + (size_t)w * NPD_MAINT_FLAG_WORDS);
-    mine |= fa.x | fa.y | fa.z | fa.w | wave_flags[(size_t)w * NPD_MAINT_FLAG_WORDS + 4];
-  }
-  if (!mine) return;
-#pragma unroll 1
-  for (unsigned w = blockIdx.x; w < n_waves; w += gridDim.x) {
-  const uint4 fa = *(const uint4 *)(wave_flags + (size_t)w * NPD_MAINT_FLAG_WORDS);
-  const unsigned due_with_orders = wave_flags[(size_t)w * NPD_MAINT_FLAG_WORDS + 4];
-  if (!(fa.x | fa.y | fa.z | fa.w | due_with_orders)) continue;
-  const size_t p = (size_t)w * NPB_WAVE + threadIdx.x;
-  const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
-  if (!due_with_orders) {   /* flagged by a crossed threshold alone: look properly before anything else is fetched */
-    bool work = false;
-#pragma unroll 1
-    for (int k = 0; k < NPB_NUM_PUMPS; k++) {
-      const unsigned fk = k == 0 ? fa.x : (k == 1 ? fa.y : (k == 2 ? fa.z : fa.w));
-      if (fk) work |= npd_maint_second_look(S, f64, N, p, k, t);
-    }
-    if (!__any(work)) { npd_maint_refresh_cache(S, MC, f64, N, p, t); continue; }
-  }
-  npb_maint_t m;
-  NPD_LOAD(MAINT, npb_maint_t, m, 0);
-  int dirty = 0;
-  /* ---- AutoMaintenanceSystem.update: one due order, the earliest created, is carried out */
-  if (npd_maint_check_due(&m, &P, t)) {
-    dirty = 1;
-    if (m.work_orders_created > m.maintenance_actions_performed) {      /* some order is open */
-      double best = 0.0; int pick = -1, pick_action = -1;
-#pragma unroll 1
-      for (int k = 0; k < NPB_NUM_PUMPS; k++) {
-        npb_mpump_t mp;
-        NPD_MP_LOAD(k, wo_order, NPB_MAINT_NACT); NPD_MP_LOAD(k, wo_planned_start, NPB_MAINT_NACT);
-        int a; const double o = npd_maint_first_due(&mp, t, &a);
-        if (o > 0.0 && (best == 0.0 || o < best)) { best = o; pick = k; pick_action = a; }
-      }
-      if (pick >= 0) {
-        npb_mpump_t mp;
-        NPD_MP_LOAD(pick, wo_order, NPB_MAINT_NACT); NPD_MP_LOAD(pick, wo_planned_start, NPB_MAINT_NACT);
-        mp.wo_bearing = (double)*(const npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(pick, wo_bearing, 0));
-        const int bearing = npd_maint_close_order(&mp, &m, pick_action);
-        NPD_MP_STORE(pick, wo_order, NPB_MAINT_NACT); NPD_MP_STORE(pick, wo_planned_start, NPB_MAINT_NACT);
-        *(npd_real_t *)npd_gaddr(f64, N, p, NPD_MP_COL(pick, wo_bearing, 0)) = (npd_real_t)mp.wo_bearing;
-        npb_pump_t pm;
-        NPD_LOAD(PUMP, npb_pump_t, pm, pick);
-        npd_maint_execute(&pm, &P, pick_action, bearing);
-        NPD_STORE(PUMP, npb_pump_t, pm, pick);
-      }
-    }
-  }
-  /* ---- StateManager.collect_states: threshold scan, one orchestrated event per pump (after the work above, as the
-   * reference orders it) */
-#pragma unroll 1
-  for (int k = 0; k < NPB_NUM_PUMPS; k++) {
-    npb_pump_t pm;
-    NPD_LOAD(PUMP, npb_pump_t, pm, k);
-    npb_mpump_t mp;
-    NPD_LOAD(MPUMP, npb_mpump_t, mp, k);
-    if (npd_maint_scan_pump(&mp, &m, &P, &T, &pm, t)) {
-      dirty = 1;
-      NPD_STORE(MPUMP, npb_mpump_t, mp, k);
-    }
-  }
-  if (dirty) NPD_STORE(MAINT, npb_maint_t, m, 0);
-  npd_maint_refresh_cache(S, MC, f64, N, p, t);
-  }
-}
-
 #ifndef NPB_BUILD_F32
 /* calibration aid for the HBM traffic counters: reads every arena column and writes it back unchanged,
  * with exactly the access shape of the step kernel (8 B per lane, one 512-B line per wave and column),
@@ -728,27 +732,28 @@ static void npd_maint_fold_table(const npb_params_t *P, const npb_maint_table_t 
   H->tab[2 * NPB_MAINT_NPARAM] = always ? 1.0 : 0.0;
   H->tab[2 * NPB_MAINT_NPARAM + 1] = P->maint_check_interval_hours * 60;
 }
-/* one allocation behind the flag words: [flags: n_waves x NPD_MAINT_FLAG_WORDS u32][until: 4 x npad f64][mask: 4 x npad u32] */
-static npd_maint_cache_t npd_maint_cache_of(unsigned *maint_flags, size_t npad) {
+/* the handle's maintenance side buffer: [rule constants, 256-byte slot][cache entries: npad x 4 pumps x {u32, float}] */
+#define NPD_MAINT_CONSTS_BYTES ((sizeof(npd_maint_rule_consts_t) + 255) / 256 * 256)
+static npd_maint_cache_t npd_maint_cache_of(void *maint_side, int32_t *counts, int n_plants) {
   npd_maint_cache_t C;
-  C.pitch = npad;
-  C.until = maint_flags ? (double *)(maint_flags + npad / NPB_WAVE * NPD_MAINT_FLAG_WORDS) : nullptr;
-  C.mask = maint_flags ? (uint32_t *)(C.until + (size_t)NPB_NUM_PUMPS * npad) : nullptr;
+  C.counts = counts; C.n_plants = n_plants;
+  C.entry = maint_side ? (npd_u32x4 *)((char *)maint_side + NPD_MAINT_CONSTS_BYTES) : nullptr;
   return C;
 }
-/* maint_table / maint_flags: NULL unless the automatic maintenance is on (npb_step) */
+/* maint_table / maint_side (the handle's maintenance side buffer, rule constants uploaded): NULL unless the automatic maintenance is on (npb_step) */
 extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad, void *arena,
                                 const int32_t *action, const double *magnitude, const double *setpoint,
                                 const double *noise_z, const double *cw_temp, double *obs, double *reward, uint8_t *done,
                                 uint32_t *trip_flags, double *info, int variant, double *diag, size_t diag_pitch,
-                                const npb_maint_table_t *maint_table, unsigned *maint_flags, hipStream_t stream) {
+                                const npb_maint_table_t *maint_table, void *maint_side, int32_t *maint_counts, hipStream_t stream) {
   npd_maint_hot_t MH;
-  npd_maint_fold_table(P, maint_flags ? maint_table : nullptr, &MH);
-  const npd_maint_cache_t MC = npd_maint_cache_of(maint_flags, npad);
+  npd_maint_fold_table(P, maint_side ? maint_table : nullptr, &MH);
+  const npd_maint_cache_t MC = npd_maint_cache_of(maint_side, maint_counts, n_plants);
+  const npd_maint_rule_consts_t *maint_rc = (const npd_maint_rule_consts_t *)maint_side;     /* NULL = off */
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
   if (diag && P->mode == NPB_MODE_FULL) {   /* npb_set_diagnostics: the diagnostics build of the one-wave kernel at any size */
     hipLaunchKernelGGL(npb_step_diag_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
-                       noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_flags, MC, diag, diag_pitch);
+                       noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC, diag, diag_pitch);
     return NPB_KERNEL_STEP_DIAG;
   }
   /* two kernels, one result (the same device functions in the same order per plant; tests/test_gpu_parity.py,
@@ -766,31 +771,36 @@ extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t np
   if (variant == 0) variant = npad <= 57344 ? 2 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1);
   if (variant == 4) {
     hipLaunchKernelGGL(npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
-                       noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_flags, MC);
+                       noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
     return NPB_KERNEL_STEP_NT;
   }
   const bool two_wave = (variant == 2 || variant == 3) && P->mode == NPB_MODE_FULL;
   const bool wide = two_wave && variant == 2 && npad <= 32768;   /* the whole register file while one wave per SIMD is all there is; variant 3 = never */
   if (wide) {
     hipLaunchKernelGGL(npb_step2_wide_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
-                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_flags, MC);
+                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
     return NPB_KERNEL_STEP2_WIDE;
   }
   if (two_wave) {
     hipLaunchKernelGGL(npb_step2_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
-                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_flags, MC);
+                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
     return NPB_KERNEL_STEP2;
   }
   hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
-                     noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_flags, MC);
+                     noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
   return NPB_KERNEL_STEP;
 }
-/* flags_from_step: the step kernel that ran just before wrote this step's flag words (full mode); otherwise every wave is
- * marked "look" here and the rule kernel decides everything itself (the modes that do not step the pumps) */
-extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, const npb_maint_table_t *T, size_t npad, void *arena, unsigned *wave_flags, int flags_from_step,
-                                    hipStream_t stream) {
-  dim3 block(NPB_WAVE);
-  npd_maint_screen_t S = {};
+/* the rule as a launch of its own (modes that do not step the pumps) */
+extern "C" void NPB_LAUNCHER(maint)(size_t npad, void *arena, void *maint_side, int32_t *counts, int n_plants, hipStream_t stream) {
+  hipLaunchKernelGGL(npb_maint_kernel, dim3((unsigned)(npad / NPB_WAVE)), dim3(NPB_WAVE), 0, stream, (const npd_maint_rule_consts_t *)maint_side,
+                     npd_maint_cache_of(maint_side, counts, n_plants), npad, (npd_real_t *)arena);
+}
+/* the rule's constants as the device reads them: host_out = NPB_LAUNCHER(maint_consts_bytes)() bytes */
+extern "C" void NPB_LAUNCHER(maint_consts)(const npb_params_t *P, const npb_maint_table_t *T, void *host_out) {
+  npd_maint_rule_consts_t *RC = (npd_maint_rule_consts_t *)host_out;
+  memset(RC, 0, sizeof(*RC));
+  RC->P = *P; RC->T = *T;
+  npd_maint_screen_t &S = RC->S;
   for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
     S.threshold[q] = T->threshold[q];
     S.cooldown_minutes[q] = T->cooldown_hours[q] * 60;
@@ -803,15 +813,11 @@ extern "C" void NPB_LAUNCHER(maint)(const npb_params_t *P, const npb_maint_table
     if (c == NPB_CMP_EQUALS) S.want_near |= bit;
     if (c != NPB_CMP_GREATER_THAN && c != NPB_CMP_GREATER_EQUAL && c != NPB_CMP_LESS_THAN && c != NPB_CMP_LESS_EQUAL && c != NPB_CMP_EQUALS) S.want_far |= bit;
   }
-  const unsigned n_waves = (unsigned)(npad / NPB_WAVE);
-  if (!flags_from_step) (void)hipMemsetAsync(wave_flags, 0x01, (size_t)n_waves * NPD_MAINT_FLAG_WORDS * sizeof(unsigned), stream);
-  hipLaunchKernelGGL(npb_maint_kernel, dim3(n_waves < 256u ? n_waves : 256u), block, 0, stream, *P, *T, S, npad, (npd_real_t *)arena, (const unsigned *)wave_flags,
-                     npd_maint_cache_of(wave_flags, npad));
 }
-/* flag words + cooldown cache (npd_maint_cache_of); zero = "nothing known: look" */
-extern "C" size_t NPB_LAUNCHER(maint_flag_bytes)(size_t npad) {
-  return npad / NPB_WAVE * NPD_MAINT_FLAG_WORDS * sizeof(unsigned) + (size_t)NPB_NUM_PUMPS * npad * (sizeof(double) + sizeof(uint32_t));
-}
+extern "C" size_t NPB_LAUNCHER(maint_consts_bytes)(void) { return sizeof(npd_maint_rule_consts_t); }
+/* rule constants + cooldown cache (npd_maint_cache_of); a zeroed cache = "nothing known: look" */
+extern "C" size_t NPB_LAUNCHER(maint_side_bytes)(size_t npad) { return NPD_MAINT_CONSTS_BYTES + (size_t)NPB_NUM_PUMPS * npad * (sizeof(float) + sizeof(uint32_t)); }
+extern "C" size_t NPB_LAUNCHER(maint_cache_offset)(void) { return NPD_MAINT_CONSTS_BYTES; }
 extern "C" void NPB_LAUNCHER(observe)(int mode, int n_plants, size_t npad, const void *arena, double *obs, hipStream_t stream) {
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
   hipLaunchKernelGGL(npb_observe_kernel, grid, block, 0, stream, mode, n_plants, npad, (const npd_real_t *)arena, obs);

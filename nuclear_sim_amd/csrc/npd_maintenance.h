@@ -321,15 +321,34 @@ struct npd_maint_hot_t { double tab[NPD_MH_N]; };
 /* flag words per wave of 64 plants: [0..3] pump k has a lane with something new, [4] a lane whose check is due finds open
  * work orders; [5..7] unused */
 #define NPD_MAINT_FLAG_WORDS 8
-/* the side cache: mask[pump][pitch] (uint32: bit q = row q of the table is inside its cooldown), until[pump][pitch] (double:
- * no masked row leaves its cooldown before this time [min]; +inf with an empty mask; 0 = unknown, look) */
-struct npd_maint_cache_t { uint32_t *mask; double *until; size_t pitch; };
-__device__ __forceinline__ uint32_t *npd_maint_cache_mask(const npd_maint_cache_t &C, int k, size_t p) { return C.mask + (size_t)k * C.pitch + p; }
-__device__ __forceinline__ double *npd_maint_cache_until(const npd_maint_cache_t &C, int k, size_t p) { return C.until + (size_t)k * C.pitch + p; }
+/* the side cache: entry[plant][pump] = {uint32 mask: bit q = row q of the table is inside its cooldown; float until: no masked
+ * row leaves its cooldown before this time [min] (rounded DOWN to float; +inf with an empty mask; 0 = unknown, look)}: 32 bytes
+ * per plant, two 16-byte loads.  The step kernels fetch them with asm loads when they start and first look at them two phases
+ * later: left to the compiler the loads sink to their first use, and a lone wave then waits out a full memory latency per
+ * pump (measured: +4 us at 65 536 plants). */
+typedef uint32_t npd_u32x4 __attribute__((ext_vector_type(4)));
+struct npd_maint_cache_t { npd_u32x4 *entry;      /* [pitch][2]: pumps 0,1 | pumps 2,3 */
+                           int32_t *counts;       /* the caller's maintenance_actions_performed column (npb_set_maintenance_count_buffer), or NULL */
+                           int n_plants; };
+__device__ __forceinline__ npd_u32x4 npd_maint_cache_fetch(const npd_maint_cache_t &C, size_t p, int half) {
+  npd_u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(C.entry + p * 2 + half) : "memory");
+  return v;
+}
+/* after the wait that covers the fetch (an explicit s_waitcnt vmcnt(0), or the staging pipeline's own): ties the register to
+ * this point of the instruction stream */
+__device__ __forceinline__ void npd_maint_cache_landed(npd_u32x4 &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ float npd_float_below(double x) {     /* the largest float <= x */
+  float f = (float)x;
+  if ((double)f > x) f = __uint_as_float(f > 0.0f ? __float_as_uint(f) - 1u : (f < 0.0f ? __float_as_uint(f) + 1u : 0x80000001u));
+  return f;
+}
 /* tl: the table in LDS (every lane reads the same word: a broadcast).  (npd_real_t): the value as the arena will hold it
  * (rounded to float under fp32 storage), which is what the rule kernel will see.  t: the plant's clock after this step */
-template <typename TL>
-__device__ __forceinline__ bool npd_maint_pump_hit(const npb_pump_t *pm, TL tl, uint32_t cooling_mask, double cooling_until, double t) {
+__device__ __forceinline__ bool npd_maint_pump_hit(const npb_pump_t *pm, const double *table_lds, uint32_t cooling_mask, float cooling_until, double t) {
+  /* read where it is used, every time (volatile): hoisted out of the rolled pump loop the 34 entries would sit in 68 registers
+   * across the whole pump phase, which spills */
+  const volatile __attribute__((address_space(3))) double *tl = (const volatile __attribute__((address_space(3))) double *)table_lds;
   double v[NPB_MAINT_NPARAM];
   npd_maint_values(pm, v);
   double m = -1.0;
@@ -340,11 +359,11 @@ __device__ __forceinline__ bool npd_maint_pump_hit(const npb_pump_t *pm, TL tl, 
     const uint32_t hi = (uint32_t)__double2hiint(d) | ((cooling_mask << (31 - q)) & 0x80000000u);
     m = __builtin_fmax(m, __hiloint2double((int)hi, __double2loint(d)));
   }
-  return (m > 0.0) | (tl[2 * NPB_MAINT_NPARAM] != 0.0) | !(t < cooling_until);
+  return (m > 0.0) | (tl[2 * NPB_MAINT_NPARAM] != 0.0) | !(t < (double)cooling_until);
 }
 /* the cache entry of one (plant, pump) from its stamps, as of time t (the rule kernel, after it has looked at a wave) */
 __device__ __forceinline__ void npd_maint_cache_entry(const double *last_violation_time, const double *cooldown_minutes, uint32_t scan_mask, double t,
-                                                      uint32_t *mask_out, double *until_out) {
+                                                      uint32_t *mask_out, float *until_out) {
   uint32_t mask = 0; double until = __builtin_inf();
 #pragma unroll
   for (int q = 0; q < NPB_MAINT_NPARAM; q++) {
@@ -356,21 +375,27 @@ __device__ __forceinline__ void npd_maint_cache_entry(const double *last_violati
       until = fmin(until, ends - (fabs(ends) * 1e-9 + 1e-9));     /* a hair early: rounding of (t - lv) must never hide an expiry */
     }
   }
-  *mask_out = mask; *until_out = until;
+  *mask_out = mask; *until_out = npd_float_below(until);
 }
 /* AutoMaintenanceSystem.update as far as it needs no order (auto_maintenance.py:200-236): a check that falls due with nothing
- * open only moves last_check_time; one that finds open orders is left, untouched, to the rule kernel.  Returns "work". */
-__device__ __forceinline__ bool npd_maint_due_check(npd_real_t *f64, size_t N, size_t p, double t, double check_interval_minutes) {
-  npd_real_t *lct_p = (npd_real_t *)((char *)(f64 + (size_t)(NPD_SEC_COL(MAINT, 0) + NPB_F64_SLOT(npb_maint_t, last_check_time)) * N + p));
+ * open only moves last_check_time; one that finds open orders is left, untouched, to the rule kernel.  In two parts, so that a
+ * step kernel can issue the three loads when it starts and decide once the plant's clock is known: a lone wave that uses a
+ * load at once waits out the whole memory latency. */
+struct npd_maint_due_t { npd_real_t *last_check_time_p; double last_check_time; int created, performed; };
+__device__ __forceinline__ void npd_maint_due_load(npd_maint_due_t *d, npd_real_t *f64, size_t N, size_t p) {
+  d->last_check_time_p = (npd_real_t *)((char *)(f64 + (size_t)(NPD_SEC_COL(MAINT, 0) + NPB_F64_SLOT(npb_maint_t, last_check_time)) * N + p));
   const char *cnt = (const char *)(f64 + (size_t)(NPD_SEC_COL(MAINT, 0) + NPB_MAINT_NCARRY) * N + p);
-  const double last_check_time = (double)*lct_p;
-  const int created = *(const int32_t *)(cnt + ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, work_orders_created)) / NPD_NPC) * N * sizeof(npd_real_t) +
-                                         ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, work_orders_created)) % NPD_NPC) * 4);
-  const int performed = *(const int32_t *)(cnt + ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, maintenance_actions_performed)) / NPD_NPC) * N * sizeof(npd_real_t) +
-                                           ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, maintenance_actions_performed)) % NPD_NPC) * 4);
-  const bool due = !(last_check_time > 0.0 && t - last_check_time < check_interval_minutes);    /* npd_maint_check_due */
-  const bool work = due & (created > performed);
-  if (due & !work) *lct_p = (npd_real_t)t;
+  d->last_check_time = (double)*d->last_check_time_p;
+  d->created = *(const int32_t *)(cnt + ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, work_orders_created)) / NPD_NPC) * N * sizeof(npd_real_t) +
+                                  ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, work_orders_created)) % NPD_NPC) * 4);
+  d->performed = *(const int32_t *)(cnt + ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, maintenance_actions_performed)) / NPD_NPC) * N * sizeof(npd_real_t) +
+                                    ((NPB_MAINT_NOUT + NPB_I32_SLOT(npb_maint_t, MAINT, maintenance_actions_performed)) % NPD_NPC) * 4);
+}
+/* returns "work": the check is due and finds open orders */
+__device__ __forceinline__ bool npd_maint_due_decide(const npd_maint_due_t *d, double t, double check_interval_minutes) {
+  const bool due = !(d->last_check_time > 0.0 && t - d->last_check_time < check_interval_minutes);    /* npd_maint_check_due */
+  const bool work = due & (d->created > d->performed);
+  if (due & !work) *d->last_check_time_p = (npd_real_t)t;
   return work;
 }
 

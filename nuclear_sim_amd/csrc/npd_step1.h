@@ -6,7 +6,7 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
     const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,
     double *__restrict__ reward_out, uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out,
-    double *__restrict__ info_out, npd_maint_hot_t MH, unsigned *__restrict__ maint_flags, npd_maint_cache_t MC
+    double *__restrict__ info_out, npd_maint_hot_t MH, const npd_maint_rule_consts_t *maint_rc, npd_maint_cache_t MC
 #ifdef NPD_STEP1_DIAG
     , double *diag, size_t diag_pitch
 #endif
@@ -35,11 +35,18 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
   /* automatic maintenance on (npd_maintenance.h, "the threshold screen inside the step kernels"): lane l fetches entry l of the
    * folded threshold table from the kernel-argument segment; it goes to the last 512 B of the staging region -- no staged
    * section reaches that far -- once the first staged group has landed, and the pump phase reads it from there */
-  const bool maint = P.maint_enabled && maint_flags != nullptr && full;
+  const bool maint = P.maint_enabled && maint_rc != nullptr && full;
+  unsigned maint_hit_bits = 0, maint_due_with_orders = 0;     /* wave-uniform: what the screen found (npd_maintenance.h) */
   double *const maint_tab = lds + (NPB_STAGE_BYTES - 512) / 8;
   static_assert(NPD_MH_N <= 64 && (size_t)NPD_SLOTS(TSTG) * NPD_SLOTB <= NPB_STAGE_BYTES - 512, "room for the threshold table behind the largest staged group");
   double maint_entry = 0.0, maint_time = 0.0;
   if (maint && threadIdx.x < NPD_MH_N) maint_entry = MH.tab[threadIdx.x];
+  npd_maint_due_t maint_due = {};
+  npd_u32x4 maint_cache01 = {0, 0, 0, 0}, maint_cache23 = {0, 0, 0, 0};      /* {mask, until} of pumps 0,1 | 2,3 (npd_maintenance.h) */
+  if (maint) {
+    npd_maint_due_load(&maint_due, f64, N, p);
+    maint_cache01 = npd_maint_cache_fetch(MC, p, 0); maint_cache23 = npd_maint_cache_fetch(MC, p, 1);
+  }
   /* under ConstantHeatSource the point-kinetics columns of the primary section stay where they are: neither staged
    * nor stored (their register copies are then never used either) */
   const bool kinetics = P.heat_source == NPB_HEAT_REACTOR;
@@ -84,6 +91,7 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     prev_quals[i] = NPD_STAGED_F64(SEC, npb_sec_t, prev_sg_qualities, i, NPD_LS_SEC);
   }
   if (maint && threadIdx.x < NPD_MH_N) maint_tab[threadIdx.x] = maint_entry;
+  if (maint) { npd_maint_cache_landed(maint_cache01); npd_maint_cache_landed(maint_cache23); }    /* behind the NPD_DMA_WAIT above */
   NPD_LDS_DRAIN();
   if (full) { NPD_DMA(FW, 0, NPD_LS_FW); NPD_DMA(PUMP, 0, NPD_LS_PUMP0); }
   else NPD_DMA(SG, 0, 0);
@@ -99,9 +107,8 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     load_demand = s.power_level; /* sim.py:161: the caller's load_demand is overwritten */
     if (maint) {   /* sim.py:208-216 as far as no work order is involved; t = the clock after this step */
       maint_time = s.sim_time;
-      const bool work = npd_maint_due_check(f64, N, p, s.sim_time, maint_tab[2 * NPB_MAINT_NPARAM + 1]);
-      const bool any = __builtin_amdgcn_ballot_w64(work) != 0;
-      if (threadIdx.x == 0) maint_flags[(size_t)blockIdx.x * NPD_MAINT_FLAG_WORDS + 4] = any ? 1u : 0u;
+      const bool work = npd_maint_due_decide(&maint_due, s.sim_time, maint_tab[2 * NPB_MAINT_NPARAM + 1]);
+      maint_due_with_orders = __builtin_amdgcn_ballot_w64(work) != 0 ? 1u : 0u;
     }
     scram_status = s.scram_status;
     npd_obs_primary(s, obs); /* obs[7] is patched after the secondary side has produced the steam flow */
@@ -170,12 +177,12 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
 #pragma unroll 1
     for (int i = 0; i < NPB_NUM_PUMPS; i++) {
       NPD_STAMP(2 + i);
-      uint32_t cooling_mask = 0; double cooling_until = 0.0;     /* this (plant, pump)'s entry of the cooldown cache: lands behind the pump's arithmetic */
-      if (maint) { cooling_mask = *npd_maint_cache_mask(MC, i, p); cooling_until = *npd_maint_cache_until(MC, i, p); }
+      /* this (plant, pump)'s entry of the cooldown cache (rolled loop: picked by selects, as the per-SG values are) */
+      const uint32_t cooling_mask = i == 0 ? maint_cache01.x : (i == 1 ? maint_cache01.z : (i == 2 ? maint_cache23.x : maint_cache23.z));
+      const float cooling_until = __uint_as_float(i == 0 ? maint_cache01.y : (i == 1 ? maint_cache01.w : (i == 2 ? maint_cache23.y : maint_cache23.w)));
       npd_fw_pump_step(&pm, &fw, &acc, i, n_prev_running, flow_per_pump, &sc, dt);
       if (maint) {   /* anything new at this pump -- a threshold crossed outside its cooldown, a cooldown run out -- for any plant of the wave?  (npd_maintenance.h) */
-        const bool any = __builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, maint_time)) != 0;
-        if (threadIdx.x == 0) maint_flags[(size_t)blockIdx.x * NPD_MAINT_FLAG_WORDS + i] = any ? 1u : 0u;
+        if (__builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, maint_time)) != 0) maint_hit_bits |= 1u << i;
       }
       /* boundary: pump i -> HBM, pump i+1 (staged during this pump's arithmetic) -> the same registers,
        * then stage pump i+2, or SG 0 once the last pump is on its way */
@@ -423,4 +430,9 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
   }
   NPD_STAMP(22);
   NPD_WAIT_ACC_STORE();
+  /* ================= automatic maintenance (sim.py:208-223), for a wave whose screen found something: rarely ================= */
+  if (maint && (maint_hit_bits | maint_due_with_orders)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* this wave's own state stores are in memory before the rule reads them back */
+    npd_maint_rule_for_wave<NPD_STEP1_WHO>(maint_rc, MC, f64, N, p, maint_hit_bits, maint_due_with_orders);
+  }
 }

@@ -294,12 +294,13 @@ __device__ __forceinline__ void npd2_stage_post(const npd_stage_t &st, const npd
 }
 
 /* the body of both two-wave kernels (below): same code, compiled once per register budget */
+template <int WHO>
 __device__ __forceinline__ void npd_step2_body(
     const npb_params_t &P, int n_plants, size_t N, npd_real_t *__restrict__ f64,
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
     const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,
     double *__restrict__ reward_out, uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out,
-    double *__restrict__ info_out, const npd_maint_hot_t &MH, unsigned *__restrict__ maint_flags, const npd_maint_cache_t &MC) {
+    double *__restrict__ info_out, const npd_maint_hot_t &MH, const npd_maint_rule_consts_t *maint_rc, const npd_maint_cache_t &MC) {
   __shared__ __attribute__((aligned(16))) double xch[NPD2_SLOTS * NPB_WAVE];
   const int lane = threadIdx.x & (NPB_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform role: 0 = A, 1 = B */
@@ -320,12 +321,17 @@ __device__ __forceinline__ void npd_step2_body(
   /* automatic maintenance on: the folded threshold table (npd_maintenance.h, "the threshold screen inside the step kernels")
    * goes to exchange slot X_MAINT_TAB, which nothing else uses, written by wave A before barrier #1 and read by both waves'
    * pump phases behind it */
-  const bool maint = P.maint_enabled && maint_flags != nullptr;
+  const bool maint = P.maint_enabled && maint_rc != nullptr;
+  unsigned maint_hit_bits = 0, maint_due_with_orders = 0;     /* wave-uniform: what this wave's part of the screen found */
   double *const maint_tab = xch + X_MAINT_TAB * NPB_WAVE;
   NPD2_STAMP(0);
   if (wave == 0) {
     /* =========================================== wave A =========================================== */
-    if (maint && lane < NPD_MH_N) maint_tab[lane] = MH.tab[lane];
+    double maint_entry = 0.0;
+    if (maint && lane < NPD_MH_N) maint_entry = MH.tab[lane];
+    npd_maint_due_t maint_due = {};
+    npd_u32x4 maint_cache01 = {0, 0, 0, 0};       /* {mask, until} of this wave's pumps 0, 1 (npd_maintenance.h) */
+    if (maint) { npd_maint_due_load(&maint_due, f64, N, p); maint_cache01 = npd_maint_cache_fetch(MC, p, 0); }
     npd_inputs_t in;
     in.action = (live && action) ? action[p] : 8;
     in.magnitude = (live && magnitude) ? magnitude[p] : 1.0;
@@ -380,9 +386,8 @@ __device__ __forceinline__ void npd_step2_body(
       NPD_ST_STORE_ELIDE_PRIM(s, s_old);
       if (maint) {   /* sim.py:208-216 as far as no work order is involved; t = the clock after this step */
         XW(X_MAINT_TIME, s.sim_time);
-        const bool work = npd_maint_due_check(f64, N, p, s.sim_time, MH.tab[2 * NPB_MAINT_NPARAM + 1]);
-        const bool any = __builtin_amdgcn_ballot_w64(work) != 0;
-        if (lane == 0) maint_flags[(size_t)blockIdx.x * NPD_MAINT_FLAG_WORDS + 4] = any ? 1u : 0u;
+        const bool work = npd_maint_due_decide(&maint_due, s.sim_time, MH.tab[2 * NPB_MAINT_NPARAM + 1]);
+        maint_due_with_orders = __builtin_amdgcn_ballot_w64(work) != 0 ? 1u : 0u;
       }
     }
     /* ---- secondary prelude (secondary/__init__.py:371-453) */
@@ -430,7 +435,9 @@ __device__ __forceinline__ void npd_step2_body(
       may_run += (stt == NPD_PUMP_RUNNING || stt == NPD_PUMP_STARTING);
     }
     const bool serial_pumps = __builtin_amdgcn_ballot_w64(n_prev_running > 0 && may_run > n_prev_running) != 0;
+    if (maint && lane < NPD_MH_N) maint_tab[lane] = maint_entry;
     NPD2_SYNCJ(1);                                                                                     /* #1 */
+    if (maint) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); npd_maint_cache_landed(maint_cache01); }
     /* ---- pumps 0 and 1 */
     int running_count = 0;
 #pragma unroll 1
@@ -438,14 +445,13 @@ __device__ __forceinline__ void npd_step2_body(
       npb_pump_t pm;
       NPD_ST_LOAD(PUMP, npb_pump_t, pm, i);
       const npb_pump_t pm_old = pm;
-      uint32_t cooling_mask = 0; double cooling_until = 0.0;     /* this (plant, pump)'s entry of the cooldown cache */
-      if (maint) { cooling_mask = *npd_maint_cache_mask(MC, i, p); cooling_until = *npd_maint_cache_until(MC, i, p); }
+      const uint32_t cooling_mask = i == 0 ? maint_cache01.x : maint_cache01.z;     /* this (plant, pump)'s entry of the cooldown cache */
+      const float cooling_until = __uint_as_float(i == 0 ? maint_cache01.y : maint_cache01.w);
       npd2_pump(&pm, running_count < n_prev_running, n_prev_running, flow_per_pump, &sc, dt);
       running_count += pm.status == NPD_PUMP_RUNNING;
       npd2_publish_pump(xch, lane, i, pm);
       if (maint) {   /* anything new at this pump, for any plant of the group?  (npd_maintenance.h) */
-        const bool any = __builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, time_info)) != 0;
-        if (lane == 0) maint_flags[(size_t)blockIdx.x * NPD_MAINT_FLAG_WORDS + i] = any ? 1u : 0u;
+        if (__builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, time_info)) != 0) maint_hit_bits |= 1u << i;
       }
       NPD_ST_STORE_ELIDE(PUMP, npb_pump_t, pm, pm_old, i);
     }
@@ -662,6 +668,8 @@ __device__ __forceinline__ void npd_step2_body(
     if (obs_out) npd2_store_rows<NPB_OBS_DIM>(obs, obs_out, xch + X_OBS * NPB_WAVE, lane, block_base, (size_t)n_plants);
   } else {
     /* =========================================== wave B =========================================== */
+    npd_u32x4 maint_cache23 = {0, 0, 0, 0};       /* {mask, until} of this wave's pumps 2, 3 (npd_maintenance.h) */
+    if (maint) maint_cache23 = npd_maint_cache_fetch(MC, p, 1);
     const double tdt = dt / 60.0;
     if (lane == 0) { *(volatile int *)&xch[X_FLAG * NPB_WAVE] = 0; *(volatile int *)&xch[X_FLAG2 * NPB_WAVE] = 0; }
     /* ---- turbine lubrication pre-step: reads the previous step's rotor / bearing members, owns the lub_* ones */
@@ -711,21 +719,21 @@ __device__ __forceinline__ void npd_step2_body(
     sc.feedwater_temperature = 40.0; sc.suction_pressure = 0.5; sc.discharge_pressure = 7.4; sc.max_sg_level = XR(X_MAXLVL);
     int running_count = 0;
     const double maint_time_b = maint ? XR(X_MAINT_TIME) : 0.0;
+    if (maint) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); npd_maint_cache_landed(maint_cache23); }
     if (serial_pumps) { NPD2_SYNC_(); running_count = (int)XR(X_RUNCOUNT); }                         /* #1b */
 #pragma unroll 1
     for (int i = 2; i < NPB_NUM_PUMPS; i++) {
       npb_pump_t pm;
       NPD_ST_LOAD(PUMP, npb_pump_t, pm, i);
       const npb_pump_t pm_old = pm;
-      uint32_t cooling_mask = 0; double cooling_until = 0.0;
-      if (maint) { cooling_mask = *npd_maint_cache_mask(MC, i, p); cooling_until = *npd_maint_cache_until(MC, i, p); }
+      const uint32_t cooling_mask = i == 2 ? maint_cache23.x : maint_cache23.z;
+      const float cooling_until = __uint_as_float(i == 2 ? maint_cache23.y : maint_cache23.w);
       /* parallel mode: the gate cannot close (serial_pumps is false for every lane), so its outcome needs no count */
       npd2_pump(&pm, serial_pumps ? (running_count < n_prev_running) : 1, n_prev_running, flow_per_pump, &sc, dt);
       running_count += pm.status == NPD_PUMP_RUNNING;
       npd2_publish_pump(xch, lane, i, pm);
       if (maint) {
-        const bool any = __builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, maint_time_b)) != 0;
-        if (lane == 0) maint_flags[(size_t)blockIdx.x * NPD_MAINT_FLAG_WORDS + i] = any ? 1u : 0u;
+        if (__builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, maint_time_b)) != 0) maint_hit_bits |= 1u << i;
       }
       NPD_ST_STORE_ELIDE(PUMP, npb_pump_t, pm, pm_old, i);
     }
@@ -879,6 +887,18 @@ __device__ __forceinline__ void npd_step2_body(
     }
   }
   NPD2_STAMP(31);
+  /* ================= automatic maintenance (sim.py:208-223), for a group whose screen found something: rarely.  Wave B hands
+   * its two pumps' verdict over (a word of the table's slot, past the table), both waves' state stores are in memory behind
+   * the barrier, and wave A runs the rule for the 64 plants. */
+  if (maint) {
+    volatile unsigned *handover = (volatile unsigned *)(maint_tab + 48);
+    if (wave == 1 && lane == 0) *handover = maint_hit_bits;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wave == 0) {
+      const unsigned bits = maint_hit_bits | (unsigned)__builtin_amdgcn_readfirstlane((int)*handover);
+      if (bits | maint_due_with_orders) npd_maint_rule_for_wave<WHO>(maint_rc, MC, f64, N, p, bits, maint_due_with_orders);
+    }
+  }
 #undef NPD_EXT_IDX
 #undef NPD_IS_EXT
 }
@@ -887,12 +907,12 @@ __device__ __forceinline__ void npd_step2_body(
     npb_params_t P, int n_plants, size_t N, npd_real_t *__restrict__ f64, const int32_t *__restrict__ action, \
     const double *__restrict__ magnitude, const double *__restrict__ setpoint, const double *__restrict__ noise_z, \
     const double *__restrict__ cw_temp, double *__restrict__ obs_out, double *__restrict__ reward_out, uint8_t *__restrict__ done_out, \
-    uint32_t *__restrict__ trip_out, double *__restrict__ info_out, npd_maint_hot_t MH, unsigned *__restrict__ maint_flags, npd_maint_cache_t MC
-#define NPD2_KERNEL_PASS P, n_plants, N, f64, action, magnitude, setpoint, noise_z, cw_temp, obs_out, reward_out, done_out, trip_out, info_out, MH, maint_flags, MC
+    uint32_t *__restrict__ trip_out, double *__restrict__ info_out, npd_maint_hot_t MH, const npd_maint_rule_consts_t *maint_rc, npd_maint_cache_t MC
+#define NPD2_KERNEL_PASS P, n_plants, N, f64, action, magnitude, setpoint, noise_z, cw_temp, obs_out, reward_out, done_out, trip_out, info_out, MH, maint_rc, MC
 /* two waves per SIMD (256 registers each, part of the state spilled): for batches between one and two waves per SIMD */
-__global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(NPD2_KERNEL_ARGS) { npd_step2_body(NPD2_KERNEL_PASS); }
+__global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(NPD2_KERNEL_ARGS) { npd_step2_body<4>(NPD2_KERNEL_PASS); }
 /* one wave per SIMD and the whole register file: up to 32 768 plants (1 024 waves) nothing is gained by leaving room for a
  * second wave, and the spill code goes away */
-__global__ __launch_bounds__(NPD2_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void npb_step2_wide_kernel(NPD2_KERNEL_ARGS) { npd_step2_body(NPD2_KERNEL_PASS); }
+__global__ __launch_bounds__(NPD2_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void npb_step2_wide_kernel(NPD2_KERNEL_ARGS) { npd_step2_body<5>(NPD2_KERNEL_PASS); }
 
 #endif

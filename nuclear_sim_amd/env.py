@@ -168,6 +168,11 @@ class BatchedPlantEnv:
             self._info_buf = torch.zeros(self.n * (len(INFO_COLUMNS) + (_lib.INFO_NRHO if self._with_rho else 0)), dtype=torch.float64, device=self.device)
             self._info = self._info_buf[: self.n * len(INFO_COLUMNS)].view(self.n, len(INFO_COLUMNS))
             self._rho = self._info_buf[self.n * len(INFO_COLUMNS):].view(self.n, -1) if self._with_rho else None
+        self._event_counts = None
+        if p.maint_enabled and hasattr(self.L, "npb_set_maintenance_count_buffer"):
+            with torch.cuda.device(self.device):
+                self._event_counts = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+            _lib.check(self.L.npb_set_maintenance_count_buffer(self._h, ctypes.c_void_p(self._event_counts.data_ptr())), self._h)
         self._noise = None
         self._noise_seeds = None if noise_seeds is None else np.asarray(noise_seeds, dtype=np.int64).copy()
         if noise_enabled and noise_seeds is not None:
@@ -364,7 +369,8 @@ class BatchedPlantEnv:
         info["trip_flags"] = self._flags
         info["scram_activated"] = self._done
         if self.params.maint_enabled:  # bit-exact counterpart of AutoMaintenanceSystem.maintenance_actions_performed
-            info["maintenance_event_count"] = self.get_field("maint.maintenance_actions_performed")
+            # a column the step keeps current (npb_set_maintenance_count_buffer): no gather launch per step
+            info["maintenance_event_count"] = self._event_counts if self._event_counts is not None else self.get_field("maint.maintenance_actions_performed")
         return self._obs, self._reward, self._done, info
 
 

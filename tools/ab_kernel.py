@@ -16,7 +16,7 @@ def child():
     from nuclear_sim_amd.env import BatchedPlantEnv
     n, K = int(os.environ.get("NPB_AB_N", "65536")), 300
     env = BatchedPlantEnv(n, dt=1.0, heat_source="constant", noise_enabled=True, noise_std_percent=0.1,
-                          storage=os.environ.get("NPB_AB_STORAGE", "f64"))
+                          storage=os.environ.get("NPB_AB_STORAGE", "f64"), maintenance=bool(int(os.environ.get("NPB_AB_MAINT", "0"))))
     dev = env.device
     gen = torch.Generator(device=dev); gen.manual_seed(1234)
     z = torch.randn((K + 20, n), device=dev, dtype=torch.float64, generator=gen)
