@@ -62,7 +62,7 @@ typedef struct npb_params_t {
 #undef NPB__P
   /* run-mode switches (not reference attributes) */
   double dt;               /* NuclearPlantSimulator(dt=...)  sim.py:33 */
-  int heat_source;         /* NPB_HEAT_CONSTANT | NPB_HEAT_REACTOR */
+  int heat_source;         /* NPB_HEAT_CONSTANT | NPB_HEAT_REACTOR | NPB_HEAT_EXTERNAL */
   int hs_noise_enabled;    /* ConstantHeatSource(noise_enabled=...) */
   int mode;                /* NPB_MODE_FULL | NPB_MODE_PRIMARY_SG | NPB_MODE_PRIMARY */
   int maint_enabled;       /* 1: run the automatic maintenance of the feedwater pumps after every step (maint.*, mpump.* columns) */
@@ -73,7 +73,12 @@ typedef struct npb_params_t {
                                    * reference has no such integrator, so this mode is self-consistency-tested only */
 } npb_params_t;
 
-enum { NPB_HEAT_CONSTANT = 0, NPB_HEAT_REACTOR = 1 };
+/* NPB_HEAT_EXTERNAL: a heat source the caller computes (the reference's HeatSource plugin interface,
+ * heat_sources/heat_source_interface.py:23-112, consumed at primary/__init__.py:203-225): the step takes the plugin's result as
+ * two per-step input columns -- under this mode npb_step's `noise_z` column IS heat_result['thermal_power_mw'] and its
+ * `power_setpoint` column IS heat_result['power_percent'] (NULL / NaN: thermal power / rated power x 100) -- sets
+ * total_reactivity_pcm = 0 (a result without 'reactivity_pcm', :218-222) and leaves neutron_flux alone (:214-215). */
+enum { NPB_HEAT_CONSTANT = 0, NPB_HEAT_REACTOR = 1, NPB_HEAT_EXTERNAL = 2 };
 /* NPB_MODE_PRIMARY: NuclearPlantSimulator(enable_secondary=False), sim.py:155,309,333 -- primary side only, 12 observations */
 enum { NPB_MODE_FULL = 0, NPB_MODE_PRIMARY_SG = 1, NPB_MODE_PRIMARY = 2 };
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NPB_LIB", os.path.join(_HERE, "libnpb.so"))
 
 NPB_KIND_F64, NPB_KIND_I32 = 0, 1
-HEAT_CONSTANT, HEAT_REACTOR = 0, 1
+HEAT_CONSTANT, HEAT_REACTOR, HEAT_EXTERNAL = 0, 1, 2
 STORAGE_F64, STORAGE_F32 = 0, 1
 MODE_FULL, MODE_PRIMARY_SG, MODE_PRIMARY = 0, 1, 2
 OBS_DIM, INFO_DIM = 22, 17   # include/npb.h NPB_OBS_DIM / NPB_INFO_DIM; checked against the library in load()

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_primary_kernel(
   in.cooling_water_temp = NAN;
   npb_prim_t s;
   NPD_LOAD(PRIM, npb_prim_t, s, 0);
-  if (!isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
+  if (P.heat_source != NPB_HEAT_EXTERNAL && !isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
   int nan_reset;
   double rho[NPB_INFO_NRHO];
   const int scram_fired = npd_primary_update(&s, &P, &in, &nan_reset, rho);

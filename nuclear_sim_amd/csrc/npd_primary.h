@@ -244,6 +244,11 @@ NPD_FN int npd_primary_update(npb_prim_t *s, const npb_params_t *P, const npd_in
     npd_reactor_heat_source(s, P, dt, &thermal_power_mw, &power_percent, &total_pcm, components);
     s->total_reactivity_pcm = total_pcm;
     s->reactivity = total_pcm / 100000.0; /* __init__.py:220 overwrites heat source's value */
+  } else if (P->heat_source == NPB_HEAT_EXTERNAL) {
+    /* a HeatSource plugin's result (heat_source_interface.py:23-112): the two columns the caller computed for this step */
+    thermal_power_mw = in->noise_z;
+    power_percent = isnan(in->power_setpoint) ? thermal_power_mw / P->rated_power_mw * 100.0 : in->power_setpoint;
+    s->total_reactivity_pcm = 0.0;
   } else {
     npd_constant_heat_source(s, P, dt, in->noise_z, &thermal_power_mw, &power_percent);
     s->total_reactivity_pcm = 0.0;

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
 
   /* ================= phase 0: primary side + coupling (sim.py:141-161) ================= */
   {
-    if (!isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
+    if (P.heat_source != NPB_HEAT_EXTERNAL && !isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
     double rho[NPB_INFO_NRHO];
     scram_fired = npd_primary_update(&s, &P, &in, &nan_reset, rho);
     npd_store_reactivity_components(P, rho, info_out, n_plants, p);

@@ -359,7 +359,7 @@ __device__ __forceinline__ void npd_step2_body(
         for (int k = 0; k < NPB_PRIM_NI32; k++) q[k] = *NPD_NP(const int32_t, NPD_SEC_COL(PRIM, 0) + NPB_PRIM_NCARRY + (NPB_PRIM_NOUT + k) / NPD_NPC, (NPB_PRIM_NOUT + k) % NPD_NPC);
       }
       const npb_prim_t s_old = s;
-      if (!isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
+      if (P.heat_source != NPB_HEAT_EXTERNAL && !isnan(in.power_setpoint)) s.hs_setpoint_percent = npd_clip(in.power_setpoint, 0.0, 150.0);
       double rho[NPB_INFO_NRHO];
       scram_fired = npd_primary_update(&s, &P, &in, &nan_reset, rho);
       npd_store_reactivity_components(P, rho, info_out, n_plants, p);

@@ -129,7 +129,10 @@ class BatchedPlantEnv:
         self.device = torch.device("cuda", device)
         p = _lib.default_params()
         p.dt = float(dt)
-        p.heat_source = {"constant": _lib.HEAT_CONSTANT, "reactor": _lib.HEAT_REACTOR}[heat_source]
+        # "external": a heat source the caller computes (the reference's HeatSource plugin interface, heat_source_interface.py:23-112):
+        # step(thermal_power_mw=..., power_percent=...) takes the plugin's result as two input columns (include/npb_params.h)
+        p.heat_source = {"constant": _lib.HEAT_CONSTANT, "reactor": _lib.HEAT_REACTOR, "external": _lib.HEAT_EXTERNAL}[heat_source]
+        self.heat_source = heat_source
         p.hs_noise_enabled = int(bool(noise_enabled))
         p.hs_noise_std_percent = float(noise_std_percent)
         # "primary": NuclearPlantSimulator(enable_secondary=False) -- the primary side alone, obs[:, :12] (sim.py:155,333)
@@ -347,8 +350,19 @@ class BatchedPlantEnv:
         info = {name: self._info[:, j] for j, name in enumerate(INFO_COLUMNS)}
         return secondary_result(info, members)
 
-    def step(self, action=None, magnitude=None, power_setpoint=None, cooling_water_temp=None, noise_z=None):
+    def step(self, action=None, magnitude=None, power_setpoint=None, cooling_water_temp=None, noise_z=None,
+             thermal_power_mw=None, power_percent=None):
         self._keep = []
+        if self.heat_source == "external":
+            # the plugin's heat_result['thermal_power_mw'] / ['power_percent'] for this step travel in the noise_z / power_setpoint
+            # columns of the C ABI (include/npb_params.h, NPB_HEAT_EXTERNAL); power_percent None = thermal power / rated x 100
+            if thermal_power_mw is None:
+                if noise_z is None:
+                    raise ValueError("heat_source='external': step() needs the heat source's thermal_power_mw for this step")
+                thermal_power_mw, power_percent = noise_z, power_setpoint       # (a caller that speaks the C ABI's column names)
+            noise_z, power_setpoint = thermal_power_mw, power_percent
+        elif thermal_power_mw is not None or power_percent is not None:
+            raise ValueError("thermal_power_mw / power_percent are the inputs of heat_source='external'")
         a = self._col(None if action is None else action, torch.int32)
         m = self._col(magnitude, torch.float64)
         sp = self._col(power_setpoint, torch.float64)
@@ -460,6 +474,10 @@ SECONDARY_RESULT_MEMBERS = ("sec.electrical_power_output", "sec.thermal_efficien
                             "cond.cooling_water_outlet_temp", "cond.active_tube_count", "cond.total_fouling_resistance")
 
 
+FACTORY_DEFAULT_PUMP_THRESHOLDS = {"oil_level": {"threshold": 30.0, "comparison": "less_than", "action": "oil_top_off",
+                                                 "cooldown_hours": 24.0, "priority": "HIGH"}}
+
+
 class ConstantHeatSource:
     """systems/primary/reactor/heat_sources/constant_heat_source.py:29-102 (constructor and setpoint surface)."""
 
@@ -476,6 +494,28 @@ class ConstantHeatSource:
     def set_power_setpoint(self, power_percent: float) -> None:
         self.power_setpoint_percent = float(np.clip(power_percent, 0.0, 150.0))
         self._pending = float(power_percent)
+
+
+class HeatSource:
+    """The reference's plugin interface for heat sources (heat_sources/heat_source_interface.py:23-112): subclass it and hand the
+    object to NuclearPlantSimulator -- every step calls ``update(dt=..., reactor_state=..., control_action=...)`` on the host and
+    feeds the returned ``thermal_power_mw`` / ``power_percent`` to the step as input columns (keys beyond those two --
+    ``neutron_flux``, ``reactivity_pcm``, ``reactivity_components`` -- are not supported and raise).  Batches: compute the two
+    columns yourself and call ``BatchedPlantEnv(heat_source="external").step(thermal_power_mw=..., power_percent=...)``."""
+
+    def __init__(self, rated_power_mw: float = 3000.0):
+        self.rated_power_mw = rated_power_mw
+        self.current_power_mw = 0.0
+        self.power_setpoint_percent = 100.0
+
+    def update(self, dt: float, **kwargs) -> dict:
+        raise NotImplementedError
+
+    def set_power_setpoint(self, power_percent: float) -> None:
+        self.power_setpoint_percent = power_percent
+
+    def reset(self) -> None:
+        pass
 
 
 class ReactorHeatSource:
@@ -571,6 +611,14 @@ class NuclearPlantSimulator:
         elif heat_source == "constant":
             heat_source = ConstantHeatSource(noise_std_percent=0.1)
         constant = isinstance(heat_source, ConstantHeatSource)
+        # anything else must speak the reference's HeatSource plugin interface; an object this facade cannot map is refused
+        # rather than silently run as the reactor model
+        plugin = not constant and not isinstance(heat_source, ReactorHeatSource)
+        if plugin and not (callable(getattr(heat_source, "update", None)) and hasattr(heat_source, "rated_power_mw")):
+            raise TypeError("heat_source must be a ConstantHeatSource, a ReactorHeatSource, 'constant', 'reactor' or an object with the "
+                            "reference's HeatSource interface (update(dt, **kwargs) -> {'thermal_power_mw', 'power_percent'}, "
+                            "rated_power_mw): got %r" % (heat_source,))
+        self._plugin = heat_source if plugin else None
         self.dt = dt
         self.enable_secondary = bool(enable_secondary)
         self.enable_state_management = enable_state_management
@@ -586,17 +634,24 @@ class NuclearPlantSimulator:
         if constant:
             params["hs_noise_filter_tau"] = float(heat_source.noise_filter_time_constant)
         maint_cfg = (secondary_config or {}).get("maintenance_system", {}) if isinstance(secondary_config, dict) else {}
-        if maint_cfg.get("maintenance_mode") not in ("aggressive", "ultra_aggressive") and enable_state_management and secondary_config is not None:
+        # sim.py:97-128, auto_maintenance.py:187-198: anything but an aggressive mode in the configuration -- no configuration at
+        # all included -- delays execution by priority
+        if maint_cfg.get("maintenance_mode") not in ("aggressive", "ultra_aggressive") and enable_state_management:
             params.update(maint_start_delay_hours=1.0, maint_medium_delay_hours=4.0, maint_low_delay_hours=24.0)
         thresholds = ((maint_cfg.get("component_configs") or {}).get("feedwater") or {}).get("thresholds")
-        self._env = BatchedPlantEnv(1, dt=dt, heat_source="constant" if constant else "reactor",
+        if thresholds is None:
+            # no maintenance configuration: the state manager's factory default (state_manager.py
+            # _create_default_maintenance_config) gives a feedwater pump this one threshold -- not the data-gen action-test
+            # table, which would top a pump off at 58 % (fixture m14_default_configuration_maintenance)
+            thresholds = dict(FACTORY_DEFAULT_PUMP_THRESHOLDS)
+        self._env = BatchedPlantEnv(1, dt=dt, heat_source="constant" if constant else ("external" if plugin else "reactor"),
                                     noise_enabled=bool(constant and heat_source.noise_enabled),
                                     noise_std_percent=float(heat_source.noise_std_percent) if constant else 0.1,
                                     noise_seeds=[heat_source.noise_seed] if (constant and heat_source.noise_enabled and
                                                                              heat_source.noise_seed is not None) else None,
                                     device=device, maintenance=bool(enable_state_management and enable_secondary), params=params,
                                     maintenance_thresholds=thresholds, mode="full" if enable_secondary else "primary",
-                                    reactivity_components=not constant)
+                                    reactivity_components=not constant and not plugin)
         # the reference's object tree, as far as it is plant state: attribute paths resolve against the schema
         self.primary_physics = _PathProxy(self._env, "primary_physics",
                                           extras={"heat_source": heat_source, "rated_power_mw": heat_source.rated_power_mw})
@@ -645,16 +700,30 @@ class NuclearPlantSimulator:
 
     def set_power_setpoint(self, power_percent: float) -> None:
         """heat_source.set_power_setpoint  constant_heat_source.py:93-102 (applied at the next step)."""
-        self.primary_physics.heat_source._pending = float(power_percent)
+        if self._plugin is not None:
+            self._plugin.set_power_setpoint(float(power_percent))
+        else:
+            self.primary_physics.heat_source._pending = float(power_percent)
 
     def step(self, action: Optional[ControlAction] = None, magnitude: float = 1.0, load_demand: float = None,
              cooling_water_temp: float = None) -> Dict:
         a = ControlAction.NO_ACTION.value if action is None else (action.value if isinstance(action, ControlAction) else int(action))
         hs = self.primary_physics.heat_source
-        sp, hs._pending = hs._pending, None
-        obs, rew, done, info = self._env.step(action=[a], magnitude=[magnitude],
-                                              power_setpoint=None if sp is None else [sp],
-                                              cooling_water_temp=None if cooling_water_temp is None else [cooling_water_temp])
+        if self._plugin is not None:
+            # primary/__init__.py:203-225: actuators first, then heat_source.update(dt, reactor_state, control_action); the plugin
+            # sees the state as it is before this step's actuator movement (its result is an input column of the launch)
+            res = self._plugin.update(dt=self.dt, reactor_state=self.state, control_action=ControlAction(a))
+            unsupported = [k for k in ("neutron_flux", "reactivity_pcm", "reactivity_components") if k in res and res[k] not in (None, {}, 0, 0.0)]
+            if unsupported:
+                raise NotImplementedError("a HeatSource plugin's result may carry thermal_power_mw and power_percent; %s are not supported" % unsupported)
+            obs, rew, done, info = self._env.step(action=[a], magnitude=[magnitude], thermal_power_mw=[float(res["thermal_power_mw"])],
+                                                  power_percent=[float(res["power_percent"])],
+                                                  cooling_water_temp=None if cooling_water_temp is None else [cooling_water_temp])
+        else:
+            sp, hs._pending = getattr(hs, "_pending", None), None
+            obs, rew, done, info = self._env.step(action=[a], magnitude=[magnitude],
+                                                  power_setpoint=None if sp is None else [sp],
+                                                  cooling_water_temp=None if cooling_water_temp is None else [cooling_water_temp])
         o = obs[0].cpu().numpy().copy()
         rho = info.pop("reactivity_components", None)
         inf = {k: (v[0].item()) for k, v in info.items()}
@@ -700,7 +769,10 @@ class NuclearPlantSimulator:
             eff = torch.stack([env.get_field("pump.lubrication_effectiveness", instance=k) for k in range(scenarios.NUM_PUMPS)], dim=1).cpu().numpy()
             env.set_fields(scenarios.feedwater_reset_fields(self._feedwater_ic, 1, eff, start_at_steady_state))
             obs = env.get_observation()
-        self.primary_physics.heat_source._pending = None
+        if self._plugin is not None:
+            self._plugin.reset()        # primary/__init__.py reset_system -> heat_source.reset()
+        else:
+            self.primary_physics.heat_source._pending = None
         if hasattr(self.primary_physics.heat_source, "power_setpoint_percent"):
             self.primary_physics.heat_source.power_setpoint_percent = 100.0
         self.load_demand = 100.0

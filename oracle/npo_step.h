@@ -76,7 +76,7 @@ NPO_FN double npo_finite_or(double x, double dflt) { return isfinite(x) ? x : df
 NPO_FN void npo_step(npo_plant_t *pl, const npb_params_t *P, const npo_inputs_t *in, npo_outputs_t *out) {
   npb_prim_t *s = &pl->prim;
   /* heat_source.set_power_setpoint  constant_heat_source.py:93-102 (called by the driver loop before step) */
-  if (!isnan(in->power_setpoint)) s->hs_setpoint_percent = npo_clip(in->power_setpoint, 0.0, 150.0);
+  if (P->heat_source != NPB_HEAT_EXTERNAL && !isnan(in->power_setpoint)) s->hs_setpoint_percent = npo_clip(in->power_setpoint, 0.0, 150.0);
   if (!isnan(in->cooling_water_temp)) pl->sec.cooling_water_temperature = in->cooling_water_temp; /* sim.py:138-139 */
 
   int nan_reset = 0;

@@ -121,6 +121,20 @@ def scenarios():
              [(W % (2, "pump_bearings"), 6.0)])):
         S.append(dict(name="m13" + tag, steps=14, dt=5.0, noise=True, noise_seed=42, every=1, thresholds_override=override, init_pokes=pokes,
                       runner=dict(action="oil_top_off", duration_hours=2.0)))
+    # M14: NuclearPlantSimulator(enable_state_management=True) WITHOUT a maintenance configuration (sim.py:97-128): the state
+    # manager's factory default gives a feedwater pump ONE threshold (oil_level < 30 -> oil_top_off, HIGH, 24 h cooldown,
+    # state_manager.py _create_default_maintenance_config) and the non-aggressive mode delays execution by 1 / 4 / 24 h
+    # (auto_maintenance.py:187-198).  FWP-1 at 57 % (below the data-gen table's 58 %, above 30: nothing), FWP-2 at 25 % and FWP-3
+    # at 29.9 % (one order each at step 0, executed one per 15-min check once the hour has passed)
+    S.append(dict(name="m14_default_configuration_maintenance", steps=100, dt=1.0, every=2, state_management=True,
+                  init_pokes=[(L % (1, "oil_level"), 57.0), (L % (2, "oil_level"), 25.0), (L % (3, "oil_level"), 29.9)]))
+    # H1: a user-supplied heat source through the reference's plugin interface (heat_source_interface.py:23-112, consumed at
+    # primary/__init__.py:203-225): a scripted load swing whose power_percent is NOT its thermal power over rated (the two keys
+    # are independent in the interface), with actuator actions and a cooling-water swing on top
+    S.append(dict(name="h1_heat_source_plugin", steps=160, heat_source="external", every=4,
+                  heat_script=lambda k: (3000.0 * (0.82 + 0.15 * float(np.sin(k / 17.0))), 100.0 * (0.80 + 0.17 * float(np.sin(k / 17.0 + 0.2)))),
+                  actions=lambda t: (int(acts[t]), float(mags[t])) if t % 3 == 0 else None,
+                  cooling=lambda t: 24.0 + 3.0 * float(np.cos(t / 25.0))))
     # C1-C5: branches no other fixture visits (tests/test_fixture_coverage.py lists what varies where)
     FP = "secondary_physics.feedwater_system.pump_system.pumps['FWP-%d']"
     SGP = "secondary_physics.steam_generator_system.steam_generators[%d].tsp_fouling.deposits.%s_thickness[%d]"
@@ -322,9 +336,11 @@ def main(only=None):
         every = sc.get("every", 1)
         steps = sorted(set(list(range(0, T + 1, every)) + [T] + [t + 1 for t in sc.get("pokes", {})] + list(sc.get("pokes", {}).keys())
                            + [t for t in sc.get("resets", {})] + [t + 1 for t in sc.get("resets", {})]))
-        meta = {k: v for k, v in sc.items() if not callable(v) and k not in ("pokes", "resets", "_maint_thresholds", "init_pokes")}
+        meta = {k: v for k, v in sc.items() if not callable(v) and k not in ("pokes", "resets", "_maint_thresholds", "_maint_params", "init_pokes")}
         if sc.get("_maint_thresholds"):
             meta["maint_thresholds"] = sc["_maint_thresholds"]   # the FWP thresholds dict the run used, in its order
+        if sc.get("_maint_params"):
+            meta["maint_params"] = sc["_maint_params"]           # execution delays by priority, when they are not the runner's zeros
         meta["resets"] = {str(k): bool(v) for k, v in sc.get("resets", {}).items()}
         meta["pokes"] = {str(k): [[p, trace.poke_number(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
         meta["init_pokes"] = [[p, trace.poke_number(v)] for p, v in sc.get("init_pokes", [])]

@@ -125,12 +125,49 @@ def make_sim(dt=1.0, heat_source="constant", noise=False, noise_std_percent=0.1,
             hs = ConstantHeatSource(3000.0, noise_enabled=noise,
                                     noise_std_percent=noise_std_percent,
                                     noise_seed=noise_seed)
+        elif callable(heat_source):
+            hs = scripted_heat_source(heat_source)
         else:
             hs = ReactorHeatSource(3000.0)
         cfg = {"secondary_system": secondary or {}}
         sim = NuclearPlantSimulator(dt=dt, heat_source=hs, secondary_config=cfg,
                                     enable_state_management=state_management, enable_secondary=enable_secondary)
     return sim
+
+
+def scripted_heat_source(script, rated_power_mw=3000.0):
+    """a user-supplied heat source written against the reference's plugin interface (heat_source_interface.py:23-112):
+    script(k) -> (thermal_power_mw, power_percent) of its k-th update"""
+    from systems.primary.reactor.heat_sources.heat_source_interface import HeatSource
+
+    class ScriptedHeatSource(HeatSource):
+        def __init__(self):
+            super().__init__(rated_power_mw)
+            self.k = 0
+            self.results = []
+
+        def get_thermal_power_mw(self):
+            return self.current_power_mw
+
+        def get_power_percent(self):
+            return self.current_power_mw / self.rated_power_mw * 100.0
+
+        def set_power_setpoint(self, power_percent):
+            self.power_setpoint_percent = power_percent
+
+        def update(self, dt, **kwargs):
+            tp, pp = script(self.k)
+            self.k += 1
+            self.current_power_mw = tp
+            self.results.append((tp, pp))
+            return {"thermal_power_mw": tp, "power_percent": pp}
+
+        def get_state_dict(self):
+            return {"thermal_power_mw": self.current_power_mw}
+
+        def reset(self):
+            self.current_power_mw = 0.0
+    return ScriptedHeatSource()
 
 
 def make_runner_sim(action="oil_top_off", duration_hours=4.0, feedwater_ic=None, randomization_seed=None):

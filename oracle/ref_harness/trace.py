@@ -77,10 +77,10 @@ def run_reference(sc, columns):
         runner, sim = refsim.make_runner_sim(**sc["runner"])
         profile = runner._generate_power_profile(sc["steps"])
     else:
-      sim = refsim.make_sim(dt=sc.get("dt", 1.0), heat_source=sc.get("heat_source", "constant"),
+      sim = refsim.make_sim(dt=sc.get("dt", 1.0), heat_source=sc.get("heat_script") or sc.get("heat_source", "constant"),
                           noise=sc.get("noise", False), noise_std_percent=sc.get("noise_std_percent", 0.1),
                           noise_seed=sc.get("noise_seed", 42), secondary=sc.get("secondary"),
-                          enable_secondary=sc.get("enable_secondary", True))
+                          enable_secondary=sc.get("enable_secondary", True), state_management=sc.get("state_management", False))
     from systems.primary import ControlAction
     if sc.get("thresholds_override"):
         # edit the live maintenance thresholds of every feedwater pump (what another maintenance configuration would load)
@@ -90,6 +90,14 @@ def run_reference(sc, columns):
                     th[name].update(changes)
         sc["_maint_thresholds"] = [[n, {k: c.get(k) for k in ("threshold", "comparison", "action", "cooldown_hours", "priority", "component_id")}]
                                    for n, c in sim.state_manager.maintenance_thresholds["FWP-1"].items()]
+    if sc.get("state_management") and getattr(sim, "maintenance_system", None) is not None:
+        # a simulator constructed with state management but without a maintenance configuration: the thresholds the state
+        # manager's factory default gives a feedwater pump and the execution delays of the non-aggressive mode, as the run used them
+        ms = sim.maintenance_system
+        sc["_maint_thresholds"] = [[n, {k: c.get(k) for k in ("threshold", "comparison", "action", "cooldown_hours", "priority", "component_id")}]
+                                   for n, c in sim.state_manager.maintenance_thresholds["FWP-1"].items()]
+        sc["_maint_params"] = dict(maint_emergency_delay_hours=float(ms.emergency_delay_hours), maint_start_delay_hours=float(ms.high_priority_delay_hours),
+                                   maint_medium_delay_hours=float(ms.medium_priority_delay_hours), maint_low_delay_hours=float(ms.low_priority_delay_hours))
     if sc.get("equilibrium") is not None:
         from systems.primary.reactor.reactivity_model import create_equilibrium_state
         p, rods = sc["equilibrium"]
@@ -143,6 +151,8 @@ def run_reference(sc, columns):
                 cw[t] = v; kw["cooling_water_temp"] = v
         with refsim.quiet():
             r = sim.step(ControlAction(int(act[t])), magnitude=float(mag[t]), **kw)
+        if sc.get("heat_script") is not None:    # the plugin's result for this step, in the columns the C ABI carries it in (NPB_HEAT_EXTERNAL)
+            z[t], sp[t] = sim.primary_physics.heat_source.results[-1]
         obs[t, :len(r["observation"])] = r["observation"]; rew[t] = r["reward"]; done[t] = bool(r["done"])
         i = r["info"]
         info[t] = [i["thermal_power"], i["reactivity"], i.get("electrical_power", np.nan),

@@ -17,7 +17,9 @@ def _env(g=None, n=1, **kw):
         kw.setdefault("heat_source", m.get("heat_source", "constant"))
         kw.setdefault("noise_enabled", bool(m.get("noise")))
         kw.setdefault("noise_std_percent", m.get("noise_std_percent", 0.1))
-        kw.setdefault("maintenance", bool(m.get("runner")))
+        kw.setdefault("maintenance", bool(m.get("runner") or m.get("state_management")))
+        if m.get("maint_params"):    # execution delays by priority (the non-aggressive mode of a simulator without a maintenance configuration)
+            kw.setdefault("params", dict(m["maint_params"]))
         kw.setdefault("mode", "full" if m.get("enable_secondary", True) else "primary")   # NuclearPlantSimulator(enable_secondary=False)
         kw.setdefault("reactivity_components", g.rc is not None)
         if m.get("maint_thresholds"):    # the run used a maintenance configuration other than the default one
@@ -352,6 +354,66 @@ def test_config4_randomized_oil_top_off_scenario(oracle_lib):
             np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)
     created = env.get_field("maint.work_orders_created").cpu().numpy()
     assert created.max() >= 1 and created.min() == 0, "the scenario mix has plants that trigger within 2 h and plants that do not"
+
+
+def test_facade_without_a_maintenance_configuration_is_the_references_default():
+    """NuclearPlantSimulator(enable_state_management=True) with NO maintenance configuration (the constructor's default): the
+    reference gives a feedwater pump one threshold, oil_level < 30 -> oil_top_off, and delays HIGH-priority work by an hour
+    (sim.py:97-128, auto_maintenance.py:187-198, state_manager.py _create_default_maintenance_config) -- not the data-gen
+    action-test table, which would top a pump off at 58 % at once.  Fixture m14 is that reference run: FWP-1 at 57 % is left
+    alone, FWP-2 (25 %) and FWP-3 (29.9 %) get one order each at step 0, carried out one per check after the hour."""
+    from nuclear_sim_amd.env import NuclearPlantSimulator, ConstantHeatSource, ControlAction
+    g = Golden("m14_default_configuration_maintenance")
+    sim = NuclearPlantSimulator(dt=1.0, heat_source=ConstantHeatSource(rated_power_mw=3000.0), secondary_config={"secondary_system": {}},
+                                enable_state_management=True)
+    for k, lv in ((0, 57.0), (1, 25.0), (2, 29.9)):
+        sim._env.set_field("pump.oil_level", np.array([lv]), instance=k)
+    cols = {c[2]: j for j, c in enumerate(g.cols)}
+    sampled = {int(s): k for k, s in enumerate(g.state_steps)}
+    for t in range(g.T):
+        r = sim.step(action=ControlAction.NO_ACTION)
+        np.testing.assert_allclose(r["observation"], g.obs[t], rtol=RTOL, atol=1e-12, err_msg="obs step %d" % t)
+        if t + 1 in sampled:
+            row = g.state[sampled[t + 1]]
+            assert int(sim._env.get_field("maint.work_orders_created")[0].item()) == int(row[cols["maint.work_orders_created"]]), t
+            assert r["info"]["maintenance_event_count"] == int(row[cols["maint.maintenance_actions_performed"]]), t
+            for k in range(3):
+                np.testing.assert_allclose(sim._env.get_field("pump.oil_level", instance=k)[0].item(), row[cols["pump[%d].oil_level" % k]], rtol=RTOL)
+    assert int(sim._env.get_field("maint.maintenance_actions_performed")[0].item()) == 2
+    assert sim._env.get_field("pump.oil_level", instance=0)[0].item() < 57.0      # never topped off: 57 % is above the default's 30 %
+
+
+def test_heat_source_plugin_through_the_facade():
+    """The reference's HeatSource plugin interface (heat_sources/heat_source_interface.py:23-112): a user's heat source object
+    handed to NuclearPlantSimulator is called once per step on the host and its thermal_power_mw / power_percent reach the
+    step as input columns (NPB_HEAT_EXTERNAL).  Fixture h1 is the reference itself running the same scripted source, with
+    actuator actions and a cooling-water swing; an object the facade cannot map is refused, not run as the reactor model."""
+    from nuclear_sim_amd.env import NuclearPlantSimulator, HeatSource, ControlAction
+    g = Golden("h1_heat_source_plugin")
+
+    class Scripted(HeatSource):
+        def __init__(self):
+            super().__init__(3000.0)
+            self.k = 0
+
+        def update(self, dt, **kwargs):
+            assert "reactor_state" in kwargs and "control_action" in kwargs          # primary/__init__.py:203-207
+            k = self.k; self.k += 1
+            return {"thermal_power_mw": 3000.0 * (0.82 + 0.15 * float(np.sin(k / 17.0))), "power_percent": 100.0 * (0.80 + 0.17 * float(np.sin(k / 17.0 + 0.2)))}
+
+    sim = NuclearPlantSimulator(dt=1.0, heat_source=Scripted(), secondary_config={"secondary_system": {}}, enable_state_management=False)
+    for t in range(g.T):
+        np.testing.assert_allclose([3000.0 * (0.82 + 0.15 * np.sin(t / 17.0)), 100.0 * (0.80 + 0.17 * np.sin(t / 17.0 + 0.2))], [g.noise_z[t], g.setpoint[t]], rtol=1e-15)
+        r = sim.step(action=ControlAction(int(g.action[t])), magnitude=float(g.magnitude[t]), cooling_water_temp=float(g.cooling[t]))
+        np.testing.assert_allclose(r["observation"], g.obs[t], rtol=RTOL, atol=1e-12, err_msg="obs step %d" % t)
+        np.testing.assert_allclose(r["reward"], g.reward[t], rtol=RTOL, atol=1e-9)
+        assert r["info"]["reactivity"] == 0.0 and r["info"]["reactivity_components"] == {}      # primary/__init__.py:218-225
+    with pytest.raises(TypeError):
+        NuclearPlantSimulator(heat_source=object())
+    with pytest.raises(ValueError):
+        _env(n=4, heat_source="external").step()                      # the plugin's columns are this mode's required inputs
+    with pytest.raises(ValueError):
+        _env(n=4).step(thermal_power_mw=np.full(4, 3000.0))
 
 
 def test_config4_counts_held_by_the_reference():

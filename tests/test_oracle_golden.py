@@ -10,10 +10,12 @@ def _configure(npo, g):
     P = npo.Params()
     m = g.meta
     P.dt = m.get("dt", 1.0)
-    P.heat_source = 1 if m.get("heat_source") == "reactor" else 0
+    P.heat_source = {"reactor": 1, "external": 2}.get(m.get("heat_source"), 0)
     P.hs_noise_enabled = 1 if m.get("noise") else 0
     P.hs_noise_std_percent = m.get("noise_std_percent", 0.1)
-    P.maint_enabled = 1 if m.get("runner") else 0  # fixtures made through the data-gen runner have auto-maintenance on
+    P.maint_enabled = 1 if (m.get("runner") or m.get("state_management")) else 0  # the data-gen runner's simulators and enable_state_management=True have auto-maintenance on
+    for k, v in (m.get("maint_params") or {}).items():     # execution delays by priority (non-aggressive mode)
+        setattr(P, k, v)
     P.mode = 0 if m.get("enable_secondary", True) else 2     # NuclearPlantSimulator(enable_secondary=False)
     P.info_reactivity_components = 1 if g.rc is not None else 0
     # the maintenance thresholds the run used, when they are not the default configuration's
