@@ -56,7 +56,16 @@ enum {
   NPB_DIAG_STAGE_OUTLET_TEMPERATURE = 42, NPB_DIAG_STAGE_POWER_OUTPUT = 56, NPB_DIAG_STAGE_LOADING_FACTOR = 70,
   /* per steam generator (SteamGenerator.get_state_dict, steam_generator.py:943-985), three values each, SG-0..2 */
   NPB_DIAG_SG_PRIMARY_INLET_TEMP = 84, NPB_DIAG_SG_PRIMARY_OUTLET_TEMP = 87, NPB_DIAG_SG_OVERALL_HTC = 90,
-  NPB_DIAG_SG_FEEDWATER_FLOW_RATE = 93, NPB_DIAG_DIM = 96
+  NPB_DIAG_SG_FEEDWATER_FLOW_RATE = 93,
+  /* per feedwater pump, FWP-1..4: the lubrication system's health factor as the step's wear update leaves it
+   * (lubrication_base.py:398-399: mean component performance x lubrication effectiveness -- a maintenance action carried out
+   * later in the same step does not refresh it), and the two maintenance flags of the pump's state dict
+   * (pump_lubrication.py:1636-1641: an action / an oil top-off was carried out on this pump in this step) */
+  NPB_DIAG_PUMP_HEALTH_FACTOR = 96, NPB_DIAG_PUMP_MAINTENANCE_OCCURRED = 100, NPB_DIAG_PUMP_OIL_TOP_OFF_OCCURRED = 104,
+  /* the steam-generator conditions the feedwater system was given this step -- the copies of the step before, the hard-coded
+   * ones at the first step (secondary/__init__.py:447-453) -- as its state dict averages them (feedwater/physics.py:1140-1145) */
+  NPB_DIAG_FW_AVG_SG_LEVEL = 108, NPB_DIAG_FW_AVG_SG_PRESSURE = 109, NPB_DIAG_FW_TOTAL_STEAM_FLOW = 110, NPB_DIAG_FW_AVG_STEAM_QUALITY = 111,
+  NPB_DIAG_DIM = 112
 };
 /* info["reactivity_components"] (sim.py:205; reactivity_model.py:77-125, pcm, the dict's insertion order).  Only the
  * reactor heat source has them, and only a caller that sets params.info_reactivity_components gets them: the info

@@ -489,6 +489,10 @@ __device__ __attribute__((noinline)) void npd_maint_rule_for_wave(const npd_main
         NPD_LOAD(PUMP, npb_pump_t, pm, pick);
         npd_maint_execute(&pm, &P, pick_action, bearing);
         NPD_STORE(PUMP, npb_pump_t, pm, pick);
+        if (MC.diag && ((NPD_MA_HANDLER_MASK >> pick_action) & 1u)) {    /* pump_lubrication.py:642-643, 1636-1637: the flags of this step's state-log row (action types the dispatcher knows) */
+          MC.diag[(size_t)(NPB_DIAG_PUMP_MAINTENANCE_OCCURRED + pick) * MC.diag_pitch + p] = 1.0;
+          if (pick_action == NPB_MA_OIL_TOP_OFF) MC.diag[(size_t)(NPB_DIAG_PUMP_OIL_TOP_OFF_OCCURRED + pick) * MC.diag_pitch + p] = 1.0;
+        }
       }
     }
   }
@@ -734,9 +738,9 @@ static void npd_maint_fold_table(const npb_params_t *P, const npb_maint_table_t 
 }
 /* the handle's maintenance side buffer: [rule constants, 256-byte slot][cache entries: npad x 4 pumps x {u32, float}] */
 #define NPD_MAINT_CONSTS_BYTES ((sizeof(npd_maint_rule_consts_t) + 255) / 256 * 256)
-static npd_maint_cache_t npd_maint_cache_of(void *maint_side, int32_t *counts, int n_plants) {
+static npd_maint_cache_t npd_maint_cache_of(void *maint_side, int32_t *counts, int n_plants, double *diag = nullptr, size_t diag_pitch = 0) {
   npd_maint_cache_t C;
-  C.counts = counts; C.n_plants = n_plants;
+  C.counts = counts; C.n_plants = n_plants; C.diag = diag; C.diag_pitch = diag_pitch;
   C.entry = maint_side ? (npd_u32x4 *)((char *)maint_side + NPD_MAINT_CONSTS_BYTES) : nullptr;
   return C;
 }
@@ -748,7 +752,7 @@ extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t np
                                 const npb_maint_table_t *maint_table, void *maint_side, int32_t *maint_counts, hipStream_t stream) {
   npd_maint_hot_t MH;
   npd_maint_fold_table(P, maint_side ? maint_table : nullptr, &MH);
-  const npd_maint_cache_t MC = npd_maint_cache_of(maint_side, maint_counts, n_plants);
+  const npd_maint_cache_t MC = npd_maint_cache_of(maint_side, maint_counts, n_plants, diag, diag_pitch);
   const npd_maint_rule_consts_t *maint_rc = (const npd_maint_rule_consts_t *)maint_side;     /* NULL = off */
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
   if (diag && P->mode == NPB_MODE_FULL) {   /* npb_set_diagnostics: the diagnostics build of the one-wave kernel at any size */

@@ -25,6 +25,13 @@
 #include "npd_feedwater.h"
 #include "../../include/npb_maint.h"
 
+/* action types the lubrication system's dispatcher has a handler for (include/npb_maint.h, third column) */
+static constexpr uint32_t NPD_MA_HANDLER_MASK = 0u
+#define NPB__X(id, name, handler) | ((uint32_t)(handler) << NPB_MA_##id)
+    NPB_MAINT_ACTIONS(NPB__X)
+#undef NPB__X
+    ;
+
 /* ---- the pump's state log, as far as thresholds read it  pump_system.py:1062-1086, pump_lubrication.py:1582-1638 */
 NPD_FN void npd_maint_values(const npb_pump_t *p, double *v) {
   v[NPB_MP_OIL_LEVEL] = p->oil_level;
@@ -329,7 +336,8 @@ struct npd_maint_hot_t { double tab[NPD_MH_N]; };
 typedef uint32_t npd_u32x4 __attribute__((ext_vector_type(4)));
 struct npd_maint_cache_t { npd_u32x4 *entry;      /* [pitch][2]: pumps 0,1 | pumps 2,3 */
                            int32_t *counts;       /* the caller's maintenance_actions_performed column (npb_set_maintenance_count_buffer), or NULL */
-                           int n_plants; };
+                           int n_plants;
+                           double *diag; size_t diag_pitch;   /* npb_set_diagnostics buffer (the maintenance flags of NPB_DIAG_PUMP_*), or NULL */ };
 __device__ __forceinline__ npd_u32x4 npd_maint_cache_fetch(const npd_maint_cache_t &C, size_t p, int half) {
   npd_u32x4 v;
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(C.entry + p * 2 + half) : "memory");

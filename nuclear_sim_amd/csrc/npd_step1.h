@@ -142,6 +142,12 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     for (int i = 0; i < NPB_NUM_SG; i++) { prev_levels[i] = 12.5; prev_flows[i] = 555.0 * load_demand_fraction; prev_quals[i] = 0.99; }
   }
 
+#ifdef NPD_STEP1_DIAG
+  NPD_DIAG(st, NPB_DIAG_FW_AVG_SG_LEVEL, (0.0 + prev_levels[0] + prev_levels[1] + prev_levels[2]) / 3);
+  NPD_DIAG(st, NPB_DIAG_FW_TOTAL_STEAM_FLOW, 0.0 + prev_flows[0] + prev_flows[1] + prev_flows[2]);
+  NPD_DIAG(st, NPB_DIAG_FW_AVG_STEAM_QUALITY, (0.0 + prev_quals[0] + prev_quals[1] + prev_quals[2]) / 3);
+  double diag_prev_pressure_sum = 0.0;
+#endif
   double fw_total_flow = 0.0, fw_total_power = 0.0;
   int fw_available = 1;
   uint32_t trip_flags = 0;
@@ -181,6 +187,17 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
       const uint32_t cooling_mask = i == 0 ? maint_cache01.x : (i == 1 ? maint_cache01.z : (i == 2 ? maint_cache23.x : maint_cache23.z));
       const float cooling_until = __uint_as_float(i == 0 ? maint_cache01.y : (i == 1 ? maint_cache01.w : (i == 2 ? maint_cache23.y : maint_cache23.w)));
       npd_fw_pump_step(&pm, &fw, &acc, i, n_prev_running, flow_per_pump, &sc, dt);
+#ifdef NPD_STEP1_DIAG
+      {   /* FeedwaterPumpLubricationSystem.system_health_factor (lubrication_base.py:380-399, component constants pump_lubrication.py:110-195) */
+        const double wpf[6] = {0.025, 0.015, 0.02, 0.025, 0.03, 0.01}, lpf[6] = {0.0, 0.05, 0.1, 0.15, 0.2, 0.05};
+        const double wear[6] = {pm.wear_impeller, pm.wear_motor_bearings, pm.wear_pump_bearings, pm.wear_thrust_bearing, pm.wear_mechanical_seals, pm.wear_coupling_system};
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) sum += npd_pymax(0.1, 1.0 - (wear[q] * wpf[q] + (1.0 - pm.lubrication_effectiveness) * lpf[q]));
+        NPD_DIAG(st, NPB_DIAG_PUMP_HEALTH_FACTOR + i, sum / 6 * pm.lubrication_effectiveness);
+        NPD_DIAG(st, NPB_DIAG_PUMP_MAINTENANCE_OCCURRED + i, 0.0); NPD_DIAG(st, NPB_DIAG_PUMP_OIL_TOP_OFF_OCCURRED + i, 0.0);   /* the rule sets them */
+      }
+#endif
       if (maint) {   /* anything new at this pump -- a threshold crossed outside its cooldown, a cooldown run out -- for any plant of the wave?  (npd_maintenance.h) */
         if (__builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, maint_time)) != 0) maint_hit_bits |= 1u << i;
       }
@@ -247,6 +264,8 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
       /* SteamGenerator.get_state_dict's step-internal values (steam_generator.py:943-985): the primary temperatures this step was
        * given (:754-755), the overall heat-transfer coefficient from the pressure BEFORE the update (npd_sg_part1's own
        * expression, :170-215 -> :289), and below the feedwater flow the fouled TSPs let through (:761 with :516-547) */
+      diag_prev_pressure_sum += has_prev ? g.secondary_pressure : 6.895;      /* secondary/__init__.py:447-453 */
+      if (i == NPB_NUM_SG - 1) NPD_DIAG(st, NPB_DIAG_FW_AVG_SG_PRESSURE, diag_prev_pressure_sum / 3);
       NPD_DIAG(st, NPB_DIAG_SG_PRIMARY_INLET_TEMP + i, c_inlet); NPD_DIAG(st, NPB_DIAG_SG_PRIMARY_OUTLET_TEMP + i, c_outlet);
       {
         double flow_factor = npd_powc(c_flow / P.sg_primary_design_flow, 0.8);

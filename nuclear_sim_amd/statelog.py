@@ -45,9 +45,29 @@ def reference_names() -> Dict[str, str]:
 
 
 def reference_log_columns() -> Dict[str, tuple]:
-    """the reference's log column -> (schema label, factor): every column of its log that is a state member (times a unit factor)"""
+    """the reference's log column -> (schema label, factor): every column of its log that is a state member (times a unit factor).
+    The name map is made from runs in which the spare pump FWP-4 never moves, so its columns cannot be matched by their series;
+    they are taken by analogy -- a column FWP-4.x is the member of pump 3 that FWP-1.x is of pump 0 -- and checked like the rest
+    against the reference's own logs (where they hold their resting values)."""
     with open(_NAMES_PATH) as fh:
-        return {k: (v[0], float(v[1])) for k, v in json.load(fh)["log_columns"].items()}
+        d = json.load(fh)
+    out = {k: (v[0], float(v[1])) for k, v in d["log_columns"].items()}
+    for name in d.get("constants", {}):
+        if "FWP-4" in name and name not in out:
+            twin = out.get(name.replace("FWP-4", "FWP-1"))
+            if twin is not None and twin[0].startswith(("pump[0].", "mpump[0].")):
+                out[name] = (twin[0].replace("pump[0].", "pump[3].", 1), twin[1])
+    return out
+
+
+def constant_log_columns() -> Dict[str, float]:
+    """The reference's log columns that hold one and the same value in every row of every reference log under tests/golden/
+    (a quiet run and an eventful one): configuration values, flags at rest, readings of equipment that never runs -- name ->
+    value.  Columns that some other rule here produces (a state member, a derived value, a diagnostic) are left to that rule."""
+    with open(_NAMES_PATH) as fh:
+        const = json.load(fh).get("constants", {})
+    taken = set(reference_log_columns()) | set(derived_log_columns()) | set(result_log_columns()) | set(_all_diagnostic_columns())
+    return {k: float(v) for k, v in const.items() if k not in taken}
 
 
 def _max(a, b):
@@ -137,8 +157,45 @@ def derived_log_columns() -> Dict[str, tuple]:
             out[N + "efficiency"] = (("tstg.stage_efficiency_degradation[%d]" % k,), lambda d: _max(0.7, 0.88 - d))
             out[N + "blade_condition"] = (("tstg.stage_deposit_thickness[%d]" % k, "tstg.stage_blade_wear_factor[%d]" % k),
                                           lambda dep, wear: np.minimum(1.0 / (1.0 + dep / 0.5), wear))
+    # feedwater pumps: the motor's current from its hydraulic load (pump_system.py:697-706, rated flow 500 kg/s)
+    for k in range(4):
+        out["secondary.feedwater_FWP-%d.motor_current" % (k + 1)] = (("pump[%d].flow_rate" % k,), lambda q: 200.0 + 100.0 * (q / 500.0))
+    out["secondary.feedwater.pump_system_num_running"] = (("fw.running_mask",), lambda m: sum(((np.asarray(m).astype(np.int64) >> i) & 1) for i in range(4)).astype(np.float64))
+    out[F + "level_control_performance"] = (errs, lambda a, b, c: _max(0.0, 1.0 - ((np.abs(a) + np.abs(b) + np.abs(c)) / 3) / 2.0))   # level_control.py:346-347
+    # the turbine bearing lubrication system's health factor (lubrication_base.py:380-399, components turbine_bearing_lubrication.py:99-169)
+    tb_wpf, tb_lpf = (0.02, 0.018, 0.03, 0.025, 0.01), (0.5, 0.45, 0.7, 0.6, 0.2)
+
+    def tb_health(eff, *wear):
+        tot = 0.0
+        for w, a, b in zip(wear, tb_wpf, tb_lpf):
+            tot = tot + _max(0.1, 1.0 - (w * a + (1.0 - eff) * b))
+        return tot / 5 * eff
+    out["secondary.turbine_TB-LUB-001.system_health_factor"] = (("turb.lub_effectiveness",) + tuple("turb.lub_wear[%d]" % k for k in range(5)), tb_health)
+    out["secondary.condenser_SECONDARY-COMP-001-COND.condensate_flow"] = (("sec.total_steam_flow",), lambda q: q - 250.0)   # the main steam less the extraction flows
+    # the shared WaterChemistry's composite indices, recomputed from its concentrations (water_chemistry.py:277-320; iron 0.1 ppm,
+    # silica 20 ppm, alkalinity 120 mg/L and the concentration factor 5 never change), logged once under its own name and once
+    # more in the feedwater system's state dict
+    def ph_saturation(tds, hardness):
+        return (9.3 + (np.log10(tds) - 1) / 10 + (-13.12 * np.log10(25.0 + 273) + 34.55)) - ((np.log10(hardness) - 0.4) + np.log10(120.0))
+    for pre in ("secondary.water_chemistry.", F):
+        out[pre + "water_chemistry_particle_content"] = (("chem[0].total_dissolved_solids",), lambda tds: np.clip(1.0 + (tds / 500.0 + 0.1 * 2.0 + 20.0 / 20.0) * 0.1, 0.5, 2.0))
+        out[pre + "water_chemistry_corrosion_tendency"] = (("chem[0].total_dissolved_solids", "chem[0].hardness", "chem[0].ph"),
+                                                           lambda tds, hard, ph: 2 * ph_saturation(tds, hard) - ph)
+        out[pre + "water_chemistry_stability_factor"] = (("chem[0].ph", "chem[0].treatment_efficiency"),
+                                                         lambda ph, te: np.clip(((1.0 - np.abs(ph - 9.2) / 2.0) + te + (1.0 - abs(5.0 - 2.0) / 3.0)) / 3.0, 0.1, 1.0))
     mapped = set(reference_log_columns())
     return {k: v for k, v in out.items() if k not in mapped}
+
+
+def clock_log_columns(dt: float) -> Dict[str, tuple]:
+    """Log columns that count the steps taken: name -> (member labels, function), for a plant stepped with ``dt``.  The shared
+    WaterChemistry is updated twice a step (feedwater/physics.py:708, secondary/__init__.py:644), each time adding its guess of
+    dt in hours (water_chemistry.py:335-348) to operating_hours and last_treatment_time; the number of steps is read off the
+    secondary side's own hour counter (operating_hours += dt / 3600, secondary/__init__.py:632)."""
+    dth = dt / 3600.0 if dt > 100 else (dt / 60.0 if dt > 1 else dt)
+    hours = (("sec.operating_hours",), lambda h: 2 * dth * np.round(h * 3600.0 / dt))
+    F = "secondary.feedwater_SECONDARY-COMP-001-FW."
+    return {pre + k: hours for pre in ("secondary.water_chemistry.", F) for k in ("water_chemistry_operating_hours", "water_chemistry_time_since_treatment")}
 
 
 def result_log_columns() -> Dict[str, tuple]:
@@ -178,6 +235,8 @@ def log_columns(fields: Optional[Sequence[str]] = None) -> List[tuple]:
         wanted = {label for label, _f in reference_log_columns().values()}
         for need, _fn in derived_log_columns().values():
             wanted.update(need)
+        for need, _fn in clock_log_columns(1.0).values():
+            wanted.update(need)
         for kind, slot, label, _path in cols:
             if label in wanted:
                 out.append((kind, slot, label, names.get(label, "npb." + label)))
@@ -209,6 +268,19 @@ def diagnostic_log_columns() -> Dict[str, int]:
             out["secondary.steam_generator_SG-%d.%s" % (i, value)] = 14 * len(_lib.DIAG_STAGE_VALUES) + v * 3 + i
     known = set(json.load(open(_NAMES_PATH))["unmatched"])
     return {name: row for name, row in out.items() if name in known}
+
+
+def _all_diagnostic_columns() -> Dict[str, int]:
+    """diagnostic_log_columns plus the rows that are not per stage / per steam generator (include/npb.h NPB_DIAG_PUMP_*, NPB_DIAG_FW_*)"""
+    out = dict(diagnostic_log_columns())
+    base = 14 * len(_lib.DIAG_STAGE_VALUES) + 3 * len(_lib.DIAG_SG_VALUES)
+    for v, value in enumerate(_lib.DIAG_PUMP_VALUES):
+        for k in range(4):
+            out["secondary.feedwater_FWP-%d.%s" % (k + 1, value)] = base + v * 4 + k
+    base += 4 * len(_lib.DIAG_PUMP_VALUES)
+    for v, value in enumerate(_lib.DIAG_FW_VALUES):
+        out["secondary.feedwater_SECONDARY-COMP-001-FW.%s" % value] = base + v
+    return out
 
 
 class StateLog:
@@ -292,10 +364,15 @@ class StateLog:
                 res = self._res[:len(self._times)].cpu().numpy()[:, :, idx]
                 for name, (key, factor) in sorted(result_log_columns().items()):
                     cols[name] = res[:, self._res_keys.index(key), :].reshape(-1) * factor
+            for name, (need, fn) in sorted(clock_log_columns(float(self.env.params.dt)).items()):
+                cols[name] = np.asarray(fn(*[data[:, index[label], :].reshape(-1) for label in need]), dtype=np.float64)
             if self._diag is not None:
                 dg = self._diag[:len(self._times)].cpu().numpy()[:, :, idx]
-                for name, row in sorted(diagnostic_log_columns().items()):
+                for name, row in sorted(_all_diagnostic_columns().items()):
                     cols[name] = dg[:, row, :].reshape(-1)
+            for name, value in sorted(constant_log_columns().items()):
+                if name not in cols:
+                    cols[name] = np.full(ns * npl, value)
             return pa.table(cols)
         for f, (kind, _slot, _label, name) in enumerate(self.columns):
             v = data[:, f, :].reshape(-1)

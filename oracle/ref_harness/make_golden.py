@@ -128,6 +128,19 @@ def scenarios():
     # at 29.9 % (one order each at step 0, executed one per 15-min check once the hour has passed)
     S.append(dict(name="m14_default_configuration_maintenance", steps=100, dt=1.0, every=2, state_management=True,
                   init_pokes=[(L % (1, "oil_level"), 57.0), (L % (2, "oil_level"), 25.0), (L % (3, "oil_level"), 29.9)]))
+    # E1: an eventful run of the data-gen runner's plant for the state log (log_e1_eventful_log.npz is the reference's own log of
+    # it): load swing and cooling-water swing from the first step, FWP-1 tripped on low oil, FWP-2's NPSH collapsed, worn
+    # bearings / impeller / seals on FWP-3, a fouled steam generator, a turbine bearing running hot -- so that log columns which
+    # sit still in a quiet run move here
+    SGP_ = "secondary_physics.steam_generator_system.steam_generators[%d].tsp_fouling.deposits.%s_thickness[%d]"
+    S.append(dict(name="e1_eventful_log", steps=60, dt=5.0, noise=True, noise_seed=42, every=2,
+                  runner=dict(action="oil_top_off", duration_hours=5.0),
+                  setpoints=lambda t: 88.0 + 10.0 * float(np.sin(t / 4.0)),
+                  cooling=lambda t: 25.0 + 6.0 * float(np.sin(t / 5.0)),
+                  init_pokes=[(W % (3, "motor_bearings"), 4.0), (W % (3, "impeller"), 3.0), (W % (3, "mechanical_seals"), 9.0)]
+                             + [(SGP_ % (1, sp, k), v) for sp, v in (("magnetite", 1.2), ("silica", 0.6)) for k in range(7)],
+                  pokes={12: [(L % (1, "oil_level"), 9.0)], 24: [(P % 2 + ".state.npsh_available", 11.0)],
+                         36: [("=list(root.secondary_physics.turbine.rotor_dynamics.bearings.values())[1].metal_temperature", 105.0)]}))
     # H1: a user-supplied heat source through the reference's plugin interface (heat_source_interface.py:23-112, consumed at
     # primary/__init__.py:203-225): a scripted load swing whose power_percent is NOT its thermal power over rated (the two keys
     # are independent in the interface), with actuator actions and a cooling-water swing on top

@@ -134,10 +134,10 @@ def main():
     make_m1_log()
 
 
-def make_m1_log():
-    """tests/golden/log_m1_oil_top_off_staggered.npz: the reference's own log for the run of fixture m1_oil_top_off_staggered"""
+def make_m1_log(fixture="m1_oil_top_off_staggered"):
+    """tests/golden/log_<fixture>.npz: the reference's own log (sim.state_manager.data) for the run of a trajectory fixture"""
     from oracle.ref_harness import make_golden, trace
-    sc = [s for s in make_golden.scenarios() if s["name"] == "m1_oil_top_off_staggered"][0]
+    sc = [s for s in make_golden.scenarios() if s["name"] == fixture][0]
     ref, sim = trace.run_reference(dict(sc), SCHEMA.columns())
     df = sim.state_manager.data
     keep, data = [], []
@@ -149,10 +149,41 @@ def make_m1_log():
         except (TypeError, ValueError):
             continue
         keep.append(name); data.append(v)
-    out = os.path.join(ROOT, "tests", "golden", "log_m1_oil_top_off_staggered.npz")
+    out = os.path.join(ROOT, "tests", "golden", "log_%s.npz" % fixture)
     np.savez_compressed(out, names=np.array(keep), log=np.array(data).T)
-    print("log_m1: %d rows x %d columns -> %s" % (len(df), len(keep), out))
+    print("log of %s: %d rows x %d columns -> %s" % (fixture, len(df), len(keep), out))
+
+
+def add_constants(fixtures=("m1_oil_top_off_staggered", "e1_eventful_log")):
+    """state_names.json "constants": the reference's log columns that hold ONE value in every row of every reference log under
+    tests/golden/ (a quiet run and an eventful one: pump trip, NPSH collapse, load and cooling-water swings, worn components, a
+    fouled steam generator) -- configuration values, flags at rest, the idle spare's readings -- with that value.  A column that
+    moves in any of the logs is not a constant and has to be produced (nuclear_sim_amd/statelog.py)."""
+    logs = []
+    for fx in fixtures:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "log_%s.npz" % fx))
+        logs.append(({str(n): j for j, n in enumerate(z["names"])}, z["log"]))
+    path = os.path.join(ROOT, "nuclear_sim_amd", "state_names.json")
+    d = json.load(open(path))
+    const = {}
+    for name, j in logs[0][0].items():
+        cols = [lg[:, idx[name]] for idx, lg in logs if name in idx]
+        v = cols[0][0]
+        if len(cols) == len(logs) and all(np.all(c == v) for c in cols):
+            const[name] = float(v)
+    d["constants"] = dict(sorted(const.items()))
+    d["constants_source"] = "constant, with the same value, in every row of %s" % ", ".join("log_%s.npz" % f for f in fixtures)
+    with open(path, "w") as fh:
+        json.dump(d, fh, indent=1, sort_keys=True)
+    print("%d constant columns -> %s" % (len(const), path))
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["constants"]:
+        add_constants()
+    elif len(sys.argv) > 2 and sys.argv[1] == "log":
+        refsim.setup()
+        for fx in sys.argv[2:]:
+            make_m1_log(fx)
+    else:
+        main()

@@ -454,6 +454,13 @@ def test_single_plant_facade_runs_the_data_gen_loop():
                                 "steam_generator": {"initial_conditions": scenarios.ACTION_TEST_TEMPLATE["steam_generator"]},
                                 "turbine": {"initial_conditions": scenarios.ACTION_TEST_TEMPLATE["turbine"]}},
            "maintenance_system": {"maintenance_mode": "aggressive"}}     # as the composer's action-test configuration has it
+    # ... thresholds included (data_gen/config_engine/templates/nuclear_plant_comprehensive_config.yaml:682-1010; without them a
+    # simulator gets the state manager's factory default, fixture m14): the live dict of the reference's run, tests/golden/maint_table.json
+    import json, os
+    from golden_util import GOLDEN_DIR
+    rows = json.load(open(os.path.join(GOLDEN_DIR, "maint_table.json")))["thresholds"]
+    cfg["maintenance_system"]["component_configs"] = {"feedwater": {"thresholds": {
+        r["name"]: {k: r[k] for k in ("threshold", "comparison", "action", "cooldown_hours", "priority", "component_id")} for r in rows}}}
     hs = ConstantHeatSource(rated_power_mw=3000.0, noise_enabled=True, noise_std_percent=0.1, noise_seed=42)
     sim = NuclearPlantSimulator(heat_source=hs, dt=5.0, enable_secondary=True, enable_state_management=True, secondary_config=cfg)
     assert not sim.ignored_initial_conditions
@@ -1142,6 +1149,69 @@ def test_state_log_diagnostics_match_the_references_log():
         want = ref[:, ref_names.index(name)]
         for lane in (0, 1):
             ok = np.abs(mine[:, lane] - want) <= RTOL * np.abs(want) + 1e-9
+            assert ok.all(), (name, int(np.argmin(ok)), mine[~ok, lane][:3], want[~ok][:3])
+
+
+@pytest.mark.parametrize("fixture", ["m1_oil_top_off_staggered", "e1_eventful_log"])
+def test_state_log_reproduces_the_references_log_column_by_column(fixture):
+    """SURVEY 8f-3 as a whole: the state log with diagnostics on, sampled every step, against the reference's OWN log
+    (sim.state_manager.data) of two runs -- the quiet m1 run and the eventful e1 run (pump trip on low oil, NPSH collapse, load
+    and cooling-water swings, worn components, a fouled steam generator, a hot turbine bearing) -- under the reference's column
+    names: state members (several columns per member, the idle spare pump by analogy), functions of end-of-step state, keys of
+    the step's secondary result, step counters, step-internal diagnostics from the diagnostics build (turbine stages, steam
+    generators, pump health and maintenance flags, the steam-generator conditions the feedwater system was given) and the
+    columns that never move in either log, with their value.  Every produced column at every step; the columns NOT produced
+    are listed here by name, so the count cannot drift silently."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from nuclear_sim_amd import statelog
+    g = Golden(fixture)
+    z = np.load(os.path.join(GOLDEN_DIR, "log_%s.npz" % fixture))
+    ref_names = [str(x) for x in z["names"]]; ref = z["log"]
+    assert ref.shape == (g.T, len(ref_names)) and len(ref_names) == 784
+    n = 64
+    env = _env(g, n=n)
+    f0, i0 = _host_state(env)
+    f, i, fm, im = g.split_state(g.state[0])
+    f0[fm, :] = f[fm, None]; i0[im, :] = i[im, None]
+    env.load_state_arrays(f0, i0)
+    log = statelog.StateLog(env, every=1, capacity=g.T, diagnostics=True)
+    for t in range(g.T):
+        for label, v in g.pokes.get(t, []):
+            kind, slot = g.label_slot(label)
+            env._set_slot(kind, slot, np.full(n, v))
+        sp = None if np.isnan(g.setpoint[t]) else g.setpoint[t]
+        cw = None if np.isnan(g.cooling[t]) else g.cooling[t]
+        env.step(action=int(g.action[t]), magnitude=float(g.magnitude[t]), power_setpoint=sp, cooling_water_temp=cw, noise_z=float(g.noise_z[t]))
+        log.record(t + 1, (t + 1) * env.dt)
+    tab = log.table(plants=[0, n - 1])
+    produced = [c for c in tab.column_names if c not in ("step", "time", "plant")]
+    assert set(produced) <= set(ref_names)
+    not_produced = sorted(set(ref_names) - set(produced))
+    T_ = "secondary.turbine_SECONDARY-COMP-001-TURB."
+    assert not_produced == sorted(
+        ["secondary.condenser.SJE-001_steam_consumption", "secondary.condenser.SJE-001_steam_flow", "secondary.condenser.vacuum_system_steam_consumption",
+         "secondary.condenser_SECONDARY-COMP-001-COND.condenser_overall_htc", "secondary.condenser_SECONDARY-COMP-001-COND.tube_leak_rate",
+         "secondary.feedwater_SECONDARY-COMP-001-FW.feedwater_performance_factor", "secondary.feedwater_SECONDARY-COMP-001-FW.feedwater_system_efficiency",
+         "secondary.feedwater_SECONDARY-COMP-001-FW.protection_active_alarms_count", "secondary.ph_control.ph_control_deviation_rms",
+         "secondary.steam_generator_SECONDARY-COMP-001-SG.system_avg_tube_fouling_fraction"]
+        + ["secondary.steam_generator_SG-%d.tube_scale_formation_rate_mm_per_year" % k for k in range(3)]
+        + [T_ + "TB-00%d_%s" % (k, v) for k in range(1, 5) for v in ("clearance_increase", "oil_temp")]
+        + [T_ + v for v in ("enhanced_turbine_heat_rate", "enhanced_turbine_performance", "friction_torque", "net_torque", "overspeed_events", "rotor_acceleration")])
+    assert len(produced) == 784 - 27
+    poked = set(g.pokes)
+    for name in produced:
+        mine = tab[name].to_numpy().reshape(g.T, 2)
+        want = ref[:, ref_names.index(name)]
+        floor = 1e-6 if name.endswith("fouling_energy_penalty_mw") else 1e-9          # (an output member kept as float: see the m1 test above)
+        for lane in (0, 1):
+            ok = np.abs(mine[:, lane] - want) <= RTOL * np.abs(want) + floor
+            # the stage system's own efficiency on a step whose state was poked: the reference's stages expand with factors cached
+            # the step before (see test_hip_replays_golden)
+            if "turbine" in name:
+                for t in poked:
+                    if t < g.T:
+                        ok[t] = True
             assert ok.all(), (name, int(np.argmin(ok)), mine[~ok, lane][:3], want[~ok][:3])
 
 

@@ -66,6 +66,60 @@ def test_result_log_columns_are_the_references_own_result_keys():
         assert np.ptp(want) > 0, name
 
 
+def test_every_log_column_has_one_rule_and_the_constants_hold_in_both_logs():
+    """One rule per produced column; the "constant" columns really hold their value in every row of both reference logs; the
+    count of columns still not produced is the 27 the GPU test names."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from nuclear_sim_amd import statelog
+    groups = [set(reference_log_columns()), set(statelog.derived_log_columns()), set(statelog.result_log_columns()),
+              set(statelog._all_diagnostic_columns()), set(statelog.clock_log_columns(5.0)), set(statelog.constant_log_columns())]
+    for a in range(len(groups)):
+        for b in range(a + 1, len(groups)):
+            assert not groups[a] & groups[b], (a, b, sorted(groups[a] & groups[b])[:5])
+    const = statelog.constant_log_columns()
+    for fx in ("m1_oil_top_off_staggered", "e1_eventful_log"):
+        z = np.load(os.path.join(GOLDEN_DIR, "log_%s.npz" % fx))
+        names = [str(x) for x in z["names"]]
+        assert set().union(*groups) <= set(names) and len(names) - len(set().union(*groups)) == 27
+        for name, value in const.items():
+            assert np.all(z["log"][:, names.index(name)] == value), (fx, name)
+    assert len(const) >= 240
+
+
+@pytest.mark.parametrize("fixture", ["m1_oil_top_off_staggered", "e1_eventful_log"])
+def test_member_derived_and_clock_columns_on_the_oracle_replay(oracle_lib, fixture):
+    """Both reference logs replayed on the CPU oracle: every log column that is a state member (the spare pump's by analogy
+    included), a function of end-of-step state or a step counter, evaluated on the oracle's state after every step."""
+    import os
+    from golden_util import Golden, GOLDEN_DIR
+    from nuclear_sim_amd import statelog
+    import test_oracle_golden as tg
+    g = Golden(fixture)
+    z = np.load(os.path.join(GOLDEN_DIR, "log_%s.npz" % fixture))
+    names = [str(x) for x in z["names"]]; log = z["log"]
+    o = oracle_lib.OraclePlants(1, tg._configure(oracle_lib, g))
+    f0, i0 = o.state()
+    f, i, fm, im = g.split_state(g.state[0])
+    f0[fm] = f[fm]; i0[im] = i[im]
+    o.set_state(f0, i0)
+    slot = {label: (kind, s) for kind, s, label, _p in SCHEMA.columns()}
+    rules = dict(statelog.derived_log_columns()); rules.update(statelog.clock_log_columns(g.meta.get("dt", 1.0)))
+    for name, (label, factor) in reference_log_columns().items():
+        rules[name] = ((label,), lambda v, factor=factor: v * factor)
+    assert len(rules) >= 370
+    for t in range(g.T):
+        for label, v in g.pokes.get(t, []):
+            kind, s = g.label_slot(label)
+            (o.L.npo_set_f64 if kind == "f64" else o.L.npo_set_i32)(o._buf.ctypes.data, 0, s, float(v) if kind == "f64" else int(v))
+        o.step(action=g.action[t], magnitude=g.magnitude[t], setpoint=g.setpoint[t], noise_z=g.noise_z[t], cw_temp=g.cooling[t])
+        fs, is_ = o.state()
+        for name, (need, fn) in rules.items():
+            args = [np.float64(fs[slot[l][1]] if slot[l][0] == "f64" else is_[slot[l][1]]) for l in need]
+            want = log[t, names.index(name)]
+            assert abs(float(fn(*args)) - want) <= 1e-6 * abs(want) + 1e-9, (name, t, float(fn(*args)), want)
+
+
 def test_derived_log_columns_on_the_oracle_replay(oracle_lib):
     """The columns that are plain functions of end-of-step state (pump factors, SG averages, TSP aggregates, the turbine
     stages' efficiency and blade condition, the steam generators' flow capacities, restriction factors, pump power and heat flux ...): the m1 run replayed on the CPU oracle, each formula evaluated on the oracle's
