@@ -65,7 +65,10 @@ enum {
   /* the steam-generator conditions the feedwater system was given this step -- the copies of the step before, the hard-coded
    * ones at the first step (secondary/__init__.py:447-453) -- as its state dict averages them (feedwater/physics.py:1140-1145) */
   NPB_DIAG_FW_AVG_SG_LEVEL = 108, NPB_DIAG_FW_AVG_SG_PRESSURE = 109, NPB_DIAG_FW_TOTAL_STEAM_FLOW = 110, NPB_DIAG_FW_AVG_STEAM_QUALITY = 111,
-  NPB_DIAG_DIM = 112
+  /* the rotor model's torque balance of this step (rotor_dynamics.py:855-911): bearing friction torque [N m] from the bearing loads
+   * the step began with, net torque, acceleration [RPM/s] */
+  NPB_DIAG_ROTOR_FRICTION_TORQUE = 112, NPB_DIAG_ROTOR_NET_TORQUE = 113, NPB_DIAG_ROTOR_ACCELERATION = 114,
+  NPB_DIAG_DIM = 115
 };
 /* info["reactivity_components"] (sim.py:205; reactivity_model.py:77-125, pcm, the dict's insertion order).  Only the
  * reactor heat source has them, and only a caller that sets params.info_reactivity_components gets them: the info

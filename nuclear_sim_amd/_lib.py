@@ -25,7 +25,8 @@ DIAG_STAGE_VALUES = ("inlet_pressure", "inlet_temperature", "outlet_pressure", "
 DIAG_SG_VALUES = ("primary_inlet_temp", "primary_outlet_temp", "overall_htc", "feedwater_flow_rate")   # steam_generator.py:943-985
 DIAG_PUMP_VALUES = ("system_health_factor", "maintenance_action_occurred", "oil_top_off_occurred")   # per pump, FWP-1..4 (NPB_DIAG_PUMP_*)
 DIAG_FW_VALUES = ("feedwater_avg_sg_level", "feedwater_avg_sg_pressure", "feedwater_total_steam_flow", "feedwater_avg_steam_quality")   # NPB_DIAG_FW_*
-DIAG_DIM = 14 * len(DIAG_STAGE_VALUES) + 3 * len(DIAG_SG_VALUES) + 4 * len(DIAG_PUMP_VALUES) + len(DIAG_FW_VALUES)
+DIAG_ROTOR_VALUES = ("friction_torque", "net_torque", "rotor_acceleration")   # NPB_DIAG_ROTOR_*
+DIAG_DIM = 14 * len(DIAG_STAGE_VALUES) + 3 * len(DIAG_SG_VALUES) + 4 * len(DIAG_PUMP_VALUES) + len(DIAG_FW_VALUES) + len(DIAG_ROTOR_VALUES)
 REACTIVITY_COMPONENTS = ("control_rods", "boron", "doppler", "moderator_temp", "moderator_void", "pressure", "xenon", "samarium",
                          "fuel_depletion", "burnable_poisons")   # reactivity_model.py:87-121, NPB_RHO_*
 

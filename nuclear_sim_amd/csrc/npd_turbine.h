@@ -501,7 +501,7 @@ NPD_FN void npd_turbine_lube(npb_turb_t *t, double dt) {
 /* RotorDynamicsModel.update_state  rotor_dynamics.py:956-1070 (rotor, thermal effects, four bearings, vibration
  * response); returns the hottest bearing metal temperature and the total vibration displacement for the protection */
 NPD_FN void npd_turbine_rotor(npb_turb_t *t, double stage_power_mw, double steam_temperature, double load_demand, double dt,
-                              double *max_bearing_metal_out, double *total_displacement_out) {
+                              double *max_bearing_metal_out, double *total_displacement_out, double *torques_out = nullptr) {
   double applied_torque = stage_power_mw * 1e6 / (2 * NPD_PI * 3600 / 60);
 
   /* ---- RotorDynamicsModel.update_state  rotor_dynamics.py:956-1070 */
@@ -512,6 +512,7 @@ NPD_FN void npd_turbine_rotor(npb_turb_t *t, double stage_power_mw, double steam
   double net_torque = applied_torque - total_friction;
   double angular_acceleration = net_torque / 45000.0;
   double rotor_acceleration = angular_acceleration * 60.0 / (2 * NPD_PI);
+  if (torques_out) { torques_out[0] = total_friction; torques_out[1] = net_torque; torques_out[2] = rotor_acceleration; }   /* state-log diagnostics */
   t->rotor_speed += rotor_acceleration * dt_seconds;
   t->rotor_speed = npd_pymax(0.0, npd_pymin(t->rotor_speed, 3780.0));
   /* calculate_thermal_effects :913-954 */
@@ -621,7 +622,9 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
   NPD_STAMP(15);
   double stage_power_mw = ss.total_power;
   double max_bearing_metal, total_displacement;
-  npd_turbine_rotor(t, stage_power_mw, steam_temperature, load_demand, dt, &max_bearing_metal, &total_displacement);
+  double torques[3];
+  npd_turbine_rotor(t, stage_power_mw, steam_temperature, load_demand, dt, &max_bearing_metal, &total_displacement, st.diag ? torques : nullptr);
+  if (st.diag) { NPD_DIAG(st, NPB_DIAG_ROTOR_FRICTION_TORQUE, torques[0]); NPD_DIAG(st, NPB_DIAG_ROTOR_NET_TORQUE, torques[1]); NPD_DIAG(st, NPB_DIAG_ROTOR_ACCELERATION, torques[2]); }
   /* MetalTemperatureTracker.update_temperatures ran per stage inside the stage pass (npd_stage_post) */
   npd_turbine_protect(t, stage_power_mw, ss.max_thermal_stress, max_bearing_metal, total_displacement, sg_system_availability, condenser_pressure, dt);
   res->electrical_power_gross = t->total_power_output;

@@ -280,6 +280,9 @@ def _all_diagnostic_columns() -> Dict[str, int]:
     base += 4 * len(_lib.DIAG_PUMP_VALUES)
     for v, value in enumerate(_lib.DIAG_FW_VALUES):
         out["secondary.feedwater_SECONDARY-COMP-001-FW.%s" % value] = base + v
+    base += len(_lib.DIAG_FW_VALUES)
+    for v, value in enumerate(_lib.DIAG_ROTOR_VALUES):
+        out["secondary.turbine_SECONDARY-COMP-001-TURB.%s" % value] = base + v
     return out
 
 
