@@ -193,10 +193,13 @@ NPB_API int npb_locate_field(const NpbHandle *h, int kind, int slot, int *column
  * (NaN entries also mean unchanged; replaces heat_source.set_power_setpoint), noise_z -> 0
  * (standard-normal sample that ConstantHeatSource would draw, constant_heat_source.py:178),
  * cooling_water_temp -> unchanged.  Output columns (device) may be NULL:
- * obs [n,22] row-major, reward [n], done [n] u8, trip_flags [n] u32, info [n,10].
- * With params.maint_enabled the automatic-maintenance rule for the feedwater pumps' oil_top_off action runs
- * after the physics, in the reference's order (sim.py:208-223: AutoMaintenanceSystem.update, then the state
- * manager's threshold scan); its state and counters are the maint.* columns of npb_fields.h. */
+ * obs [n,22] row-major, reward [n], done [n] u8, trip_flags [n] u32, info [n,NPB_INFO_DIM] (+ [n,NPB_INFO_NRHO] behind it with
+ * params.info_reactivity_components).  Under NPB_HEAT_EXTERNAL the noise_z / power_setpoint columns carry the caller's heat
+ * source (include/npb_params.h).
+ * With params.maint_enabled the automatic maintenance of the feedwater pumps -- the handle's threshold table (npb_maint.h), the
+ * orchestrator's rule, the work-order queue, the thirteen handlers -- runs after the physics, in the reference's order
+ * (sim.py:208-223: AutoMaintenanceSystem.update, then the state manager's threshold scan), inside the same launch (full mode);
+ * its state and counters are the maint.* / mpump.* columns of npb_fields.h. */
 NPB_API int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const double *power_setpoint,
              const double *noise_z, const double *cooling_water_temp, double *obs, double *reward, uint8_t *done,
              uint32_t *trip_flags, double *info, void *stream);

@@ -36,3 +36,12 @@ def reduce_counters(counters: torch.Tensor, group=None) -> torch.Tensor:
     c = counters.clone()
     dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
     return c
+
+
+def event_histogram(events: torch.Tensor, bins: int = 16, group=None) -> torch.Tensor:
+    """Histogram of a per-plant event count over the WHOLE job (BASELINE config 4's report: how many plants topped off 0, 1, 2 ...
+    times): the local bincount, counts beyond the last bin clamped into it, summed over the ranks when there are several."""
+    hist = torch.bincount(events.to(torch.int64).clamp(min=0, max=bins - 1), minlength=bins)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+    return hist

@@ -3,7 +3,8 @@
 reference's outputs, plus the value of every schema column's reference attribute:
 
   action[T] magnitude[T] setpoint[T] cooling[T] noise_z[T]     per-step inputs
-  obs[T,22] reward[T] done[T] info[T,10]                        per-step outputs
+  obs[T,22] reward[T] done[T] info[T,10]                        per-step outputs (info: the ten scalar keys of step()'s info dict
+                                                                recorded since round 1; sec / rc below hold the rest)
   state_steps[K], state[K,ncol]                                 sampled state trajectory (step 0 = initial)
   labels[ncol], paths[ncol]                                     schema column labels at generation time and the reference
                                                                 attribute path of each column (the stable key tests match on)

@@ -1080,8 +1080,8 @@ def test_other_feedwater_action_scenarios_run_on_the_oracle_track(oracle_lib, ac
     """Other randomised action-test scenarios -- feedwater (pre-degraded seals / oil / bearings, reduced NPSH), steam
     generator (TSP and tube-scale deposits), condenser (air in-leakage): plants
     built from nuclear_sim_amd.scenarios on the GPU and on the oracle from the same columns, 2 h of the runner's loop,
-    every column compared.  (Only the oil_top_off work order is executed on the device; these check the physics from
-    the scenarios' initial conditions.)"""
+    every column compared, the maintenance columns of the feedwater scenarios included (the whole threshold table and
+    all thirteen handlers run on the device; work orders of steam generators and the condenser are outside the path)."""
     from nuclear_sim_amd.env import BatchedPlantEnv
     from nuclear_sim_amd import scenarios
     n, T = 192, 24

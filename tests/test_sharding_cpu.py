@@ -103,3 +103,51 @@ def test_sharded_episode_does_not_depend_on_the_world_size():
     assert np.array_equal(results[1][0], results[2][0])
     assert results[1][1].tolist() == results[2][1].tolist()
     assert results[1][1][1] > 0, "some plants had a maintenance event"
+
+
+def _config4_worker(rank, world, port, n_global, T, q):
+    """One rank of BASELINE config 4's run at test size: ITS seeds' plants from the scenario catalog (seeds = global plant ids),
+    stepped by the CPU oracle standing in for the GPU stepper, then the job-wide histogram of executions per plant."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import npo
+    from nuclear_sim_amd import scenarios
+    from nuclear_sim_amd.sharding import event_histogram
+    lo, hi = shard_range(n_global, rank, world)
+    P = npo.Params(); P.hs_noise_enabled = 1; P.maint_enabled = 1; P.dt = 5.0
+    ora = npo.OraclePlants(hi - lo, P)
+    eff = float(ora.get("pump.lubrication_effectiveness"))
+    for key, v in scenarios.action_test_fields("oil_top_off", list(range(lo, hi)), eff).items():
+        name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
+        ora.set(name, v, instance=inst, k=k)
+    z = np.random.RandomState(42).standard_normal(T)
+    for t in range(T):
+        ora.step(setpoint=np.full(hi - lo, 90.0), noise_z=np.full(hi - lo, z[t]))
+    events = torch.tensor([ora.get("maint.maintenance_actions_performed", plant=i) for i in range(hi - lo)], dtype=torch.int64)
+    hist = event_histogram(events)
+    if rank == 0:
+        q.put(hist.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_histogram_does_not_depend_on_the_world_size():
+    """tools/config4.py's episode-end report: the histogram of oil_top_off executions per plant over all ranks (seeds by global
+    plant id, shards contiguous, one all-reduce).  45 seeds as one rank and as two ragged shards: the same histogram, with
+    plants that top off and plants that never do."""
+    n_global, T = 45, 30
+    ctx = mp.get_context("spawn")
+    hists = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 33500 + (os.getpid() % 2000) + world
+        procs = [ctx.Process(target=_config4_worker, args=(r, world, port, n_global, T, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        hists[world] = q.get(timeout=300)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    assert np.array_equal(hists[1], hists[2])
+    assert hists[1].sum() == n_global and hists[1][0] > 0 and hists[1][1:].sum() > 0

@@ -29,13 +29,20 @@ def main():
     import torch
     import torch.distributed as dist
     from nuclear_sim_amd.env import BatchedPlantEnv
-    from nuclear_sim_amd.sharding import gather_observations, reduce_counters, shard_range
+    from nuclear_sim_amd.sharding import gather_observations, reduce_counters, shard_range, event_histogram
 
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    # rehearsal on a one-GPU box (as bench.py's, tools/bench_rehearsal.sh): every rank on device NPB_BENCH_DEVICE, collectives over gloo
+    if os.environ.get("NPB_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["NPB_BENCH_DEVICE"])
+    backend = os.environ.get("NPB_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     lo, hi = shard_range(args.plants, rank, world)
     n = hi - lo
@@ -59,13 +66,14 @@ def main():
     loop_s = time.perf_counter() - t0
     events = env.get_field("maint.maintenance_actions_performed").to(torch.int64)
     created = env.get_field("maint.work_orders_created").to(torch.int64)
-    hist = torch.bincount(events.clamp(max=15), minlength=16)
+    gloo = world > 1 and backend != "nccl"      # gloo moves host tensors
+    hist = event_histogram(events.cpu() if gloo else events)
     flags = info["trip_flags"]
     counters = torch.stack([(flags & 1).ne(0).sum(), (flags & 0xF00).ne(0).sum(), events.sum(), created.sum()]).to(torch.int64)
     if world > 1:
-        full_obs = gather_observations(obs, args.plants)
-        counters = reduce_counters(counters); dist.all_reduce(hist)
-        el = torch.tensor([loop_s], dtype=torch.float64, device=dev); dist.all_reduce(el, op=dist.ReduceOp.MAX); loop_s = float(el.item())
+        full_obs = gather_observations(obs.cpu() if gloo else obs, args.plants)
+        counters = reduce_counters(counters.cpu() if gloo else counters)
+        el = torch.tensor([loop_s], dtype=torch.float64, device="cpu" if gloo else dev); dist.all_reduce(el, op=dist.ReduceOp.MAX); loop_s = float(el.item())
         assert full_obs.shape == (args.plants, 22)
     if rank == 0:
         h = hist.cpu().numpy()
