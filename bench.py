@@ -120,7 +120,7 @@ def c3_noise(lo, n, total):
     return np.ascontiguousarray(z.T)
 
 
-def step_kernel_name(n, storage="f64", forced=None, mode="full"):
+def step_kernel_name(n, storage="f64", forced=None, mode="full", maintenance=False):
     """which step kernel npb_step launches for n plants -- the selection rule of the launcher (npb_kernels.hip,
     NPB_LAUNCHER(step)) restated, for labels made before anything ran; NPB_STEP_KERNEL / npb_set_step_kernel (`forced`)
     override the choice by batch size.  The JSON line itself names what npb_debug_last_step_kernel reports after the run;
@@ -133,11 +133,12 @@ def step_kernel_name(n, storage="f64", forced=None, mode="full"):
         return "npb_step_primary_kernel"
     if variant == 0:
         variant = 2 if npad <= 57344 else (4 if npad * (8 if storage == "f64" else 4) > 90112 * 8 else 1)
+    m = "_maint" if (maintenance and mode == "full") else ""       # the builds with the automatic maintenance compiled in
     if variant == 4:
-        return "npb_step_nt_kernel"
+        return "npb_step_nt%s_kernel" % m
     if variant in (2, 3) and mode == "full":
-        return "npb_step2_wide_kernel" if (variant == 2 and npad <= 32768) else "npb_step2_kernel"
-    return "npb_step_kernel"
+        return ("npb_step2_wide%s_kernel" if (variant == 2 and npad <= 32768) else "npb_step2%s_kernel") % m
+    return "npb_step%s_kernel" % m
 
 
 def past_the_knee(n, device, storage, bytes_per_plant, K=40):
@@ -299,7 +300,7 @@ def main():
     torch.cuda.synchronize(dev)
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
     launched_kernel = env.last_step_kernel()       # what npb_step launched, asked of the library (npb_debug_last_step_kernel)
-    assert launched_kernel == step_kernel_name(n, args.storage), (launched_kernel, step_kernel_name(n, args.storage))
+    assert launched_kernel == step_kernel_name(n, args.storage, maintenance=args.maintenance), (launched_kernel, step_kernel_name(n, args.storage, maintenance=args.maintenance))
     # self-check: the same loop as the timed region over >= 0.6 s of launches (the driver's --steps 20 is a 2 ms
     # timed region; one scheduling hiccup there is a 10 % error), inputs cycled
     K_long = max(K, int(np.ceil(0.6 / max(elapsed / K, 1e-6))))
@@ -353,7 +354,7 @@ def main():
                                             "(measured writes ~200 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "
                                             "of the reads is served by the 256 MB Infinity Cache; NULL inputs (20 B/plant) are "
                                             "already excluded",
-                         "kernel": launched_kernel + (" (automatic maintenance inside: threshold screen in the pump phase, rule by function call for flagged waves)" if args.maintenance else ""),
+                         "kernel": launched_kernel + (" (the build with the automatic maintenance inside: threshold screen in the pump phase, rule by function call for flagged waves)" if args.maintenance else ""),
                          "kernel_ms": kernel_ms},
             "preconditioning": {"ms": precondition_ms, "what": "a scratch handle of the same size stepped on the same inputs before the %d warm-up "
                                 "steps of the benchmarked one (whose state is not advanced), so that the timed steps run at the GPU's "

@@ -68,7 +68,16 @@ enum {
   /* the rotor model's torque balance of this step (rotor_dynamics.py:855-911): bearing friction torque [N m] from the bearing loads
    * the step began with, net torque, acceleration [RPM/s] */
   NPB_DIAG_ROTOR_FRICTION_TORQUE = 112, NPB_DIAG_ROTOR_NET_TORQUE = 113, NPB_DIAG_ROTOR_ACCELERATION = 114,
-  NPB_DIAG_DIM = 115
+  /* the condenser's step (condenser/physics.py:564-728, 73-145; vacuum_pump.py:96-190): overall heat-transfer coefficient, tube
+   * leak rate, the first ejector's motive steam flow and steam consumption rate, the vacuum system's total motive steam */
+  NPB_DIAG_COND_OVERALL_HTC = 115, NPB_DIAG_COND_TUBE_LEAK_RATE = 116, NPB_DIAG_COND_SJE1_STEAM_FLOW = 117,
+  NPB_DIAG_COND_SJE1_STEAM_CONSUMPTION = 118, NPB_DIAG_COND_VACUUM_STEAM_CONSUMPTION = 119,
+  /* per steam generator: the tube-scale formation rate of the step [mm / year] (tube_interior_fouling.py:117-188) */
+  NPB_DIAG_SG_SCALE_FORMATION_RATE = 120,
+  /* the feedwater system's performance factor (feedwater/physics.py:800-805: mean flow x efficiency factor of the running pumps x
+   * water-quality factor, from the shared chemistry between its two updates of the step, x the diagnostics' health score) */
+  NPB_DIAG_FW_PERFORMANCE_FACTOR = 123,
+  NPB_DIAG_DIM = 124
 };
 /* info["reactivity_components"] (sim.py:205; reactivity_model.py:77-125, pcm, the dict's insertion order).  Only the
  * reactor heat source has them, and only a caller that sets params.info_reactivity_components gets them: the info
@@ -228,6 +237,8 @@ enum {
   NPB_KERNEL_STEP_NT = 4,      /* npb_step_nt_kernel: one wavefront, streaming state stores */
   NPB_KERNEL_STEP_DIAG = 5,    /* npb_step_diag_kernel: one wavefront, step-internal diagnostics written (npb_set_diagnostics) */
   NPB_KERNEL_STEP_PRIMARY = 6, /* npb_step_primary_kernel: NPB_MODE_PRIMARY */
+  /* the builds of 1-4 with the automatic maintenance compiled in (params.maint_enabled, full mode): same step, same results */
+  NPB_KERNEL_STEP_MAINT = 7, NPB_KERNEL_STEP2_WIDE_MAINT = 8, NPB_KERNEL_STEP2_MAINT = 9, NPB_KERNEL_STEP_NT_MAINT = 10,
   NPB_KERNEL_COUNT_
 };
 NPB_API int npb_debug_last_step_kernel(const NpbHandle *h);

@@ -26,7 +26,14 @@ DIAG_SG_VALUES = ("primary_inlet_temp", "primary_outlet_temp", "overall_htc", "f
 DIAG_PUMP_VALUES = ("system_health_factor", "maintenance_action_occurred", "oil_top_off_occurred")   # per pump, FWP-1..4 (NPB_DIAG_PUMP_*)
 DIAG_FW_VALUES = ("feedwater_avg_sg_level", "feedwater_avg_sg_pressure", "feedwater_total_steam_flow", "feedwater_avg_steam_quality")   # NPB_DIAG_FW_*
 DIAG_ROTOR_VALUES = ("friction_torque", "net_torque", "rotor_acceleration")   # NPB_DIAG_ROTOR_*
-DIAG_DIM = 14 * len(DIAG_STAGE_VALUES) + 3 * len(DIAG_SG_VALUES) + 4 * len(DIAG_PUMP_VALUES) + len(DIAG_FW_VALUES) + len(DIAG_ROTOR_VALUES)
+# NPB_DIAG_COND_*, NPB_DIAG_SG_SCALE_FORMATION_RATE (x3), NPB_DIAG_FW_PERFORMANCE_FACTOR: (log column, row offset behind the rotor's)
+DIAG_TAIL_COLUMNS = (("secondary.condenser_SECONDARY-COMP-001-COND.condenser_overall_htc", 0), ("secondary.condenser_SECONDARY-COMP-001-COND.tube_leak_rate", 1),
+                     ("secondary.condenser.SJE-001_steam_flow", 2), ("secondary.condenser.SJE-001_steam_consumption", 3),
+                     ("secondary.condenser.vacuum_system_steam_consumption", 4),
+                     ("secondary.steam_generator_SG-0.tube_scale_formation_rate_mm_per_year", 5), ("secondary.steam_generator_SG-1.tube_scale_formation_rate_mm_per_year", 6),
+                     ("secondary.steam_generator_SG-2.tube_scale_formation_rate_mm_per_year", 7),
+                     ("secondary.feedwater_SECONDARY-COMP-001-FW.feedwater_performance_factor", 8))
+DIAG_DIM = 14 * len(DIAG_STAGE_VALUES) + 3 * len(DIAG_SG_VALUES) + 4 * len(DIAG_PUMP_VALUES) + len(DIAG_FW_VALUES) + len(DIAG_ROTOR_VALUES) + len(DIAG_TAIL_COLUMNS)
 REACTIVITY_COMPONENTS = ("control_rods", "boron", "doppler", "moderator_temp", "moderator_void", "pressure", "xenon", "samarium",
                          "fuel_depletion", "burnable_poisons")   # reactivity_model.py:87-121, NPB_RHO_*
 

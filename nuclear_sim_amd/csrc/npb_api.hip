@@ -267,7 +267,8 @@ int npb_set_step_kernel(NpbHandle *h, int variant) {
 int npb_debug_last_step_kernel(const NpbHandle *h) { return h ? h->last_kernel : NPB_KERNEL_NONE; }
 const char *npb_step_kernel_name(int id) {
   static const char *const names[NPB_KERNEL_COUNT_] = {"", "npb_step_kernel", "npb_step2_wide_kernel", "npb_step2_kernel", "npb_step_nt_kernel",
-                                                       "npb_step_diag_kernel", "npb_step_primary_kernel"};
+                                                       "npb_step_diag_kernel", "npb_step_primary_kernel", "npb_step_maint_kernel", "npb_step2_wide_maint_kernel",
+                                                       "npb_step2_maint_kernel", "npb_step_nt_maint_kernel"};
   return id >= 0 && id < NPB_KERNEL_COUNT_ ? names[id] : nullptr;
 }
 

@@ -523,7 +523,14 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(const npd_maint_rul
 
 #define NPD_SM 1          /* store mode of the kernels below (npd_store_real): the one-wave kernel's own 8-byte stores ... */
 #define NPD_STEP1_KERNEL npb_step_kernel
+#define NPD_STEP1_MAINT 0
 #define NPD_STEP1_WHO 1
+#include "npd_step1.h"
+#undef NPD_STEP1_KERNEL
+#undef NPD_STEP1_MAINT
+/* the same with the automatic maintenance compiled in (what npb_step launches when params.maint_enabled) */
+#define NPD_STEP1_KERNEL npb_step_maint_kernel
+#define NPD_STEP1_MAINT 1
 #include "npd_step1.h"
 #undef NPD_STEP1_KERNEL
 /* the same step with the step-internal diagnostics written (npb_set_diagnostics): for state logging, not for throughput */
@@ -534,16 +541,24 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(const npd_maint_rul
 #include "npd_step1.h"
 #undef NPD_STEP1_DIAG
 #undef NPD_STEP1_KERNEL
+#undef NPD_STEP1_MAINT
 /* ... with the non-temporal bit in this one, for batches whose sweep is far past the 256 MB Infinity Cache: nothing a step writes is still
  * cached when the next step reads it, and stores that do not allocate leave the caches to the loads (131 072 plants: 0.218 ->
  * 0.196 ms; at 65 536, where a tenth of the arena still hits, they cost 4 %: profiles/r2_ab_streaming_state_stores.txt) */
 #undef NPD_SM
 #define NPD_SM 2
 #define NPD_STEP1_KERNEL npb_step_nt_kernel
+#define NPD_STEP1_MAINT 0
 #undef NPD_STEP1_WHO
 #define NPD_STEP1_WHO 3
 #include "npd_step1.h"
 #undef NPD_STEP1_KERNEL
+#undef NPD_STEP1_MAINT
+#define NPD_STEP1_KERNEL npb_step_nt_maint_kernel
+#define NPD_STEP1_MAINT 1
+#include "npd_step1.h"
+#undef NPD_STEP1_KERNEL
+#undef NPD_STEP1_MAINT
 #undef NPD_SM
 #define NPD_SM 0          /* ... and the two-wave kernels leave theirs to the compiler */
 
@@ -773,26 +788,27 @@ extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t np
     return NPB_KERNEL_STEP_PRIMARY;
   }
   if (variant == 0) variant = npad <= 57344 ? 2 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1);
+  const bool with_maint = maint_rc != nullptr;     /* the builds with the automatic maintenance compiled in */
   if (variant == 4) {
-    hipLaunchKernelGGL(npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
+    hipLaunchKernelGGL(with_maint ? npb_step_nt_maint_kernel : npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
-    return NPB_KERNEL_STEP_NT;
+    return with_maint ? NPB_KERNEL_STEP_NT_MAINT : NPB_KERNEL_STEP_NT;
   }
   const bool two_wave = (variant == 2 || variant == 3) && P->mode == NPB_MODE_FULL;
   const bool wide = two_wave && variant == 2 && npad <= 32768;   /* the whole register file while one wave per SIMD is all there is; variant 3 = never */
   if (wide) {
-    hipLaunchKernelGGL(npb_step2_wide_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
+    hipLaunchKernelGGL(with_maint ? npb_step2_wide_maint_kernel : npb_step2_wide_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
                        setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
-    return NPB_KERNEL_STEP2_WIDE;
+    return with_maint ? NPB_KERNEL_STEP2_WIDE_MAINT : NPB_KERNEL_STEP2_WIDE;
   }
   if (two_wave) {
-    hipLaunchKernelGGL(npb_step2_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
+    hipLaunchKernelGGL(with_maint ? npb_step2_maint_kernel : npb_step2_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
                        setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
-    return NPB_KERNEL_STEP2;
+    return with_maint ? NPB_KERNEL_STEP2_MAINT : NPB_KERNEL_STEP2;
   }
-  hipLaunchKernelGGL(npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
+  hipLaunchKernelGGL(with_maint ? npb_step_maint_kernel : npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                      noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
-  return NPB_KERNEL_STEP;
+  return with_maint ? NPB_KERNEL_STEP_MAINT : NPB_KERNEL_STEP;
 }
 /* the rule as a launch of its own (modes that do not step the pumps) */
 extern "C" void NPB_LAUNCHER(maint)(size_t npad, void *arena, void *maint_side, int32_t *counts, int n_plants, hipStream_t stream) {

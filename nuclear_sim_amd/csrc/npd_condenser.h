@@ -42,7 +42,9 @@ typedef struct npd_condenser_result_t {
 NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_pressure, double steam_flow,
                                  double steam_quality, double cooling_water_flow, double cooling_water_temp_in,
                                  double motive_steam_pressure, double motive_steam_temperature, double dt,
-                                 npd_condenser_result_t *res) {
+                                 npd_condenser_result_t *res, double *diag = nullptr) {
+  /* diag (state-log diagnostics, NPB_DIAG_COND_*): [0] overall heat-transfer coefficient, [1] tube leak rate, [2] the first
+   * ejector's motive steam flow, [3] its steam consumption rate, [4] the vacuum system's total motive steam */
   /* own WaterChemistry (:769-800) */
   npd_chem_update(chem, dt);
   double water_aggressiveness = chem->water_aggressiveness;
@@ -66,6 +68,7 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
   double tubes_failed = effective_failure_rate * cd->active_tube_count * dt;
   tubes_failed = npd_pymin(tubes_failed, cd->active_tube_count * 0.01);
   cd->plugged_tube_count += tubes_failed;
+  if (diag) diag[1] = npd_pymin(tubes_failed * 0.1, npd_pymax(1000.0, 84000.0 - cd->plugged_tube_count) * 0.001) * 0.001;   /* physics.py:121-131 (the new active tube count) */
   cd->active_tube_count = npd_pymax(1000.0, initial_tube_count - cd->plugged_tube_count);
   double area_factor = cd->active_tube_count / initial_tube_count;
   double pressure_drop_factor = npd_powc(initial_tube_count / cd->active_tube_count, 1.8);
@@ -141,6 +144,7 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
   }
   int n_running = ((cd->ej_operating_mask >> 0) & 1) + ((cd->ej_operating_mask >> 1) & 1);
   double total_capacity = 0.0;
+  if (diag) { diag[2] = 0.0; diag[3] = 0.0; diag[4] = 0.0; }
   for (int e = 0; e < 2; e++) { /* SteamJetEjector.update_state vacuum_pump.py:470-536 */
     int operating = (cd->ej_operating_mask >> e) & 1;
     double capacity = 0.0;
@@ -158,6 +162,12 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
         double suction_capacity_factor = 1.0 / (1.0 + 0.5 * (suction_pressure_ratio - 1.0));
         double available_capacity = (25.0 * pressure_capacity_factor * temp_capacity_factor * suction_capacity_factor * overall);
         capacity = npd_pymax(0.0, npd_pymin(available_capacity, request));
+        if (diag && capacity > 0) {   /* the ejector's steam consumption, vacuum_pump.py:150-166 (2.5 kg/kg at design, exponents 0.8 / 1.5) */
+          double capacity_factor = capacity / 25.0;
+          double rate = (2.5 * npd_exp(0.8 * npd_log(capacity_factor))) * (suction_pressure_ratio * npd_sqrt(suction_pressure_ratio)) * (1.0 / npd_pymax(0.5, overall));
+          if (e == 0) { diag[2] = capacity * rate; diag[3] = rate; }
+          diag[4] += capacity * rate;
+        }
       }
       /* update_degradation :246-275 */
       cd->ej_nozzle_fouling[e] = npd_pymax(0.5, cd->ej_nozzle_fouling[e] - 1e-05 * dt);
@@ -211,6 +221,7 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
   double r_wall = 0.00159 / 385.0;
   double r_water = 1.0 / h_water;
   double overall_htc = 1.0 / (r_steam + cd->total_fouling_resistance + r_wall + r_water);
+  if (diag) diag[0] = overall_htc;
   double effective_area = (75000.0 * area_factor);
   double theoretical_heat_transfer = overall_htc * effective_area * lmtd;
   double heat_transfer_rate = npd_pymin(heat_available_watts, theoretical_heat_transfer);

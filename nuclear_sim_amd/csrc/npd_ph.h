@@ -80,9 +80,10 @@ NPD_FN void npd_ph_update(npb_ph_t *s, double current_ph, double dt) {
 /* the whole sidecar for one step: update #1 happens inside the feedwater system (with the effects left
  * pending by the previous step), update #2 and the controller after the condenser; nothing else reads
  * this state, so they are run back to back */
-NPD_FN void npd_chemistry_sidecar(npb_chem_t *c, npb_ph_t *ph, double dt) {
+NPD_FN void npd_chemistry_sidecar(npb_chem_t *c, npb_ph_t *ph, double dt, double *aggressiveness_in_feedwater = nullptr) {
   npd_chem_apply_pending(c, ph);
   npd_chem_update(c, dt);   /* feedwater/physics.py:708 */
+  if (aggressiveness_in_feedwater) *aggressiveness_in_feedwater = c->water_aggressiveness;   /* what the feedwater system's performance factor sees (state-log diagnostics) */
   npd_chem_update(c, dt);   /* secondary/__init__.py:644 */
   npd_ph_update(ph, c->ph, dt); /* :647-650, dt taken as hours */
 }

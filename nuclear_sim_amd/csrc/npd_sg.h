@@ -150,6 +150,21 @@ NPD_FN double npd_scale_thermal_resistance(const npb_sg_t *g) {
 /* TubeInteriorFouling.update_fouling_state  tube_interior_fouling.py:273-325
  * (+ calculate_scale_formation_rate :117-188, update_scale_buildup :245-271).
  * Primary chemistry passed by SteamGenerator.update_state :721-730 is constant. */
+/* calculate_scale_formation_rate :117-188 [mm / year], from the scale thickness the step begins with */
+NPD_FN double npd_scale_formation_rate(const npb_sg_t *g, double temperature, double flow_velocity) {
+  const double boric_acid = 1000.0, lithium = 2.0, ph = 7.2, dissolved_oxygen = 0.005;
+  double temp_kelvin = temperature + 273.15, ref_kelvin = 320.0 + 273.15;
+  double temp_factor = npd_exp_bounded(-65000.0 / (8.314 * temp_kelvin)) / npd_exp(-65000.0 / (8.314 * ref_kelvin));
+  double boric_acid_factor = 1.0 / (1.0 + boric_acid / 1000.0 * 0.5);
+  double lithium_factor = npd_pymax(0.5, 1.0 + (lithium - 2.0) * 0.1);
+  double ph_factor = 1.0 + 0.5 * fabs(ph - 7.2);
+  double velocity_factor = npd_clip(npd_powc(flow_velocity / 5.0, -0.6), 0.5, 2.0);
+  double oxygen_factor = 1.0 + dissolved_oxygen * 10.0;
+  double saturation_factor = npd_exp_bounded(-g->scale_thickness / 2.0);
+  double formation_rate = 0.001 * temp_factor * boric_acid_factor * lithium_factor * ph_factor *
+                          velocity_factor * oxygen_factor * saturation_factor;
+  return npd_clip(formation_rate, 0.0, 0.1);
+}
 NPD_FN void npd_scale_update(npb_sg_t *g, double temperature, double flow_velocity, double dt_seconds) {
   g->scale_operating_years += dt_seconds / (365.25 * 24.0 * 3600.0);
   const double boric_acid = 1000.0, lithium = 2.0, ph = 7.2, dissolved_oxygen = 0.005;

@@ -1,4 +1,6 @@
-/* The one-wave step kernel: one step of the 64 plants of this wave.  Included twice by npb_kernels.hip: as npb_step_kernel, and as
+/* The one-wave step kernel: one step of the 64 plants of this wave.  Included several times by npb_kernels.hip: as npb_step_kernel
+ * (and npb_step_nt_kernel, the streaming-store build), each also with the automatic maintenance compiled in (NPD_STEP1_MAINT:
+ * npb_step_maint_kernel, npb_step_nt_maint_kernel), and as
  * its diagnostics build npb_step_diag_kernel (NPD_STEP1_DIAG: two more arguments, and the NPB_DIAG_* columns are written as the
  * values come up -- in the plain build st.diag stays the NULL npd_stage_init left and every such store folds away). */
 __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
@@ -35,7 +37,10 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
   /* automatic maintenance on (npd_maintenance.h, "the threshold screen inside the step kernels"): lane l fetches entry l of the
    * folded threshold table from the kernel-argument segment; it goes to the last 512 B of the staging region -- no staged
    * section reaches that far -- once the first staged group has landed, and the pump phase reads it from there */
-  const bool maint = P.maint_enabled && maint_rc != nullptr && full;
+  /* NPD_STEP1_MAINT: this build carries the maintenance path (npb_step launches it when params.maint_enabled); the plain builds
+   * fold all of it away -- compiled in, even switched off it cost the step 1-3 % (a call makes the kernel a non-leaf: stack
+   * set-up, fewer scalar registers; profiles/r3_ab_r2_vs_maintenance_capable_kernels.txt) */
+  const bool maint = NPD_STEP1_MAINT && P.maint_enabled && maint_rc != nullptr && full;
   unsigned maint_hit_bits = 0, maint_due_with_orders = 0;     /* wave-uniform: what the screen found (npd_maintenance.h) */
   double *const maint_tab = lds + (NPB_STAGE_BYTES - 512) / 8;
   static_assert(NPD_MH_N <= 64 && (size_t)NPD_SLOTS(TSTG) * NPD_SLOTB <= NPB_STAGE_BYTES - 512, "room for the threshold table behind the largest staged group");
@@ -146,7 +151,8 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
   NPD_DIAG(st, NPB_DIAG_FW_AVG_SG_LEVEL, (0.0 + prev_levels[0] + prev_levels[1] + prev_levels[2]) / 3);
   NPD_DIAG(st, NPB_DIAG_FW_TOTAL_STEAM_FLOW, 0.0 + prev_flows[0] + prev_flows[1] + prev_flows[2]);
   NPD_DIAG(st, NPB_DIAG_FW_AVG_STEAM_QUALITY, (0.0 + prev_quals[0] + prev_quals[1] + prev_quals[2]) / 3);
-  double diag_prev_pressure_sum = 0.0;
+  double diag_prev_pressure_sum = 0.0, diag_perf_sum = 0.0, diag_health = 1.0;
+  int diag_perf_n = 0;
 #endif
   double fw_total_flow = 0.0, fw_total_power = 0.0;
   int fw_available = 1;
@@ -195,6 +201,10 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
 #pragma unroll
         for (int q = 0; q < 6; q++) sum += npd_pymax(0.1, 1.0 - (wear[q] * wpf[q] + (1.0 - pm.lubrication_effectiveness) * lpf[q]));
         NPD_DIAG(st, NPB_DIAG_PUMP_HEALTH_FACTOR + i, sum / 6 * pm.lubrication_effectiveness);
+        if (pm.status == NPD_PUMP_RUNNING) {   /* pump_system.py:1304-1316 */
+          diag_perf_sum += npd_pymax(0.5, 1.0 - pm.flow_degradation / 100.0) * npd_pymax(0.5, 1.0 - pm.efficiency_degradation / 100.0);
+          diag_perf_n += 1;
+        }
         NPD_DIAG(st, NPB_DIAG_PUMP_MAINTENANCE_OCCURRED + i, 0.0); NPD_DIAG(st, NPB_DIAG_PUMP_OIL_TOP_OFF_OCCURRED + i, 0.0);   /* the rule sets them */
       }
 #endif
@@ -213,6 +223,9 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     NPD_STAMP(6);
     npd_fw_result_t fwr;
     npd_fw_finish(&fw, &acc, prev_levels, dt, &fwr);
+#ifdef NPD_STEP1_DIAG
+    diag_health = fw.overall_health_score;
+#endif
     fw_total_flow = fwr.total_flow_rate; fw_total_power = fwr.total_power_consumption;
     fw_available = fwr.system_availability;
     trip_flags |= (fwr.pump_trip_mask << 8) | (fw.system_trip_active ? NPB_TRIP_FW_SYSTEM : 0);
@@ -266,6 +279,8 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
        * expression, :170-215 -> :289), and below the feedwater flow the fouled TSPs let through (:761 with :516-547) */
       diag_prev_pressure_sum += has_prev ? g.secondary_pressure : 6.895;      /* secondary/__init__.py:447-453 */
       if (i == NPB_NUM_SG - 1) NPD_DIAG(st, NPB_DIAG_FW_AVG_SG_PRESSURE, diag_prev_pressure_sum / 3);
+      NPD_DIAG(st, NPB_DIAG_SG_SCALE_FORMATION_RATE + i,
+               npd_scale_formation_rate(&g, (c_inlet + c_outlet) / 2.0, c_flow / (1000.0 * (P.sg_tube_count * (NPD_PI * npd_sq(P.sg_tube_inner_diameter / 2.0))))));
       NPD_DIAG(st, NPB_DIAG_SG_PRIMARY_INLET_TEMP + i, c_inlet); NPD_DIAG(st, NPB_DIAG_SG_PRIMARY_OUTLET_TEMP + i, c_outlet);
       {
         double flow_factor = npd_powc(c_flow / P.sg_primary_design_flow, 0.8);
@@ -344,15 +359,29 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     npd_condenser_result_t cr;
     {
       NPD_ST_STORE_ELIDE(TURB, npb_turb_t, t, t_old, 0);
+#ifdef NPD_STEP1_DIAG
+      double cond_diag[5];
+      npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
+                           cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr, cond_diag);
+#pragma unroll
+      for (int q = 0; q < 5; q++) NPD_DIAG(st, NPB_DIAG_COND_OVERALL_HTC + q, cond_diag[q]);
+#else
       npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
                            cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr);
+#endif
       NPD_ST_STORE_ELIDE(COND, npb_cond_t, cd, cd_old, 0);
       NPD_ST_STORE_ELIDE(CHEM, npb_chem_t, ch, ch_old, 1);
     }
     condenser_pressure = cr.condenser_pressure;
     NPD_STAMP(19);
     /* ================= chemistry sidecar: shared WaterChemistry + pH controller (:634-665) ========= */
+#ifdef NPD_STEP1_DIAG
+    double diag_aggressiveness;
+    npd_chemistry_sidecar(&ch0, &ph, dt, &diag_aggressiveness);
+    NPD_DIAG(st, NPB_DIAG_FW_PERFORMANCE_FACTOR, (diag_perf_n > 0 ? diag_perf_sum / diag_perf_n : 0.0) * (1.0 - diag_aggressiveness * 0.1) * diag_health);
+#else
     npd_chemistry_sidecar(&ch0, &ph, dt);
+#endif
     NPD_ST_STORE_ELIDE(CHEM, npb_chem_t, ch0, ch0_old, 0);
     NPD_ST_STORE_ELIDE(PH, npb_ph_t, ph, ph_old, 0);
     NPD_STAMP(20);

@@ -294,7 +294,8 @@ __device__ __forceinline__ void npd2_stage_post(const npd_stage_t &st, const npd
 }
 
 /* the body of both two-wave kernels (below): same code, compiled once per register budget */
-template <int WHO>
+/* MAINT: with the automatic maintenance compiled in (see npd_step1.h, NPD_STEP1_MAINT) */
+template <int WHO, bool MAINT>
 __device__ __forceinline__ void npd_step2_body(
     const npb_params_t &P, int n_plants, size_t N, npd_real_t *__restrict__ f64,
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
@@ -321,7 +322,7 @@ __device__ __forceinline__ void npd_step2_body(
   /* automatic maintenance on: the folded threshold table (npd_maintenance.h, "the threshold screen inside the step kernels")
    * goes to exchange slot X_MAINT_TAB, which nothing else uses, written by wave A before barrier #1 and read by both waves'
    * pump phases behind it */
-  const bool maint = P.maint_enabled && maint_rc != nullptr;
+  const bool maint = MAINT && P.maint_enabled && maint_rc != nullptr;
   unsigned maint_hit_bits = 0, maint_due_with_orders = 0;     /* wave-uniform: what this wave's part of the screen found */
   double *const maint_tab = xch + X_MAINT_TAB * NPB_WAVE;
   NPD2_STAMP(0);
@@ -910,9 +911,11 @@ __device__ __forceinline__ void npd_step2_body(
     uint32_t *__restrict__ trip_out, double *__restrict__ info_out, npd_maint_hot_t MH, const npd_maint_rule_consts_t *maint_rc, npd_maint_cache_t MC
 #define NPD2_KERNEL_PASS P, n_plants, N, f64, action, magnitude, setpoint, noise_z, cw_temp, obs_out, reward_out, done_out, trip_out, info_out, MH, maint_rc, MC
 /* two waves per SIMD (256 registers each, part of the state spilled): for batches between one and two waves per SIMD */
-__global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(NPD2_KERNEL_ARGS) { npd_step2_body<4>(NPD2_KERNEL_PASS); }
+__global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_kernel(NPD2_KERNEL_ARGS) { npd_step2_body<4, false>(NPD2_KERNEL_PASS); }
+__global__ __launch_bounds__(NPD2_THREADS) NPD2_OCCUPANCY void npb_step2_maint_kernel(NPD2_KERNEL_ARGS) { npd_step2_body<4, true>(NPD2_KERNEL_PASS); }
 /* one wave per SIMD and the whole register file: up to 32 768 plants (1 024 waves) nothing is gained by leaving room for a
  * second wave, and the spill code goes away */
-__global__ __launch_bounds__(NPD2_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void npb_step2_wide_kernel(NPD2_KERNEL_ARGS) { npd_step2_body<5>(NPD2_KERNEL_PASS); }
+__global__ __launch_bounds__(NPD2_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void npb_step2_wide_kernel(NPD2_KERNEL_ARGS) { npd_step2_body<5, false>(NPD2_KERNEL_PASS); }
+__global__ __launch_bounds__(NPD2_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void npb_step2_wide_maint_kernel(NPD2_KERNEL_ARGS) { npd_step2_body<5, true>(NPD2_KERNEL_PASS); }
 
 #endif

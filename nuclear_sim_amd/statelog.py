@@ -172,6 +172,11 @@ def derived_log_columns() -> Dict[str, tuple]:
         return tot / 5 * eff
     out["secondary.turbine_TB-LUB-001.system_health_factor"] = (("turb.lub_effectiveness",) + tuple("turb.lub_wear[%d]" % k for k in range(5)), tb_health)
     out["secondary.condenser_SECONDARY-COMP-001-COND.condensate_flow"] = (("sec.total_steam_flow",), lambda q: q - 250.0)   # the main steam less the extraction flows
+    # feedwater/physics.py:789-798: hydraulic power (flow x (design pressure 8.0 - suction 0.5 MPa) ...) over the pumps' power
+    out[F + "feedwater_system_efficiency"] = (("fw.total_flow_rate", "fw.total_power_consumption"),
+                                              lambda q, pw: np.where(pw > 0, (q * (8.0 - 0.5) * 1e6 * 1000 * 9.81) / 1e6 / np.where(pw > 0, pw, 1.0), 0.0))
+    # tube_interior_fouling.py:268-271: each generator's tube-side fouling fraction from its scale resistance
+    out[S + "system_avg_tube_fouling_fraction"] = (three("scale_thermal_resistance"), lambda a, b, c: (0 + np.minimum(a / 0.001, 1.0) + np.minimum(b / 0.001, 1.0) + np.minimum(c / 0.001, 1.0)) / 3)
     # the shared WaterChemistry's composite indices, recomputed from its concentrations (water_chemistry.py:277-320; iron 0.1 ppm,
     # silica 20 ppm, alkalinity 120 mg/L and the concentration factor 5 never change), logged once under its own name and once
     # more in the feedwater system's state dict
@@ -283,6 +288,9 @@ def _all_diagnostic_columns() -> Dict[str, int]:
     base += len(_lib.DIAG_FW_VALUES)
     for v, value in enumerate(_lib.DIAG_ROTOR_VALUES):
         out["secondary.turbine_SECONDARY-COMP-001-TURB.%s" % value] = base + v
+    base += len(_lib.DIAG_ROTOR_VALUES)
+    for name, off in _lib.DIAG_TAIL_COLUMNS:
+        out[name] = base + off
     return out
 
 
