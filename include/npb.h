@@ -77,7 +77,11 @@ enum {
   /* the feedwater system's performance factor (feedwater/physics.py:800-805: mean flow x efficiency factor of the running pumps x
    * water-quality factor, from the shared chemistry between its two updates of the step, x the diagnostics' health score) */
   NPB_DIAG_FW_PERFORMANCE_FACTOR = 123,
-  NPB_DIAG_DIM = 124
+  /* accumulators of the rotor model that no physics reads, summed in the caller's buffer from the step the diagnostics were
+   * switched on (zero the buffer at construction and they are the reference's): the four bearings' clearance increase [mm]
+   * (rotor_dynamics.py:298-300) and the overspeed event count (:900-902) */
+  NPB_DIAG_ROTOR_CLEARANCE_INCREASE = 124, NPB_DIAG_ROTOR_OVERSPEED_EVENTS = 128,
+  NPB_DIAG_DIM = 129
 };
 /* info["reactivity_components"] (sim.py:205; reactivity_model.py:77-125, pcm, the dict's insertion order).  Only the
  * reactor heat source has them, and only a caller that sets params.info_reactivity_components gets them: the info

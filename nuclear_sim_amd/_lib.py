@@ -32,7 +32,11 @@ DIAG_TAIL_COLUMNS = (("secondary.condenser_SECONDARY-COMP-001-COND.condenser_ove
                      ("secondary.condenser.vacuum_system_steam_consumption", 4),
                      ("secondary.steam_generator_SG-0.tube_scale_formation_rate_mm_per_year", 5), ("secondary.steam_generator_SG-1.tube_scale_formation_rate_mm_per_year", 6),
                      ("secondary.steam_generator_SG-2.tube_scale_formation_rate_mm_per_year", 7),
-                     ("secondary.feedwater_SECONDARY-COMP-001-FW.feedwater_performance_factor", 8))
+                     ("secondary.feedwater_SECONDARY-COMP-001-FW.feedwater_performance_factor", 8),
+                     # accumulators (NPB_DIAG_ROTOR_CLEARANCE_INCREASE x4, NPB_DIAG_ROTOR_OVERSPEED_EVENTS): since the diagnostics were switched on
+                     ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-001_clearance_increase", 9), ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-002_clearance_increase", 10),
+                     ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-003_clearance_increase", 11), ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-004_clearance_increase", 12),
+                     ("secondary.turbine_SECONDARY-COMP-001-TURB.overspeed_events", 13))
 DIAG_DIM = 14 * len(DIAG_STAGE_VALUES) + 3 * len(DIAG_SG_VALUES) + 4 * len(DIAG_PUMP_VALUES) + len(DIAG_FW_VALUES) + len(DIAG_ROTOR_VALUES) + len(DIAG_TAIL_COLUMNS)
 REACTIVITY_COMPONENTS = ("control_rods", "boron", "doppler", "moderator_temp", "moderator_void", "pressure", "xenon", "samarium",
                          "fuel_depletion", "burnable_poisons")   # reactivity_model.py:87-121, NPB_RHO_*

@@ -515,6 +515,7 @@ NPD_FN void npd_turbine_rotor(npb_turb_t *t, double stage_power_mw, double steam
   if (torques_out) { torques_out[0] = total_friction; torques_out[1] = net_torque; torques_out[2] = rotor_acceleration; }   /* state-log diagnostics */
   t->rotor_speed += rotor_acceleration * dt_seconds;
   t->rotor_speed = npd_pymax(0.0, npd_pymin(t->rotor_speed, 3780.0));
+  if (torques_out) torques_out[7] = (t->rotor_speed > 3780.0 * 0.99) ? 1.0 : 0.0;     /* an overspeed event, :900-902 */
   /* calculate_thermal_effects :913-954 */
   double temp_change = (steam_temperature - t->rotor_temperature) / 2.0 * dt;
   t->rotor_temperature += temp_change;
@@ -559,6 +560,7 @@ NPD_FN void npd_turbine_rotor(npb_turb_t *t, double stage_power_mw, double steam
     double load_wear_rate = 0.00001 * npd_sq(lf) * dt;
     double contamination_wear_rate = 0.000005 * 5.0 * dt;
     t->bearing_wear_factor[i] = npd_pymax(0.5, t->bearing_wear_factor[i] - (load_wear_rate + contamination_wear_rate));
+    if (torques_out) torques_out[3 + i] = (load_wear_rate + contamination_wear_rate) * 0.01;     /* this step's clearance increase [mm], rotor_dynamics.py:298-300 */
     max_bearing_metal = npd_pymax(max_bearing_metal, t->bearing_metal_temp[i]);
   }
   /* VibrationMonitor.calculate_vibration_response :624-704 */
@@ -622,9 +624,15 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
   NPD_STAMP(15);
   double stage_power_mw = ss.total_power;
   double max_bearing_metal, total_displacement;
-  double torques[3];
+  double torques[8];
   npd_turbine_rotor(t, stage_power_mw, steam_temperature, load_demand, dt, &max_bearing_metal, &total_displacement, st.diag ? torques : nullptr);
-  if (st.diag) { NPD_DIAG(st, NPB_DIAG_ROTOR_FRICTION_TORQUE, torques[0]); NPD_DIAG(st, NPB_DIAG_ROTOR_NET_TORQUE, torques[1]); NPD_DIAG(st, NPB_DIAG_ROTOR_ACCELERATION, torques[2]); }
+  if (st.diag) {
+    NPD_DIAG(st, NPB_DIAG_ROTOR_FRICTION_TORQUE, torques[0]); NPD_DIAG(st, NPB_DIAG_ROTOR_NET_TORQUE, torques[1]); NPD_DIAG(st, NPB_DIAG_ROTOR_ACCELERATION, torques[2]);
+    /* accumulators the reference carries and nothing in the physics reads: summed in the caller's buffer, i.e. since the
+     * diagnostics were switched on (from a zeroed buffer at construction they are the reference's) */
+#pragma unroll
+    for (int q = 0; q < 5; q++) st.diag[(size_t)(NPB_DIAG_ROTOR_CLEARANCE_INCREASE + q) * st.diag_pitch] += torques[3 + q];
+  }
   /* MetalTemperatureTracker.update_temperatures ran per stage inside the stage pass (npd_stage_post) */
   npd_turbine_protect(t, stage_power_mw, ss.max_thermal_stress, max_bearing_metal, total_displacement, sg_system_availability, condenser_pressure, dt);
   res->electrical_power_gross = t->total_power_output;

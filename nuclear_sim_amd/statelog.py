@@ -172,6 +172,15 @@ def derived_log_columns() -> Dict[str, tuple]:
         return tot / 5 * eff
     out["secondary.turbine_TB-LUB-001.system_health_factor"] = (("turb.lub_effectiveness",) + tuple("turb.lub_wear[%d]" % k for k in range(5)), tb_health)
     out["secondary.condenser_SECONDARY-COMP-001-COND.condensate_flow"] = (("sec.total_steam_flow",), lambda q: q - 250.0)   # the main steam less the extraction flows
+    # enhanced_physics.py:815-821 with the property fits :1285-1310: steam enthalpy at the header's conditions x steam rate
+    def header_enthalpy(p_mpa, temp_c):
+        pb = np.clip(p_mpa * 10.0, 0.01, 100.0)
+        ts = np.where(p_mpa <= 0.001, 10.0, np.clip(1730.63 / (8.07131 - np.log10(pb)) - 233.426, 10.0, 374.0))
+        h_g = 4.18 * ts + 2257.0 * (1.0 - ts / 374.0) ** 0.38
+        return np.where(temp_c <= ts, h_g, h_g + 2.1 * (temp_c - ts))
+    out["secondary.turbine_SECONDARY-COMP-001-TURB.enhanced_turbine_heat_rate"] = (
+        ("sec.sg_avg_pressure", "sec.sg_avg_temperature", "turb.total_power_output", "sec.total_steam_flow"),
+        lambda p_, t_, pw, q: np.where(pw > 0, header_enthalpy(p_, t_) * (q / np.where(pw > 0, pw * 1000, 1.0) * 3600) / 1000, 0.0))
     # feedwater/physics.py:789-798: hydraulic power (flow x (design pressure 8.0 - suction 0.5 MPa) ...) over the pumps' power
     out[F + "feedwater_system_efficiency"] = (("fw.total_flow_rate", "fw.total_power_consumption"),
                                               lambda q, pw: np.where(pw > 0, (q * (8.0 - 0.5) * 1e6 * 1000 * 9.81) / 1e6 / np.where(pw > 0, pw, 1.0), 0.0))

@@ -68,7 +68,7 @@ def test_result_log_columns_are_the_references_own_result_keys():
 
 def test_every_log_column_has_one_rule_and_the_constants_hold_in_both_logs():
     """One rule per produced column; the "constant" columns really hold their value in every row of both reference logs; the
-    count of columns still not produced is the 13 the GPU test names."""
+    count of columns still not produced is the 7 the GPU test names."""
     import os
     from golden_util import GOLDEN_DIR
     from nuclear_sim_amd import statelog
@@ -81,7 +81,7 @@ def test_every_log_column_has_one_rule_and_the_constants_hold_in_both_logs():
     for fx in ("m1_oil_top_off_staggered", "e1_eventful_log"):
         z = np.load(os.path.join(GOLDEN_DIR, "log_%s.npz" % fx))
         names = [str(x) for x in z["names"]]
-        assert set().union(*groups) <= set(names) and len(names) - len(set().union(*groups)) == 13
+        assert set().union(*groups) <= set(names) and len(names) - len(set().union(*groups)) == 7
         for name, value in const.items():
             assert np.all(z["log"][:, names.index(name)] == value), (fx, name)
     assert len(const) >= 240
