@@ -81,7 +81,14 @@ enum {
    * switched on (zero the buffer at construction and they are the reference's): the four bearings' clearance increase [mm]
    * (rotor_dynamics.py:298-300) and the overspeed event count (:900-902) */
   NPB_DIAG_ROTOR_CLEARANCE_INCREASE = 124, NPB_DIAG_ROTOR_OVERSPEED_EVENTS = 128,
-  NPB_DIAG_DIM = 129
+  /* the oil temperature the lubrication system hands each turbine bearing, TB-001..004 (turbine_bearing_lubrication.py:967-1072) */
+  NPB_DIAG_BEARING_OIL_TEMP = 129,
+  /* the stage system's efficiency factor -- a product carried from step to step in the caller's buffer like the accumulators above
+   * (a row of zeros reads as 1.0) -- and the turbine's performance factor built on it (stage_system.py:981, enhanced_physics.py:823-828) */
+  NPB_DIAG_STAGE_SYSTEM_EFFICIENCY = 133, NPB_DIAG_TURBINE_PERFORMANCE_FACTOR = 134,
+  /* number of alarms the feedwater protection system holds after the step (protection_system.py:399-445) */
+  NPB_DIAG_FW_ACTIVE_ALARMS = 135,
+  NPB_DIAG_DIM = 136
 };
 /* info["reactivity_components"] (sim.py:205; reactivity_model.py:77-125, pcm, the dict's insertion order).  Only the
  * reactor heat source has them, and only a caller that sets params.info_reactivity_components gets them: the info

@@ -36,8 +36,15 @@ DIAG_TAIL_COLUMNS = (("secondary.condenser_SECONDARY-COMP-001-COND.condenser_ove
                      # accumulators (NPB_DIAG_ROTOR_CLEARANCE_INCREASE x4, NPB_DIAG_ROTOR_OVERSPEED_EVENTS): since the diagnostics were switched on
                      ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-001_clearance_increase", 9), ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-002_clearance_increase", 10),
                      ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-003_clearance_increase", 11), ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-004_clearance_increase", 12),
-                     ("secondary.turbine_SECONDARY-COMP-001-TURB.overspeed_events", 13))
-DIAG_DIM = 14 * len(DIAG_STAGE_VALUES) + 3 * len(DIAG_SG_VALUES) + 4 * len(DIAG_PUMP_VALUES) + len(DIAG_FW_VALUES) + len(DIAG_ROTOR_VALUES) + len(DIAG_TAIL_COLUMNS)
+                     ("secondary.turbine_SECONDARY-COMP-001-TURB.overspeed_events", 13),
+                     # NPB_DIAG_BEARING_OIL_TEMP x4
+                     ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-001_oil_temp", 14), ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-002_oil_temp", 15),
+                     ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-003_oil_temp", 16), ("secondary.turbine_SECONDARY-COMP-001-TURB.TB-004_oil_temp", 17),
+                     # offset 18 = NPB_DIAG_STAGE_SYSTEM_EFFICIENCY: carried from step to step, not a log column of the reference's;
+                     # NPB_DIAG_TURBINE_PERFORMANCE_FACTOR, NPB_DIAG_FW_ACTIVE_ALARMS
+                     ("secondary.turbine_SECONDARY-COMP-001-TURB.enhanced_turbine_performance", 19),
+                     ("secondary.feedwater_SECONDARY-COMP-001-FW.protection_active_alarms_count", 20))
+DIAG_DIM = 14 * len(DIAG_STAGE_VALUES) + 3 * len(DIAG_SG_VALUES) + 4 * len(DIAG_PUMP_VALUES) + len(DIAG_FW_VALUES) + len(DIAG_ROTOR_VALUES) + len(DIAG_TAIL_COLUMNS) + 1
 REACTIVITY_COMPONENTS = ("control_rods", "boron", "doppler", "moderator_temp", "moderator_void", "pressure", "xenon", "samarium",
                          "fuel_depletion", "burnable_poisons")   # reactivity_model.py:87-121, NPB_RHO_*
 

@@ -479,6 +479,36 @@ NPD_FN void npd_fw_pump_step(npb_pump_t *p, npb_fw_t *fw, npd_fw_acc_t *acc, int
   else fw->timer_motor_temp = 0.0;
 }
 
+/* state-log diagnostics: the alarms FeedwaterProtectionSystem.check_protection_systems collects next to its trips
+ * (protection_system.py:399-445; setpoints through the same getattr fallbacks: NPSH 18 m, suction 0.3 MPa, discharge 9 MPa,
+ * vibration 5, bearing 80 C, motor 100 C; flow 2 x the low trip and 0.9 x the high trip; SG level 15.5 / 11 m; health 0.5,
+ * cavitation risk 0.5, wear 50 %).  Where the reference writes if-trip / elif-alarm the alarm is not raised beside the trip. */
+NPD_FN int npd_fw_pump_alarms(const npb_pump_t *p) {
+  int n = 0;
+  n += p->npsh_available < 18.0;
+  n += !(p->suction_pressure < 0.1) && p->suction_pressure < 0.3;
+  n += !(p->discharge_pressure > 10.0) && p->discharge_pressure > 9.0;
+  n += p->vibration_level > 5.0;
+  n += (p->oil_temperature + 5.0) > 80.0;
+  n += p->motor_temperature > 100.0;
+  return n;
+}
+NPD_FN int npd_fw_system_alarms(const npb_fw_t *fw, const npd_fw_acc_t *acc, const double *sg_levels) {
+  int n = 0;
+  n += acc->flow_sum < (0.05 * 1500.0) * 2.0;
+  n += acc->flow_sum > (1.3 * 1500.0) * 0.9;
+#pragma unroll
+  for (int i = 0; i < NPB_NUM_SG; i++) {
+    n += !(sg_levels[i] > 16.5) && sg_levels[i] > 15.5;
+    n += sg_levels[i] < 11.0;     /* "low critical" below 10 m or "low" below 11 m: one alarm either way */
+  }
+  const double avg_cavitation_risk = acc->total_cavitation_risk / NPB_NUM_PUMPS, avg_wear_level = acc->total_wear_level / NPB_NUM_PUMPS;
+  n += !(fw->overall_health_score < 0.3) && fw->overall_health_score < 0.5;
+  n += !(avg_cavitation_risk > 0.8) && avg_cavitation_risk > 0.5;
+  n += !(avg_wear_level > 85.0) && avg_wear_level > 50.0;
+  return n;
+}
+
 typedef struct npd_fw_result_t {
   double total_flow_rate, total_power_consumption;
   int system_availability, num_running_pumps;

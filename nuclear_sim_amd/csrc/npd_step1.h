@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
   NPD_DIAG(st, NPB_DIAG_FW_TOTAL_STEAM_FLOW, 0.0 + prev_flows[0] + prev_flows[1] + prev_flows[2]);
   NPD_DIAG(st, NPB_DIAG_FW_AVG_STEAM_QUALITY, (0.0 + prev_quals[0] + prev_quals[1] + prev_quals[2]) / 3);
   double diag_prev_pressure_sum = 0.0, diag_perf_sum = 0.0, diag_health = 1.0;
-  int diag_perf_n = 0;
+  int diag_perf_n = 0, diag_alarms = 0;
 #endif
   double fw_total_flow = 0.0, fw_total_power = 0.0;
   int fw_available = 1;
@@ -205,6 +205,7 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
           diag_perf_sum += npd_pymax(0.5, 1.0 - pm.flow_degradation / 100.0) * npd_pymax(0.5, 1.0 - pm.efficiency_degradation / 100.0);
           diag_perf_n += 1;
         }
+        diag_alarms += npd_fw_pump_alarms(&pm);
         NPD_DIAG(st, NPB_DIAG_PUMP_MAINTENANCE_OCCURRED + i, 0.0); NPD_DIAG(st, NPB_DIAG_PUMP_OIL_TOP_OFF_OCCURRED + i, 0.0);   /* the rule sets them */
       }
 #endif
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     npd_fw_finish(&fw, &acc, prev_levels, dt, &fwr);
 #ifdef NPD_STEP1_DIAG
     diag_health = fw.overall_health_score;
+    NPD_DIAG(st, NPB_DIAG_FW_ACTIVE_ALARMS, (double)(diag_alarms + npd_fw_system_alarms(&fw, &acc, prev_levels)));
 #endif
     fw_total_flow = fwr.total_flow_rate; fw_total_power = fwr.total_power_consumption;
     fw_available = fwr.system_availability;

@@ -167,6 +167,7 @@ typedef struct npd_stagesys_out_t {
   double total_power, total_extraction, lp6_outlet_enthalpy;
   double hp_power, lp_power, overall_efficiency;   /* enhanced_physics.py:879-880, stage_system.py:983-993 (info only) */
   double max_temp_rate, max_thermal_stress; /* MetalTemperatureTracker reductions */
+  double prev_rotor, prev_casing, max_gradient;   /* diagnostics build only: the tracker's largest rotor / casing gradient, enhanced_physics.py:128-135 */
 } npd_stagesys_out_t;
 
 /* per-stage column access: the stage / tracker arrays are read from the LDS staging region (the whole
@@ -199,12 +200,20 @@ NPD_FN void npd_stage_post(const npd_stage_t &st, const double *stg, int k, doub
     out->max_temp_rate = (k == 0) ? rate : npd_pymax(out->max_temp_rate, rate);
     double stress = (1.2e-05 * (rt - ambient)) * 200000000000.0 * 0.1;
     out->max_thermal_stress = (k == 0) ? stress : npd_pymax(out->max_thermal_stress, stress);
+    if (st.diag) {   /* rotor gradient between neighbouring points 1 m apart [C/cm] */
+      if (k > 0) { const double g = fabs(rt - out->prev_rotor) / (1.0 * 100); out->max_gradient = (k == 1) ? g : npd_pymax(out->max_gradient, g); }
+      out->prev_rotor = rt;
+    }
   }
   if (k < 6) {
     double ct = NPD_TSTG_RD(casing_temperatures, k);
     double tc = ((outlet_temperature - 80.0) - ct) / time_constant * dt;
     tc = npd_clip(tc, -3.0 * dt, 3.0 * dt);
     NPD_TSTG_WR(casing_temperatures, k, ct + tc);
+    if (st.diag) {   /* casing points 1.5 m apart; max(max(rotor), max(casing)) taken at the end (stage 5 comes after every rotor pair but the last two) */
+      if (k > 0) out->max_gradient = npd_pymax(out->max_gradient, fabs((ct + tc) - out->prev_casing) / (1.5 * 100));
+      out->prev_casing = ct + tc;
+    }
   }
   {
     double bt = NPD_TSTG_RD(blade_temperatures, k);
@@ -432,7 +441,7 @@ typedef struct npd_turbine_result_t {
  * only, so every rotor quantity takes its default and the load factor is turbine.load_demand
  * as left by the PREVIOUS step (:744-746).  Reads rotor_speed, bearing_load, bearing_metal_temp and load_demand
  * as the previous step left them; writes the lub_* members only. */
-NPD_FN void npd_turbine_lube(npb_turb_t *t, double dt) {
+NPD_FN void npd_turbine_lube(npb_turb_t *t, double dt, double *oil_temps_out = nullptr) {
   double lub_load_factor = t->load_demand;
   double friction_heat[4], b_load_factor[4], b_speed_factor, b_temperature[4];
   b_speed_factor = t->rotor_speed / 3600.0;
@@ -455,6 +464,25 @@ NPD_FN void npd_turbine_lube(npb_turb_t *t, double dt) {
     system_oil_temp = base_oil_temp + total_heat_generation / (oil_mass_flow * 2000.0);
   } else {
     system_oil_temp = base_oil_temp;
+  }
+  if (oil_temps_out) {   /* state-log diagnostics: calculate_component_oil_temperatures :967-1072, the oil temperature each bearing is handed (:1103-1120) and logs as its own */
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double offset = (i == 0) ? 2.0 : (i == 2) ? 1.0 : (i == 3) ? -5.0 : 0.0;
+      double temp = system_oil_temp + offset;
+      if (NPD_TLUB_OIL_FLOW[i] > 0 && friction_heat[i] > 0) {
+        const double mass_flow = NPD_TLUB_OIL_FLOW[i] / 60.0 * 0.85;
+        const double temp_rise_basic = friction_heat[i] / (mass_flow * 2000.0);
+        const double heat_dissipated = 50.0 * 0.5 * npd_pymax(0.0, temp_rise_basic);
+        const double net_heat = npd_pymax(0.0, friction_heat[i] - heat_dissipated);
+        double temp_rise = (net_heat > 0) ? net_heat / (mass_flow * 2000.0) : 0.0;
+        const double max_temp_rise = (i == 0) ? 25.0 : (i == 3) ? 15.0 : 20.0;
+        temp_rise = npd_pymin(max_temp_rise, npd_pymax(0.0, temp_rise));
+        temp = system_oil_temp + temp_rise;
+        temp += offset;
+      }
+      oil_temps_out[i] = npd_pymax(35.0, npd_pymin(70.0, temp));
+    }
   }
   double contamination_input = lub_load_factor * 0.02 + (1.0 - 0.99) * 0.5;
   double moisture_input = (1.0 - 0.99) * 0.01;
@@ -612,7 +640,12 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
                                double steam_temperature, double steam_flow,
                                const double *sg_pressures, int sg_system_availability, double load_demand,
                                double condenser_pressure, double dt, npd_turbine_result_t *res) {
-  npd_turbine_lube(t, dt);
+  double oil_temps[4];
+  npd_turbine_lube(t, dt, st.diag ? oil_temps : nullptr);
+  if (st.diag) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) NPD_DIAG(st, NPB_DIAG_BEARING_OIL_TEMP + i, oil_temps[i]);
+  }
 
   NPD_STAMP(12);
   /* ================= EnhancedTurbinePhysics.update_state  enhanced_physics.py:694-890 ========= */
@@ -632,6 +665,17 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
      * diagnostics were switched on (from a zeroed buffer at construction they are the reference's) */
 #pragma unroll
     for (int q = 0; q < 5; q++) st.diag[(size_t)(NPB_DIAG_ROTOR_CLEARANCE_INCREASE + q) * st.diag_pitch] += torques[3 + q];
+    /* the stage system's efficiency factor, another carried product nothing reads (stage_system.py:981: multiplied by the pressure
+     * stability factor every step and never restored); a stored 0 is a buffer that has not been through a step, i.e. 1.0 */
+    double *se_row = &st.diag[(size_t)NPB_DIAG_STAGE_SYSTEM_EFFICIENCY * st.diag_pitch];
+    const double se = npd_pymin(1.0, ((*se_row == 0.0) ? 1.0 : *se_row) * pressure_stability_factor);
+    *se_row = npd_pymax(se, 2.2250738585072014e-308);
+    /* performance factor, enhanced_physics.py:147-156 and :823-828 */
+    const double rate_risk = npd_pymin(1.0, ss.max_temp_rate / 10.0), gradient_risk = npd_pymin(1.0, ss.max_gradient / 5.0);
+    const double stress_risk = npd_pymin(1.0, ss.max_thermal_stress / 800e6);
+    const double thermal_shock_risk = npd_pymax3(rate_risk, gradient_risk, stress_risk);
+    const double applied_torque = stage_power_mw * 1e6 / (2 * NPD_PI * 3600 / 60);
+    NPD_DIAG(st, NPB_DIAG_TURBINE_PERFORMANCE_FACTOR, se * (1.0 - torques[0] / npd_pymax(1.0, applied_torque) * 0.1) * (1.0 - thermal_shock_risk * 0.1));
   }
   /* MetalTemperatureTracker.update_temperatures ran per stage inside the stage pass (npd_stage_post) */
   npd_turbine_protect(t, stage_power_mw, ss.max_thermal_stress, max_bearing_metal, total_displacement, sg_system_availability, condenser_pressure, dt);

@@ -66,7 +66,7 @@ def constant_log_columns() -> Dict[str, float]:
     value.  Columns that some other rule here produces (a state member, a derived value, a diagnostic) are left to that rule."""
     with open(_NAMES_PATH) as fh:
         const = json.load(fh).get("constants", {})
-    taken = set(reference_log_columns()) | set(derived_log_columns()) | set(result_log_columns()) | set(_all_diagnostic_columns())
+    taken = set(reference_log_columns()) | set(derived_log_columns()) | set(result_log_columns()) | set(_all_diagnostic_columns()) | set(history_log_columns())
     return {k: float(v) for k, v in const.items() if k not in taken}
 
 
@@ -210,6 +210,19 @@ def clock_log_columns(dt: float) -> Dict[str, tuple]:
     hours = (("sec.operating_hours",), lambda h: 2 * dth * np.round(h * 3600.0 / dt))
     F = "secondary.feedwater_SECONDARY-COMP-001-FW."
     return {pre + k: hours for pre in ("secondary.water_chemistry.", F) for k in ("water_chemistry_operating_hours", "water_chemistry_time_since_treatment")}
+
+
+def history_log_columns() -> Dict[str, tuple]:
+    """Log columns that are a function of another log column's recent history: name -> (source log column, function of the
+    [samples, plants] series).  The pH controller's RMS deviation is the root mean square of the last 100 steps' |pH error|
+    (ph_control_system.py:441-455), a list the reference keeps on the controller; a log that holds every step since the reset
+    holds the same list, so ``table()`` emits the column exactly then (steps 1, 2, 3 ... recorded with every=1)."""
+    def rms_of_last_100(series):
+        ns = series.shape[0]
+        csum = np.concatenate([np.zeros((1,) + series.shape[1:]), np.cumsum(np.square(series), axis=0)], axis=0)
+        hi = np.arange(1, ns + 1); lo = np.maximum(0, hi - 100)
+        return np.sqrt((csum[hi] - csum[lo]) / (hi - lo).reshape((-1,) + (1,) * (series.ndim - 1)))
+    return {"secondary.ph_control.ph_control_deviation_rms": ("secondary.ph_control.ph_control_error", rms_of_last_100)}
 
 
 def result_log_columns() -> Dict[str, tuple]:
@@ -390,6 +403,9 @@ class StateLog:
                 dg = self._diag[:len(self._times)].cpu().numpy()[:, :, idx]
                 for name, row in sorted(_all_diagnostic_columns().items()):
                     cols[name] = dg[:, row, :].reshape(-1)
+            if self._steps == list(range(1, ns + 1)):      # every step since the reset: the windowed columns can be formed
+                for name, (source, fn) in sorted(history_log_columns().items()):
+                    cols[name] = np.asarray(fn(cols[source].reshape(ns, npl)), dtype=np.float64).reshape(-1)
             for name, value in sorted(constant_log_columns().items()):
                 if name not in cols:
                     cols[name] = np.full(ns * npl, value)

@@ -67,13 +67,14 @@ def test_result_log_columns_are_the_references_own_result_keys():
 
 
 def test_every_log_column_has_one_rule_and_the_constants_hold_in_both_logs():
-    """One rule per produced column; the "constant" columns really hold their value in every row of both reference logs; the
-    count of columns still not produced is the 7 the GPU test names."""
+    """One rule per produced column; the "constant" columns really hold their value in every row of both reference logs; and
+    the rules together cover all 784 columns of the reference's log."""
     import os
     from golden_util import GOLDEN_DIR
     from nuclear_sim_amd import statelog
     groups = [set(reference_log_columns()), set(statelog.derived_log_columns()), set(statelog.result_log_columns()),
-              set(statelog._all_diagnostic_columns()), set(statelog.clock_log_columns(5.0)), set(statelog.constant_log_columns())]
+              set(statelog._all_diagnostic_columns()), set(statelog.clock_log_columns(5.0)), set(statelog.constant_log_columns()),
+              set(statelog.history_log_columns())]
     for a in range(len(groups)):
         for b in range(a + 1, len(groups)):
             assert not groups[a] & groups[b], (a, b, sorted(groups[a] & groups[b])[:5])
@@ -81,7 +82,7 @@ def test_every_log_column_has_one_rule_and_the_constants_hold_in_both_logs():
     for fx in ("m1_oil_top_off_staggered", "e1_eventful_log"):
         z = np.load(os.path.join(GOLDEN_DIR, "log_%s.npz" % fx))
         names = [str(x) for x in z["names"]]
-        assert set().union(*groups) <= set(names) and len(names) - len(set().union(*groups)) == 7
+        assert set().union(*groups) == set(names) and len(names) == 784
         for name, value in const.items():
             assert np.all(z["log"][:, names.index(name)] == value), (fx, name)
     assert len(const) >= 240
@@ -146,3 +147,29 @@ def test_derived_log_columns_on_the_oracle_replay(oracle_lib):
             args = [np.float64(fs[slot[l][1]] if slot[l][0] == "f64" else is_[slot[l][1]]) for l in need]
             want = log[t, names.index(name)]
             assert abs(float(fn(*args)) - want) <= 1e-6 * abs(want) + 1e-9, (name, t, float(fn(*args)), want)
+
+
+@pytest.mark.parametrize("fixture", ["m1_oil_top_off_staggered", "e1_eventful_log"])
+def test_history_columns_on_the_references_own_logs(fixture):
+    """The windowed columns are functions of another LOG column's history: evaluated on the reference's own series, against the
+    reference's own column; the logs are shorter than the pH controller's 100-step window, so its far edge is checked on a
+    long random series against the reference's list arithmetic written out (ph_control_system.py:441-455)."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from nuclear_sim_amd import statelog
+    z = np.load(os.path.join(GOLDEN_DIR, "log_%s.npz" % fixture))
+    names = [str(x) for x in z["names"]]; log = z["log"]
+    for name, (source, fn) in statelog.history_log_columns().items():
+        got = fn(np.stack([log[:, names.index(source)]] * 2, axis=1))
+        np.testing.assert_allclose(got[:, 0], log[:, names.index(name)], rtol=1e-9, atol=1e-12, err_msg=name)
+        np.testing.assert_array_equal(got[:, 0], got[:, 1])
+    rng = np.random.default_rng(5)
+    series = rng.normal(0, 0.01, (260, 3))
+    got = statelog.history_log_columns()["secondary.ph_control.ph_control_deviation_rms"][1](series)
+    for lane in range(3):
+        history = []
+        for t in range(series.shape[0]):
+            history.append(abs(series[t, lane]))
+            if len(history) > 100:
+                history.pop(0)
+            assert abs(got[t, lane] - np.sqrt(np.mean(np.square(history)))) <= 1e-12
