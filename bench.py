@@ -127,7 +127,7 @@ def step_kernel_name(n, storage="f64", forced=None, mode="full", maintenance=Fal
     tests/test_abi.py and the GPU tests hold the two together."""
     if forced is None:
         forced = os.environ.get("NPB_STEP_KERNEL", "0")
-    variant = int(forced) if str(forced) in ("1", "2", "3", "4") else 0
+    variant = int(forced) if str(forced) in ("1", "2", "3", "4", "5") else 0
     npad = (n + 63) // 64 * 64
     if mode == "primary":
         return "npb_step_primary_kernel"
@@ -136,6 +136,8 @@ def step_kernel_name(n, storage="f64", forced=None, mode="full", maintenance=Fal
     m = "_maint" if (maintenance and mode == "full") else ""       # the builds with the automatic maintenance compiled in
     if variant == 4:
         return "npb_step_nt%s_kernel" % m
+    if variant == 5 and mode == "full":
+        return "npb_step4%s_kernel" % m
     if variant in (2, 3) and mode == "full":
         return ("npb_step2_wide%s_kernel" if (variant == 2 and npad <= 32768) else "npb_step2%s_kernel") % m
     return "npb_step%s_kernel" % m

@@ -250,6 +250,8 @@ enum {
   NPB_KERNEL_STEP_PRIMARY = 6, /* npb_step_primary_kernel: NPB_MODE_PRIMARY */
   /* the builds of 1-4 with the automatic maintenance compiled in (params.maint_enabled, full mode): same step, same results */
   NPB_KERNEL_STEP_MAINT = 7, NPB_KERNEL_STEP2_WIDE_MAINT = 8, NPB_KERNEL_STEP2_MAINT = 9, NPB_KERNEL_STEP_NT_MAINT = 10,
+  NPB_KERNEL_STEP4 = 11,       /* npb_step4_kernel: four wavefronts per 64 plants, 256 registers (two waves per SIMD at 32 768 plants) */
+  NPB_KERNEL_STEP4_MAINT = 12,
   NPB_KERNEL_COUNT_
 };
 NPB_API int npb_debug_last_step_kernel(const NpbHandle *h);

@@ -563,6 +563,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(const npd_maint_rul
 #define NPD_SM 0          /* ... and the two-wave kernels leave theirs to the compiler */
 
 #include "npd_step2.h"
+#include "npd_step4.h"
 
 /* get_observation() without stepping (after reset / set_field): sim.py:290-333 */
 __global__ __launch_bounds__(NPB_WAVE) void npb_observe_kernel(int mode, int n_plants, size_t N, const npd_real_t *__restrict__ f64c,
@@ -793,6 +794,11 @@ extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t np
     hipLaunchKernelGGL(with_maint ? npb_step_nt_maint_kernel : npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
     return with_maint ? NPB_KERNEL_STEP_NT_MAINT : NPB_KERNEL_STEP_NT;
+  }
+  if (variant == 5 && P->mode == NPB_MODE_FULL) {     /* four waves per 64 plants (npd_step4.h) */
+    hipLaunchKernelGGL(with_maint ? npb_step4_maint_kernel : npb_step4_kernel, grid, dim3(NPD4_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
+                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
+    return with_maint ? NPB_KERNEL_STEP4_MAINT : NPB_KERNEL_STEP4;
   }
   const bool two_wave = (variant == 2 || variant == 3) && P->mode == NPB_MODE_FULL;
   const bool wide = two_wave && variant == 2 && npad <= 32768;   /* the whole register file while one wave per SIMD is all there is; variant 3 = never */

@@ -262,35 +262,49 @@ __device__ __forceinline__ void npd2_seq_stage(int k, double &cur_p, double &cur
 /* npd_stage_post (npd_turbine.h) with the stage's old values already in registers; new values go straight to the arena */
 #define NPD2_TSTG(member, k) (*NPD_RP(NPD_SEC_COL(TSTG, 0) + NPB_F64_SLOT(npb_tstg_t, member) + (k)))
 struct npd2_tstg_old_t { double eff_deg[14], deposit[14], blade_wear[14], rotor_t[8], casing_t[6], blade_t[14]; };
-__device__ __forceinline__ void npd2_stage_post(const npd_stage_t &st, const npd2_tstg_old_t &o, int k, double loading_factor,
-                                                double outlet_temperature, double dt, double *max_thermal_stress) {
-  NPD2_TSTG(stage_efficiency_degradation, k) = (npd_real_t)(o.eff_deg[k] + 1e-05 * dt);
-  NPD2_TSTG(stage_deposit_thickness, k) = (npd_real_t)(o.deposit[k] + 5e-05 * dt);
+/* stage k's old values as scalars (rotor_t / casing_t are read only where the stage has such a point); stress_out: rotor point
+ * k's thermal stress (k < 8) */
+__device__ __forceinline__ void npd2_stage_post_vals(const npd_stage_t &st, int k, double eff_deg, double deposit, double blade_wear_old, double rotor_t,
+                                                     double casing_t, double blade_t, double loading_factor, double outlet_temperature, double dt,
+                                                     double *stress_out) {
+  NPD2_TSTG(stage_efficiency_degradation, k) = (npd_real_t)(eff_deg + 1e-05 * dt);
+  NPD2_TSTG(stage_deposit_thickness, k) = (npd_real_t)(deposit + 5e-05 * dt);
   double blade_wear = (1e-06 * dt) * npd_sq(loading_factor);
-  NPD2_TSTG(stage_blade_wear_factor, k) = (npd_real_t)npd_pymax(0.7, o.blade_wear[k] - blade_wear);
+  NPD2_TSTG(stage_blade_wear_factor, k) = (npd_real_t)npd_pymax(0.7, blade_wear_old - blade_wear);
   const double time_constant = 3600.0 / 3600.0, ambient = 25.0;
   if (k < 8) {
-    double rt = o.rotor_t[k < 8 ? k : 0];
+    double rt = rotor_t;
     double tc = ((outlet_temperature - 50.0) - rt) / time_constant * dt;
     double max_rate = 5.0 * dt;
     tc = npd_clip(tc, -max_rate, max_rate);
     rt += tc;
     NPD2_TSTG(rotor_temperatures, k < 8 ? k : 0) = (npd_real_t)rt;
-    double stress = (1.2e-05 * (rt - ambient)) * 200000000000.0 * 0.1;
-    *max_thermal_stress = (k == 0) ? stress : npd_pymax(*max_thermal_stress, stress);
+    *stress_out = (1.2e-05 * (rt - ambient)) * 200000000000.0 * 0.1;
   }
   if (k < 6) {
-    double ct = o.casing_t[k < 6 ? k : 0];
+    double ct = casing_t;
     double tc = ((outlet_temperature - 80.0) - ct) / time_constant * dt;
     tc = npd_clip(tc, -3.0 * dt, 3.0 * dt);
     NPD2_TSTG(casing_temperatures, k < 6 ? k : 0) = (npd_real_t)(ct + tc);
   }
   {
-    double bt = o.blade_t[k];
+    double bt = blade_t;
     double tc = ((outlet_temperature - 20.0) - bt) / (time_constant * 0.5) * dt;
     tc = npd_clip(tc, -10.0 * dt, 10.0 * dt);
     NPD2_TSTG(blade_temperatures, k) = (npd_real_t)(bt + tc);
   }
+}
+__device__ __forceinline__ void npd2_stage_post_one(const npd_stage_t &st, const npd2_tstg_old_t &o, int k, double loading_factor,
+                                                    double outlet_temperature, double dt, double *stress_out) {
+  npd2_stage_post_vals(st, k, o.eff_deg[k], o.deposit[k], o.blade_wear[k], o.rotor_t[k < 8 ? k : 0], o.casing_t[k < 6 ? k : 0], o.blade_t[k],
+                       loading_factor, outlet_temperature, dt, stress_out);
+}
+/* the same, folding MetalTemperatureTracker's max over the rotor points in stage order */
+__device__ __forceinline__ void npd2_stage_post(const npd_stage_t &st, const npd2_tstg_old_t &o, int k, double loading_factor,
+                                                double outlet_temperature, double dt, double *max_thermal_stress) {
+  double stress = 0.0;
+  npd2_stage_post_one(st, o, k, loading_factor, outlet_temperature, dt, &stress);
+  if (k < 8) *max_thermal_stress = (k == 0) ? stress : npd_pymax(*max_thermal_stress, stress);
 }
 
 /* the body of both two-wave kernels (below): same code, compiled once per register budget */

@@ -54,7 +54,8 @@ def test_construction_state_matches_reference():
 
 # which kernel npb_step must have launched for a forced variant (include/npb.h npb_set_step_kernel) at a batch of <= 32 768
 # plants in full mode; 0 = by batch size
-KERNEL_OF_VARIANT = {0: "npb_step2_wide_kernel", 1: "npb_step_kernel", 2: "npb_step2_wide_kernel", 3: "npb_step2_kernel", 4: "npb_step_nt_kernel"}
+KERNEL_OF_VARIANT = {0: "npb_step2_wide_kernel", 1: "npb_step_kernel", 2: "npb_step2_wide_kernel", 3: "npb_step2_kernel", 4: "npb_step_nt_kernel",
+                     5: "npb_step4_kernel"}
 # fixtures replayed on EVERY shipped step kernel: reactor and constant heat sources, load following, pump trips, the data-gen
 # runner with maintenance, handler promotion, fuzzed states (flags flipped, maintenance under fire), reset(), pump start / stop,
 # pump trip reasons, turbine trips
@@ -70,7 +71,7 @@ def test_hip_replays_golden(name):
     _replay_golden(name, 0)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5])
 @pytest.mark.parametrize("name", EVERY_KERNEL_FIXTURES)
 def test_hip_replays_golden_on_every_step_kernel(name, variant):
     """The reference's fixtures against each shipped step kernel, not only the one a 64-plant batch selects: the one-wave
@@ -539,7 +540,7 @@ def test_the_two_step_kernels_agree(heat_source, storage):
 
     o1, f1, i1 = run(1)
     tol = 1e-12 if storage == "f64" else 3e-7     # fp32 storage: a last-bit difference before the rounding can move the float
-    for variant in (2, 3):    # the two builds of the two-wave kernel: whole register file / room for two waves per SIMD
+    for variant in (2, 3, 5):    # the two builds of the two-wave kernel (whole register file / room for two waves per SIMD), the four-wave kernel
         o2, f2, i2 = run(variant)
         assert np.array_equal(i1, i2)
         np.testing.assert_allclose(f1, f2, rtol=tol, atol=1e-300, equal_nan=True)
