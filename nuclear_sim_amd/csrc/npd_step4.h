@@ -6,64 +6,92 @@
  * wave of the one-wave kernel needs ~75 us however empty the chip is; the two-wave kernel's longer wave ~55 us, DESIGN.md
  * section 3).  The plant has more parallelism than two waves use: the four pumps are independent of each other once the level
  * control has handed out the demand, the three steam generators once the primary side is known, the twenty saturation states of
- * the turbine's pass B, the per-stage degradation / metal-temperature updates.  Here a group of 64 plants has four waves
- * (block = 256 threads, lane l of every wave is plant l), each <= 256 registers so that two groups share a CU's SIMDs at
- * 32 768 plants (2 048 waves, two per SIMD: one wave's scalar and memory instructions issue beside the other's vector ones):
+ * the turbine's pass B, the per-stage degradation / metal-temperature updates, and the chemistry sidecar and the lubrication
+ * pre-step depend on nothing at all.  Here a group of 64 plants has four waves (block = 256 threads, lane l of every wave is
+ * plant l), each <= 256 registers so that two groups share a CU's SIMDs at 32 768 plants (2 048 waves, two per SIMD: one wave's
+ * scalar and memory instructions issue beside the other's vector ones).  The waves do not meet at barriers: every hand-over is a
+ * progress word in LDS that the producer raises behind its data (a wave's LDS operations complete in order) and the consumer polls,
+ * so each wave runs as far ahead as its inputs allow:
  *
- *   segment        wave 0                    wave 1                    wave 2                    wave 3
- *   1              primary side, coupling    turbine lubrication       chemistry sidecar         secondary prelude, level control
- *   2              pump 0                    pump 1                    pump 2                    pump 3
- *   3              steam generator 0         steam generator 1         steam generator 2         pump tails, system level, load turbine
- *   4              stage arrays 0,3,6,..     stage arrays 1,4,7,..     stage arrays 2,5,8,..     SG sums, stage pass A
- *   5  (pass B)    stages 4..8               stages 9..13              the five extractions      inlet, stages 0..3
- *   6              stage post 0,3,6,..       stage post 1,4,7,..       stage post 2,5,8,..       stage chain, rotor
- *   7                                        condenser                                           protection, power gates
- *   8              observation, flags        reward, write-back        info
+ *   wave 3  prelude, level control -> pump 0 -> [pumps 1-3] pump tails, system level -> turbine section, stage efficiencies ->
+ *           [SG 0-2] SG sums, stage pass A (publishing each stage's pressure as it is known) -> [pass B] stage chain -> rotor ->
+ *           [stage post] protection, power gates, tail scalars
+ *   wave 0  primary side -> [level control] pump 3 -> SG 0 part 1, [feedwater flow] part 2 -> pass B units 0,3,6,.. as pass A
+ *           reaches them -> stage post 0,3,6,.. behind the chain -> [tail] observation, done, trip flags
+ *   wave 1  chemistry sidecar -> [level control] pump 1 -> [primary] SG 1 -> units 1,4,.. -> stage post 1,4,.. -> [turbine exhaust] condenser ->
+ *           [tail] reward, secondary write-back
+ *   wave 2  [level control] pump 2 -> [primary] SG 2 -> units 2,5,.. -> stage post 2,5,.. -> turbine lubrication pre-step ->
+ *           [tail, condenser] info
  *
- * Exactness: every device function is the one the other kernels call, sums over pumps / steam generators / stages are taken in
- * the reference's order by one wave from the values the others publish, and the one sequential dependence between pumps (the
- * demand gate of FeedwaterPumpSystem.update_system, npd_step2.h) falls back to running the pumps one after the other.
+ * ([..] = what the wave waits for.)  Exactness: every device function is the one the other kernels call, sums over pumps / steam
+ * generators / stages are taken in the reference's order by one wave from the values the others publish, and the one sequential
+ * dependence between pumps (the demand gate of FeedwaterPumpSystem.update_system, npd_step2.h) makes each pump wait for the one
+ * before it and take the real count.
  */
 #ifndef NPD_STEP4_H
 #define NPD_STEP4_H
 
 #define NPD4_THREADS 256
-#define NPD4_SLOTS 96                         /* exchange slots of 64 doubles: 48 KB per group */
+/* a section back to the arena.  The unchanged-column elision of the other kernels (npb_kernels.hip); -DNPD4_NO_ELIDE:
+ * plain stores, which spare the registers of the old copies (measured: 51 -> 43 spilled registers, +1.2 % kernel time at 32 768
+ * plants, nothing at 8 192: profiles/r3_step4_ab_elide.txt) */
+#ifndef NPD4_NO_ELIDE
+#define NPD4_ST_STORE(T, stype, s, old, inst) NPD_ST_STORE_ELIDE(T, stype, s, old, inst)
+#else
+#define NPD4_ST_STORE(T, stype, s, old, inst) NPD_ST_STORE(T, stype, s, inst)
+#endif
+#define NPD4_SLOTS 142                        /* exchange slots of 64 doubles: 71 KB per group, two groups per CU */
 #ifdef NPB_STAMPS
 #define NPD4_STAMP(k) do { if (lane == 0 && npb_stamp_buf) npb_stamp_buf[((size_t)blockIdx.x * 4 + wave) * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
-#define NPD4_SYNCJ(j) do { NPD4_STAMP(2 * (j) - 1); NPD2_SYNC_(); NPD4_STAMP(2 * (j)); } while (0)
 #else
 #define NPD4_STAMP(k)
-#define NPD4_SYNCJ(j) NPD2_SYNC_()
 #endif
-/* three progress words in one slot: the stage chain's (wave 3 -> the stage-post waves), the feedwater flow's (wave 3 -> the
- * steam generators' part 2) and the primary side's (wave 0 -> wave 3, only when a plant has no previous SG conditions) */
+/* progress words: one 16-byte cell each in slot Y_FLAGS; raised behind the data they announce, polled by the consumer */
+enum { FL_CHAIN = 0, FL_FWFLOW = 1, FL_PRIM = 2, FL_FWCTL = 3, FL_PUMP = 4 /* +pump */, FL_SG = 8 /* +sg */, FL_PASSA = 11, FL_UNIT = 12 /* +wave */,
+       FL_POST = 15 /* +wave */, FL_TURBOUT = 18, FL_TAIL = 19, FL_CONDP = 20, FL_LUBE = 21, FL_COUNT = 22 };
 #define NPD4_FLAGP(n) ((volatile int *)&xch[Y_FLAGS * NPB_WAVE + 2 * (n)])
-#define NPD4_FLAG_SET(n, v) do { NPD_LDS_DRAIN(); *NPD4_FLAGP(n) = (v); } while (0)
-#define NPD4_FLAG_WAIT(n, v) do { while (__builtin_amdgcn_readfirstlane(*NPD4_FLAGP(n)) < (v)) __builtin_amdgcn_s_sleep(1); } while (0)
+/* (a wave's LDS operations execute in issue order, so the word needs no wait behind the data, only the compiler's respect) */
+#define NPD4_FLAG_SET(n, v) do { asm volatile("" ::: "memory"); *NPD4_FLAGP(n) = (v); asm volatile("" ::: "memory"); } while (0)
+#define NPD4_FLAG_WAIT(n, v) do { while (__builtin_amdgcn_readfirstlane(*NPD4_FLAGP(n)) < (v)) __builtin_amdgcn_s_sleep(1); asm volatile("" ::: "memory"); } while (0)
+/* pass B unit u (0 = the turbine inlet, k + 1 = stage k): wave u % 3 works through its units in rising order and counts them */
+#define NPD4_UNIT_WAIT(u) NPD4_FLAG_WAIT(FL_UNIT + (u) % 3, (u) / 3 + 1)
 
 enum {
-  /* until the steam generators are done */
-  Y_CFLOW = 0, Y_CIN = 3, Y_COUT = 6, Y_LDF = 9, Y_FWTEMP = 10, Y_NPREV = 11, Y_FPP = 12, Y_MAXLVL = 13, Y_RUNCOUNT = 15, Y_FWFLOW = 16,
-  Y_PUMP = 17,                                /* 4 x X_PUMP_N */
-  Y_SG = 17,                                  /* 3 x 6 results, over the pump region once wave 3 has read it (flag 1) */
-  /* turbine */
-  Y_PSELF = 0, Y_PEXT = 14, Y_PIN = 19,
-  Y_SAT = 20, Y_HG = 30, Y_TRATIO = 40, Y_HGEXT = 50,   /* stages 4 .. 13 (wave 3 keeps its own: inlet, 0 .. 3) and the extractions */
-  Y_TOUT = 0, Y_LOADING = 55, Y_STRESS = 69, Y_EFFLOW = 77, Y_LP6H = 78, Y_CWT = 79, Y_CONDP = 80,
-  /* the whole step */
-  Y_PRIM = 81,                                /* base reward, load demand, thermal power, reactivity, primary thermal power, scram bits */
-  Y_TIME = 93, Y_FLAGS = 94, Y_MAINT_TAB = 95,
-  /* tail */
-  Y_TAIL = 0, Y_OBS = 24, Y_INFO = 47
+  Y_CFLOW = 0, Y_CIN = 3, Y_COUT = 6, Y_LDF = 9, Y_FWTEMP = 10, Y_NPREV = 11, Y_FPP = 12, Y_MAXLVL = 13, Y_RUNCOUNT = 14, Y_FWFLOW = 15,
+  Y_PRIM = 16,                                /* base reward, load demand, thermal power, reactivity, primary thermal power, scram bits */
+  Y_TIME = 22, Y_FLAGS = 23, Y_MAINT_TAB = 24,
+  Y_PUMP = 25,                                /* 4 x X_PUMP_N, until wave 3 has walked the pumps' tails */
+  Y_SAT = 25, Y_HG = 40, Y_TRATIO = 55, Y_HGEXT = 69,   /* pass B: 15 + 15 + 14 + 5, once pass A runs (the pumps' values have been read by then) */
+  Y_OBS = 25, Y_INFO = 48,                    /* the two transposes, after the chain */
+  Y_SG = 77,                                  /* 3 x 6 results */
+  Y_TOUT = 77,                                /* per stage, written by the chain (the SG results were summed before pass A) */
+  Y_PSELF = 95, Y_PEXT = 109, Y_PIN = 114,
+  Y_TAIL = 95,                                /* 21 tail scalars, after the chain (every pass B unit has been consumed) */
+  Y_LOADING = 116, Y_STRESS = 130, Y_EFFLOW = 138, Y_LP6H = 139, Y_CWT = 140, Y_CONDP = 141
 };
-static_assert(Y_PUMP + 4 * X_PUMP_N <= Y_PRIM && Y_SG + 18 <= Y_PUMP + 4 * X_PUMP_N && Y_HGEXT + 5 <= Y_LOADING && Y_LOADING + 14 <= Y_STRESS &&
-              Y_STRESS + 8 <= Y_EFFLOW && Y_CONDP < Y_PRIM && Y_PRIM + 6 <= Y_TIME && Y_OBS + NPB_OBS_PAD <= Y_INFO && Y_INFO + NPB_OBS_PAD <= Y_PRIM &&
-              Y_MAINT_TAB < NPD4_SLOTS && NPD_MH_N + 8 <= NPB_WAVE, "exchange slot plan");
+static_assert(Y_PUMP + 4 * X_PUMP_N <= Y_SG && Y_HGEXT + 5 <= Y_SG && Y_INFO + NPB_OBS_PAD <= Y_SG && Y_OBS + NPB_OBS_PAD <= Y_INFO && Y_SG + 18 <= Y_PSELF &&
+              Y_TOUT + 14 <= Y_PSELF && Y_TAIL + 21 <= Y_LOADING && Y_PIN < Y_LOADING && Y_LOADING + 14 <= Y_STRESS && Y_STRESS + 8 <= Y_EFFLOW &&
+              Y_CONDP < NPD4_SLOTS && 2 * FL_COUNT <= NPB_WAVE && NPD_MH_N + 8 <= NPB_WAVE, "exchange slot plan");
+
+/* carried members [K0, K1) of the turbine section back to the arena, with the other kernels' unchanged-column elision: the section
+ * has two owners here (the lubrication pre-step's lub_* members / everything else) and the rotor's members are final long before the
+ * protection system's */
+template <int K0, int K1>
+__device__ __forceinline__ void npd4_store_turb_range(const npd_stage_t &st, const npb_turb_t &t, const npb_turb_t &t_old) {
+  const double *d = reinterpret_cast<const double *>(&t), *od = reinterpret_cast<const double *>(&t_old);
+#pragma unroll
+  for (int k = K0; k < K1; k++) {
+    if ((NPD_ELIDE_TURB_F >> k) & 1) {
+      if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) *NPD_RP(NPD_SEC_COL(TURB, 0) + k) = (npd_real_t)d[k];
+    } else {
+      *NPD_RP(NPD_SEC_COL(TURB, 0) + k) = (npd_real_t)d[k];
+    }
+  }
+}
 
 /* the stage arrays of the stages k = R, R + 3, R + 6 ... (at most five) into registers / their post-pass behind the chain's flag.
  * The arrays are indexed by the stage's position j in the wave's list, so that the three waves that share this code path keep them
- * in the same registers (a barrier is a point where the compiler must assume any of them can be the wave running) */
+ * in the same registers */
 struct npd4_old_t { double eff_deg[5], deposit[5], blade_wear[5], blade_t[5], rotor_t[5], casing_t[5]; };
 template <int R>
 __device__ __forceinline__ void npd4_stage_preload(const npd_stage_t &st, npd4_old_t &old) {
@@ -85,41 +113,69 @@ __device__ __forceinline__ void npd4_stage_post(const npd_stage_t &st, const npd
   for (int j = 0; j < 5; j++) {
     const int k = R + 3 * j;
     if (k >= 14) continue;
-    NPD4_FLAG_WAIT(0, k + 1);
+    NPD4_FLAG_WAIT(FL_CHAIN, k + 1);
     double stress = 0.0;
     npd2_stage_post_vals(st, k, old.eff_deg[j], old.deposit[j], old.blade_wear[j], old.rotor_t[j], old.casing_t[j], old.blade_t[j],
                          XR(Y_LOADING + (k < 14 ? k : 0)), XR(Y_TOUT + (k < 14 ? k : 0)), tdt, &stress);
     if (k < 8) XW(Y_STRESS + (k < 8 ? k : 0), stress);
   }
+  NPD4_FLAG_SET(FL_POST + R, 1);
+}
+/* this wave's pass B units u = R, R + 3, .. (npd_stage_system_update's pass B, npd_turbine.h): each as soon as wave 3's pass A has
+ * published the pressures it needs (progress word FL_PASSA: 1 = the inlet pressure, k + 2 = stage k's outlet and, where the stage
+ * has one, its extraction pressure) */
+template <int R>
+__device__ __forceinline__ void npd4_pass_b_units(double *xch, int lane) {
+#define NPD_EXT_IDX(k) ((k) == 2 ? 0 : (k) == 3 ? 1 : (k) == 4 ? 2 : (k) == 8 ? 3 : 4)
+#define NPD_IS_EXT(k) ((k) == 2 || (k) == 3 || (k) == 4 || (k) == 8 || (k) == 9)
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const int u = R + 3 * j;
+    if (u > 14) continue;
+    if (u == 0) {
+      NPD4_FLAG_WAIT(FL_PASSA, 1);
+      const double sat = npd_tsat_antoine(XR(Y_PIN));
+      XW(Y_SAT + 0, sat); XW(Y_HG + 0, npd_hg_from_tsat(sat));
+    } else {
+      const int k = u - 1;
+      NPD4_FLAG_WAIT(FL_PASSA, k + 2);
+      const double pk = XR(Y_PSELF + (k >= 0 ? k : 0)), pkm = (k == 0) ? XR(Y_PIN) : XR(Y_PSELF + (k > 0 ? k - 1 : 0));
+      const double sat = npd_tsat_antoine(pk);
+      XW(Y_SAT + u, sat); XW(Y_HG + u, npd_hg_from_tsat(sat)); XW(Y_TRATIO + (k >= 0 ? k : 0), npd_sqrt(npd_sqrt(pk / pkm)));
+      if (NPD_IS_EXT(k)) XW(Y_HGEXT + NPD_EXT_IDX(k), npd_hg_from_tsat(npd_tsat_antoine(XR(Y_PEXT + NPD_EXT_IDX(k)))));
+    }
+    NPD4_FLAG_SET(FL_UNIT + R, j + 1);
+  }
+#undef NPD_EXT_IDX
+#undef NPD_IS_EXT
 }
 
-/* segment 2, the same for every wave: pump `wave` (serial: one after the other with the real counts, four barriers) */
-#define NPD4_PUMP_SEGMENT() \
+/* pump i of FeedwaterPumpSystem.update_system, by whichever wave has it: waits for the level control's hand-out (and, with the
+ * automatic maintenance, for the plants' clock from the primary side); if the demand gate could close (npd_step2.h), for the pump
+ * before it and its count */
+#define NPD4_PUMP(i_) \
   { \
-    const int i = wave; \
+    const int i = (i_); \
+    NPD4_FLAG_WAIT(FL_FWCTL, 1); \
+    if (maint) NPD4_FLAG_WAIT(FL_PRIM, 1); \
     const int n_prev_running = (int)XR(Y_NPREV); \
     const double flow_per_pump = XR(Y_FPP); \
     npd_pump_sysconds_t sc; \
     sc.feedwater_temperature = 40.0; sc.suction_pressure = 0.5; sc.discharge_pressure = 7.4; sc.max_sg_level = XR(Y_MAXLVL); \
     const double maint_time = maint ? XR(Y_TIME) : 0.0; \
     if (maint) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); npd_maint_cache_landed(maint_cache); } \
-    const uint32_t cooling_mask = (wave & 1) ? maint_cache.z : maint_cache.x; \
-    const float cooling_until = __uint_as_float((wave & 1) ? maint_cache.w : maint_cache.y); \
+    const uint32_t cooling_mask = (i & 1) ? maint_cache.z : maint_cache.x; \
+    const float cooling_until = __uint_as_float((i & 1) ? maint_cache.w : maint_cache.y); \
     npb_pump_t pm; \
     NPD_ST_LOAD(PUMP, npb_pump_t, pm, i); \
     const npb_pump_t pm_old = pm; \
     if (!serial_pumps) { \
       npd2_pump(&pm, 1, n_prev_running, flow_per_pump, &sc, dt);        /* the gate cannot close: its outcome needs no count */ \
     } else { \
-      _Pragma("unroll 1") \
-      for (int turn = 0; turn < NPB_NUM_PUMPS; turn++) { \
-        if (turn == i) { \
-          const int running_count = (i == 0) ? 0 : (int)XR(Y_RUNCOUNT); \
-          npd2_pump(&pm, running_count < n_prev_running, n_prev_running, flow_per_pump, &sc, dt); \
-          XW(Y_RUNCOUNT, (double)(running_count + (pm.status == NPD_PUMP_RUNNING))); \
-        } \
-        NPD2_SYNC_(); \
-      } \
+      int running_count = 0; \
+      if (i > 0) { NPD4_FLAG_WAIT(FL_PUMP + (i > 0 ? i - 1 : 0), 1); running_count = (int)XR(Y_RUNCOUNT); } \
+      npd2_pump(&pm, running_count < n_prev_running, n_prev_running, flow_per_pump, &sc, dt); \
+      XW(Y_RUNCOUNT, (double)(running_count + (pm.status == NPD_PUMP_RUNNING))); \
     } \
     {   /* npd2_publish_pump, into this kernel's region */ \
       const int b = Y_PUMP + i * X_PUMP_N; \
@@ -129,20 +185,11 @@ __device__ __forceinline__ void npd4_stage_post(const npd_stage_t &st, const npd
       XW(b + 7, pm.wear_mechanical_seals); XW(b + 8, pm.vibration_level); XW(b + 9, pm.suction_pressure); XW(b + 10, pm.discharge_pressure); \
       XW(b + 11, pm.oil_temperature); XW(b + 12, pm.motor_temperature); \
     } \
+    NPD4_FLAG_SET(FL_PUMP + i, 1); \
     if (maint) {   /* anything new at this pump, for any plant of the group?  (npd_maintenance.h) */ \
       if (__builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, maint_time)) != 0) maint_hit_bits |= 1u << i; \
     } \
-    NPD_ST_STORE_ELIDE(PUMP, npb_pump_t, pm, pm_old, i); \
-  }
-#define NPD4_GATE_VERDICT() \
-  { \
-    int n_prev = 0, may_run = 0; \
-    _Pragma("unroll") \
-    for (int i = 0; i < NPB_NUM_PUMPS; i++) { \
-      n_prev += (gate_fw_mask >> i) & 1; \
-      may_run += (gate_status[i] == NPD_PUMP_RUNNING || gate_status[i] == NPD_PUMP_STARTING); \
-    } \
-    serial_pumps = __builtin_amdgcn_ballot_w64(n_prev > 0 && may_run > n_prev) != 0; \
+    NPD4_ST_STORE(PUMP, npb_pump_t, pm, pm_old, i); \
   }
 
 template <int WHO, bool MAINT>
@@ -155,6 +202,7 @@ __device__ __forceinline__ void npd_step4_body(
   __shared__ __attribute__((aligned(16))) double xch[NPD4_SLOTS * NPB_WAVE];
   const int lane = threadIdx.x & (NPB_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform role 0 .. 3 */
+  const int my_pump = (wave == 3) ? 0 : (wave == 0 ? 3 : wave);         /* the primary side's wave takes the spare pump, normally the cheap one */
   const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
   const size_t p = block_base + lane;
   const bool live = p < (size_t)n_plants;
@@ -175,20 +223,26 @@ __device__ __forceinline__ void npd_step4_body(
   NPD4_STAMP(0);
   /* this wave's pump's entry of the cooldown cache: {mask, until} of pumps 2h, 2h + 1 come as one 16-byte load */
   npd_u32x4 maint_cache = {0, 0, 0, 0};
-  if (maint) maint_cache = npd_maint_cache_fetch(MC, p, wave >> 1);
-  /* could the demand gate close for a later pump?  (every wave evaluates this on the same data, npd_step2.h; the loads go out
-   * here, the verdict is formed at the end of segment 1, before any wave stores a pump or the feedwater section) */
-  const int gate_fw_mask = *NPD_NP(const int32_t, NPD_SEC_COL(FW, 0) + NPB_FW_NCARRY + (NPB_FW_NOUT + NPB_I32_SLOT(npb_fw_t, FW, running_mask)) / NPD_NPC,
-                                   (NPB_FW_NOUT + NPB_I32_SLOT(npb_fw_t, FW, running_mask)) % NPD_NPC);
-  int gate_status[NPB_NUM_PUMPS];
-#pragma unroll
-  for (int i = 0; i < NPB_NUM_PUMPS; i++)
-    gate_status[i] = *NPD_NP(const int32_t, NPD_SEC_COL(PUMP, i) + NPB_PUMP_NCARRY + (NPB_PUMP_NOUT + NPB_I32_SLOT(npb_pump_t, PUMP, status)) / NPD_NPC,
-                             (NPB_PUMP_NOUT + NPB_I32_SLOT(npb_pump_t, PUMP, status)) % NPD_NPC);
-  if (wave == 3 && lane == 0) { *NPD4_FLAGP(0) = 0; *NPD4_FLAGP(1) = 0; *NPD4_FLAGP(2) = 0; }
-  NPD2_SYNC_();                                                                                          /* flags are down */
-
+  if (maint) maint_cache = npd_maint_cache_fetch(MC, p, my_pump >> 1);
+  /* could the demand gate close for a later pump?  (every wave evaluates this on the same data, npd_step2.h, read before the
+   * barrier below, i.e. before any wave stores a pump or the feedwater section) */
   bool serial_pumps;
+  {
+    const int fw_mask = *NPD_NP(const int32_t, NPD_SEC_COL(FW, 0) + NPB_FW_NCARRY + (NPB_FW_NOUT + NPB_I32_SLOT(npb_fw_t, FW, running_mask)) / NPD_NPC,
+                                (NPB_FW_NOUT + NPB_I32_SLOT(npb_fw_t, FW, running_mask)) % NPD_NPC);
+    int n_prev = 0, may_run = 0;
+#pragma unroll
+    for (int i = 0; i < NPB_NUM_PUMPS; i++) {
+      n_prev += (fw_mask >> i) & 1;
+      const int stt = *NPD_NP(const int32_t, NPD_SEC_COL(PUMP, i) + NPB_PUMP_NCARRY + (NPB_PUMP_NOUT + NPB_I32_SLOT(npb_pump_t, PUMP, status)) / NPD_NPC,
+                              (NPB_PUMP_NOUT + NPB_I32_SLOT(npb_pump_t, PUMP, status)) % NPD_NPC);
+      may_run += (stt == NPD_PUMP_RUNNING || stt == NPD_PUMP_STARTING);
+    }
+    if (wave == 3 && lane < FL_COUNT) *NPD4_FLAGP(lane) = 0;
+    serial_pumps = __builtin_amdgcn_ballot_w64(n_prev > 0 && may_run > n_prev) != 0;
+  }
+  NPD2_SYNC_();                                                                       /* the only barrier before the end: the progress words are down */
+
   if (wave == 3) {
     /* ================================ wave 3: feedwater system level, then the turbine ================================ */
     npb_fw_t fw; npb_fw_t fw_old;
@@ -216,7 +270,7 @@ __device__ __forceinline__ void npd_step4_body(
     NPD_ST_LOAD(FW, npb_fw_t, fw, 0);
     fw_old = fw;
     if (__builtin_amdgcn_ballot_w64(!has_prev) != 0) {   /* a plant's first step: its previous conditions come from the primary side's load */
-      NPD4_FLAG_WAIT(2, 1);
+      NPD4_FLAG_WAIT(FL_PRIM, 1);
       const double load_demand_fraction = XR(Y_LDF);
       if (!has_prev) {
 #pragma unroll
@@ -231,10 +285,12 @@ __device__ __forceinline__ void npd_step4_body(
     XW(Y_FWTEMP, actual_feedwater_temp); XW(Y_NPREV, (double)n_prev_running); XW(Y_FPP, flow_per_pump);
     XW(Y_MAXLVL, npd_pymax3(prev_levels[0], prev_levels[1], prev_levels[2]));
     if (maint && lane < NPD_MH_N) maint_tab[lane] = maint_entry;
-    NPD4_GATE_VERDICT();
-    NPD4_SYNCJ(1);                                                                                        /* #1 */
-    NPD4_PUMP_SEGMENT();
-    NPD4_SYNCJ(2);                                                                                        /* #2 */
+    NPD4_FLAG_SET(FL_FWCTL, 1);
+    NPD4_STAMP(1);
+    NPD4_PUMP(0);
+    NPD4_STAMP(2);
+    NPD4_FLAG_WAIT(FL_PUMP + 1, 1); NPD4_FLAG_WAIT(FL_PUMP + 2, 1); NPD4_FLAG_WAIT(FL_PUMP + 3, 1);
+    NPD4_STAMP(3);
     npb_turb_t t; npb_turb_t t_old;
     double stage_eff[14];
     double fw_total_flow = 0.0, fw_total_power = 0.0;
@@ -251,13 +307,14 @@ __device__ __forceinline__ void npd_step4_body(
     fw_total_flow = fwr.total_flow_rate; fw_total_power = fwr.total_power_consumption;
     fw_available = fwr.system_availability;
     trip_flags = (fwr.pump_trip_mask << 8) | (fw.system_trip_active ? NPB_TRIP_FW_SYSTEM : 0);
-    /* the steam generators wait for this in their part 2; raising the flag also tells them that the pump region has been read */
+    /* the steam generators wait for this in their part 2 */
     XW(Y_FWFLOW, fw_total_flow);
-    NPD4_FLAG_SET(1, 1);
-    NPD_ST_STORE_ELIDE(FW, npb_fw_t, fw, fw_old, 0);
+    NPD4_FLAG_SET(FL_FWFLOW, 1);
+    NPD4_STAMP(4);
+    NPD4_ST_STORE(FW, npb_fw_t, fw, fw_old, 0);
     /* while the steam generators run: the turbine section and the 14 stages' efficiency products (TurbineStage state as the
      * previous step left it, stage_system.py:128-133, 294-339) */
-    NPD_ST_LOAD(TURB, npb_turb_t, t, 0);          /* wave 1 owns the lub_* members; they are neither used nor stored here */
+    NPD_ST_LOAD(TURB, npb_turb_t, t, 0);          /* wave 2 owns the lub_* members; they are neither used nor stored here */
     t_old = t;
 #pragma unroll
     for (int k = 0; k < 14; k++) {
@@ -267,7 +324,9 @@ __device__ __forceinline__ void npd_step4_body(
       double actual_efficiency = npd_pymax(0.7, 0.88 - (double)NPD2_TSTG(stage_efficiency_degradation, k));
       stage_eff[k] = (actual_efficiency * blade_condition_factor * fouling_factor * blade_wear_factor * 1.0);
     }
-    NPD4_SYNCJ(3);                                                                                        /* #3 */
+    NPD4_STAMP(5);
+    NPD4_FLAG_WAIT(FL_SG + 0, 1); NPD4_FLAG_WAIT(FL_SG + 1, 1); NPD4_FLAG_WAIT(FL_SG + 2, 1);
+    NPD4_STAMP(6);
     double sg_total_thermal = 0.0, sg_total_steam = 0.0, sg_avg_pressure = 0.0, sg_avg_temperature = 0.0, sg_avg_quality = 0.0;
     int sg_system_availability = 0;
     double pressure_stability_factor = 1.0, load_demand = 0.0;
@@ -289,30 +348,48 @@ __device__ __forceinline__ void npd_step4_body(
     load_demand = XR(Y_PRIM + 1);
     t.load_demand = load_demand;
     pressure_stability_factor = npd_pressure_stability_factor(sg_pressures);
-    double p_ext[5];
-    const bool rare = npd2_stage_pass_a(sg_avg_pressure, sg_total_steam, load_demand, p_self, flow_out, p_ext, ext_flow);
-    seq = __builtin_amdgcn_ballot_w64(rare) != 0;
-    NPD_LDS_DRAIN();                                /* the steam generators' results have been read: their slots are written below */
-#pragma unroll
-    for (int k = 0; k < 14; k++) XW(Y_PSELF + k, p_self[k]);
-#pragma unroll
-    for (int e = 0; e < 5; e++) XW(Y_PEXT + e, p_ext[e]);
-    XW(Y_PIN, seq ? NAN : sg_avg_pressure);         /* NaN tells the others that the group takes the sequential chain */
     XW(Y_CWT, cooling_water_temperature);
-    NPD4_SYNCJ(4);                                                                                        /* #4 */
-    /* pass B: twenty saturation states over the four waves; this one's are the inlet and stages 0 .. 3 */
-    double sat_a[4], hg_a[4], tr_a[4], sat_in0 = 0.0, hg_in0 = 0.0;
-    if (!seq) {
-      sat_in0 = npd_tsat_antoine(sg_avg_pressure);
-      hg_in0 = npd_hg_from_tsat(sat_in0);
+    XW(Y_PIN, sg_avg_pressure);
+    NPD4_FLAG_SET(FL_PASSA, 1);
+    {   /* stage pass A (npd2_stage_pass_a, npd_step2.h: pressures and flows, no transcendentals), each stage's outlet pressure
+         * published as it is known so that the other waves' pass B runs behind this loop instead of behind its end */
+#define NPD_EXT_IDX(k) ((k) == 2 ? 0 : (k) == 3 ? 1 : (k) == 4 ? 2 : (k) == 8 ? 3 : 4)
+#define NPD_IS_EXT(k) ((k) == 2 || (k) == 3 || (k) == 4 || (k) == 8 || (k) == 9)
+      const double inlet_pressure = sg_avg_pressure, inlet_flow = sg_total_steam;
+      bool rare = !(inlet_pressure >= 0.001 && inlet_pressure <= 22.0);
+      double cur_p = inlet_pressure, cur_flow = inlet_flow;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        sat_a[k] = npd_tsat_antoine(p_self[k]);
-        hg_a[k] = npd_hg_from_tsat(sat_a[k]);
-        tr_a[k] = npd_sqrt(npd_sqrt(p_self[k] / ((k == 0) ? sg_avg_pressure : p_self[k > 0 ? k - 1 : 0])));
+      for (int k = 0; k < 14; k++) {
+        double d_in, d_out, design_flow; int has_extraction, is_lp;
+        npd_stage_design(k, &d_in, &d_out, &design_flow, &has_extraction, &is_lp);
+        double design_pressure_ratio = d_out / d_in;
+        double extraction_demand = (k == 2) ? 25.0 * load_demand : (k == 3) ? 30.0 * load_demand : (k == 4) ? 20.0 * load_demand
+                                 : (k == 8) ? 15.0 * load_demand : (k == 9) ? 10.0 * load_demand : 0.0;
+        double outlet_pressure = npd_stage_requested_outlet(k, cur_p, inlet_flow);
+        rare = rare || (outlet_pressure >= cur_p);
+        double min_allowed, max_allowed;
+        if (k == 13) { min_allowed = 0.002; max_allowed = 0.009; }
+        else { min_allowed = cur_p * (design_pressure_ratio * 0.7); max_allowed = cur_p * (design_pressure_ratio * 1.3); }
+        double self_out = (outlet_pressure < min_allowed) ? min_allowed : ((outlet_pressure > max_allowed) ? max_allowed : outlet_pressure);
+        rare = rare || (self_out != outlet_pressure);
+        double ef = 0.0, pe = cur_p;
+        if (has_extraction && extraction_demand > 0) {
+          ef = npd_clip(extraction_demand, 5.0, npd_pymin(50.0, cur_flow * 0.3));
+          pe = cur_p * 0.7 + outlet_pressure * (1 - 0.7);
+        }
+        if (NPD_IS_EXT(k)) { ext_flow[NPD_EXT_IDX(k)] = ef; XW(Y_PEXT + NPD_EXT_IDX(k), pe); }
+        p_self[k] = self_out;
+        flow_out[k] = cur_flow - ef;
+        rare = rare || !(self_out >= 0.001 && self_out <= 22.0) || !(pe >= 0.001 && pe <= 22.0) || !(outlet_pressure >= 0.001);
+        cur_p = self_out; cur_flow = flow_out[k];
+        XW(Y_PSELF + k, self_out);
+        NPD4_FLAG_SET(FL_PASSA, k + 2);
       }
+      seq = __builtin_amdgcn_ballot_w64(rare) != 0;   /* any lane off the fast path: the group takes the sequential chain (the others' pass B is then not used) */
+#undef NPD_EXT_IDX
+#undef NPD_IS_EXT
     }
-    NPD4_SYNCJ(5);                                                                                        /* #5 */
+    NPD4_STAMP(7);
     double stage_power_mw = 0.0, turbine_efficiency = 0.0, hp_power = 0.0, lp_power = 0.0, max_bearing_metal = 0.0, total_displacement = 0.0;
     npd2_chain_t ch;
     ch.T_in = sg_avg_temperature; ch.total_power = 0.0; ch.total_extraction = 0.0; ch.lp6_outlet_enthalpy = 0.0;
@@ -320,19 +397,19 @@ __device__ __forceinline__ void npd_step4_body(
 #define NPD_EXT_IDX(k) ((k) == 2 ? 0 : (k) == 3 ? 1 : (k) == 4 ? 2 : (k) == 8 ? 3 : 4)
 #define NPD_IS_EXT(k) ((k) == 2 || (k) == 3 || (k) == 4 || (k) == 8 || (k) == 9)
     if (!seq) {
-      ch.sat_in = sat_in0; ch.hg_in = hg_in0;
+      NPD4_UNIT_WAIT(0);                           /* the inlet's saturation state */
+      ch.sat_in = XR(Y_SAT + 0); ch.hg_in = XR(Y_HG + 0);
 #pragma unroll
       for (int k = 0; k < 14; k++) {
         const double p_in = (k == 0) ? sg_avg_pressure : p_self[k > 0 ? k - 1 : 0];
-        const double sat_k = k < 4 ? sat_a[k < 4 ? k : 0] : XR(Y_SAT + (k < 4 ? 0 : k - 4));
-        const double hg_k = k < 4 ? hg_a[k < 4 ? k : 0] : XR(Y_HG + (k < 4 ? 0 : k - 4));
-        const double tr_k = k < 4 ? tr_a[k < 4 ? k : 0] : XR(Y_TRATIO + (k < 4 ? 0 : k - 4));
+        NPD4_UNIT_WAIT(k + 1);                     /* stage k's, and its extraction's if it has one */
+        const double sat_k = XR(Y_SAT + k + 1), hg_k = XR(Y_HG + k + 1), tr_k = XR(Y_TRATIO + k);
         const double ef = NPD_IS_EXT(k) ? ext_flow[NPD_EXT_IDX(k)] : 0.0;
         const double hgx = NPD_IS_EXT(k) ? XR(Y_HGEXT + NPD_EXT_IDX(k)) : 0.0;
         double T_out, loading;
         npd2_chain_stage(k, ch, p_in, p_self[k], sat_k, hg_k, tr_k, flow_out[k], ef, hgx, stage_eff[k], &T_out, &loading);
         XW(Y_TOUT + k, T_out); XW(Y_LOADING + k, loading);
-        NPD4_FLAG_SET(0, k + 1);
+        NPD4_FLAG_SET(FL_CHAIN, k + 1);
       }
       {   /* _steam_enthalpy at the last stage's outlet, whose saturation state pass B has */
         const double T_c = npd_pymax(0.0, npd_pymin(ch.T_in, 800.0));
@@ -347,7 +424,7 @@ __device__ __forceinline__ void npd_step4_body(
         double T_out, loading;
         npd2_seq_stage(k, cur_p, cur_T, cur_flow, sg_total_steam, load_demand, stage_eff[k], ch, &T_out, &loading);
         XW(Y_TOUT + k, T_out); XW(Y_LOADING + k, loading);
-        NPD4_FLAG_SET(0, k + 1);
+        NPD4_FLAG_SET(FL_CHAIN, k + 1);
       }
       if (sg_total_steam > 0) {
         const double h_in = npd_stage_steam_enthalpy(sg_avg_temperature, sg_avg_pressure);
@@ -359,32 +436,24 @@ __device__ __forceinline__ void npd_step4_body(
     stage_power_mw = ch.total_power * pressure_stability_factor;
     hp_power = ch.hp_power; lp_power = ch.lp_power;
     XW(Y_EFFLOW, sg_total_steam - ch.total_extraction); XW(Y_LP6H, ch.lp6_outlet_enthalpy);
+    NPD4_STAMP(8);
     npd_turbine_rotor(&t, stage_power_mw, sg_avg_temperature, load_demand, tdt, &max_bearing_metal, &total_displacement);
-    NPD4_SYNCJ(6);                                                                                        /* #6: the stage arrays are done */
+    NPD4_FLAG_SET(FL_TURBOUT, 1);
+    {   /* the rotor's members are final: to the arena while the stage-post waves finish -- behind wave 2's load of the PREVIOUS
+         * step's rotor state for the lubrication pre-step (update_with_lubrication reads it before the rotor moves) */
+      constexpr int T0 = NPB_F64_SLOT(npb_turb_t, timer_overspeed), T1 = NPB_F64_SLOT(npb_turb_t, load_demand);
+      static_assert(T1 - T0 == 3 && NPB_F64_SLOT(npb_turb_t, lub_oil_temperature) == T1 + 1, "turbine section layout");
+      NPD4_FLAG_WAIT(FL_LUBE, 1);
+      npd4_store_turb_range<0, T0>(st, t, t_old);
+      npd4_store_turb_range<T1, T1 + 1>(st, t, t_old);
+    }
+    NPD4_STAMP(9);
+    NPD4_FLAG_WAIT(FL_POST + 0, 1); NPD4_FLAG_WAIT(FL_POST + 1, 1); NPD4_FLAG_WAIT(FL_POST + 2, 1);
+    NPD4_STAMP(10);
     double max_stress = 0.0;      /* MetalTemperatureTracker's max over the rotor points, in their order */
 #pragma unroll
     for (int k = 0; k < 8; k++) max_stress = (k == 0) ? XR(Y_STRESS) : npd_pymax(max_stress, XR(Y_STRESS + k));
     npd_turbine_protect(&t, stage_power_mw, max_stress, max_bearing_metal, total_displacement, sg_system_availability, 0.007, tdt);
-    {   /* store the turbine section but for wave 1's lub_* members */
-      constexpr int L0 = NPB_F64_SLOT(npb_turb_t, lub_oil_temperature), L1 = NPB_F64_SLOT(npb_turb_t, thermal_expansion);
-      const double *d = reinterpret_cast<const double *>(&t), *od = reinterpret_cast<const double *>(&t_old);
-#pragma unroll
-      for (int k = 0; k < NPB_TURB_NCARRY; k++) {
-        if (k >= L0 && k < L1) continue;
-        if ((NPD_ELIDE_TURB_F >> k) & 1) {
-          if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) *NPD_RP(NPD_SEC_COL(TURB, 0) + k) = (npd_real_t)d[k];
-        } else {
-          *NPD_RP(NPD_SEC_COL(TURB, 0) + k) = (npd_real_t)d[k];
-        }
-      }
-      static_assert(NPB_TURB_NOUT == 4 && NPB_TURB_NI32 == 2, "turbine narrow layout");
-      constexpr int NC = NPB_TURB_NCARRY;
-      *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NC + 0 / NPD_NPC, 0 % NPD_NPC) = (float)t.thermal_expansion;
-      *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NC + 1 / NPD_NPC, 1 % NPD_NPC) = (float)t.total_power_output;
-      *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NC + 2 / NPD_NPC, 2 % NPD_NPC) = (float)t.vibration_displacement;
-      *NPD_NP(int32_t, NPD_SEC_COL(TURB, 0) + NC + 4 / NPD_NPC, 4 % NPD_NPC) = t.trip_active;
-      *NPD_NP(int32_t, NPD_SEC_COL(TURB, 0) + NC + 5 / NPD_NPC, 5 % NPD_NPC) = t.trip_latched_mask;
-    }
     /* ---- electrical-power gates (secondary/__init__.py:750-932) */
     const double primary_thermal_power = XR(Y_PRIM + 4);
     const double turbine_electrical_power = t.total_power_output * 0.98;
@@ -399,17 +468,38 @@ __device__ __forceinline__ void npd_step4_body(
     const double electrical_power = turbine_electrical_power * power_reduction_factor;
     const double thermal_efficiency = (primary_thermal_power > 0) ? electrical_power / primary_thermal_power : 0.0;
     if (t.trip_active) trip_flags |= NPB_TRIP_TURBINE;
-    /* the stage-post waves are past their reads of Y_TOUT (barrier #6): the tail goes there */
     XW(Y_TAIL + 0, electrical_power); XW(Y_TAIL + 1, thermal_efficiency); XW(Y_TAIL + 2, sg_avg_pressure); XW(Y_TAIL + 3, sg_total_steam);
     XW(Y_TAIL + 4, fw_total_flow); XW(Y_TAIL + 5, total_system_heat_rejection); XW(Y_TAIL + 6, sg_total_thermal); XW(Y_TAIL + 7, sg_avg_temperature);
     XW(Y_TAIL + 8, sg_avg_quality); XW(Y_TAIL + 9, (double)(sg_system_availability | (fw_available << 1))); XW(Y_TAIL + 10, prev_feedwater_temp);
     XW(Y_TAIL + 11, cw_old); XW(Y_TAIL + 12, operating_hours); XW(Y_TAIL + 13, t.total_power_output); XW(Y_TAIL + 14, fw_total_power);
     XW(Y_TAIL + 15, turbine_efficiency); XW(Y_TAIL + 16, hp_power); XW(Y_TAIL + 17, lp_power); XW(Y_TAIL + 18, (double)trip_flags);
     XW(Y_TAIL + 19, actual_feedwater_temp); XW(Y_TAIL + 20, (double)fw_available);
-    NPD4_SYNCJ(7);                                                                                        /* #7 */
+    NPD4_FLAG_SET(FL_TAIL, 1);
+    NPD4_STAMP(11);
+    {   /* what the protection system moved: its timers, the narrow members but the lubrication's */
+      constexpr int T0 = NPB_F64_SLOT(npb_turb_t, timer_overspeed), T1 = NPB_F64_SLOT(npb_turb_t, load_demand);
+      npd4_store_turb_range<T0, T1>(st, t, t_old);
+      static_assert(NPB_TURB_NOUT == 4 && NPB_TURB_NI32 == 2, "turbine narrow layout");
+      constexpr int NC = NPB_TURB_NCARRY;
+      *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NC + 0 / NPD_NPC, 0 % NPD_NPC) = (float)t.thermal_expansion;
+      *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NC + 1 / NPD_NPC, 1 % NPD_NPC) = (float)t.total_power_output;
+      *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NC + 2 / NPD_NPC, 2 % NPD_NPC) = (float)t.vibration_displacement;
+      *NPD_NP(int32_t, NPD_SEC_COL(TURB, 0) + NC + 4 / NPD_NPC, 4 % NPD_NPC) = t.trip_active;
+      *NPD_NP(int32_t, NPD_SEC_COL(TURB, 0) + NC + 5 / NPD_NPC, 5 % NPD_NPC) = t.trip_latched_mask;
+    }
   } else {
     /* ================================ waves 0 .. 2 ================================ */
     int scram_bits = 0;                               /* wave 0: scram_status | scram_fired << 1 | nan_reset << 2 */
+    if (wave == 1) {   /* while the level control runs */
+      /* ---- chemistry sidecar: shared WaterChemistry + pH controller (secondary/__init__.py:634-665) */
+      npb_chem_t ch0; npb_ph_t ph;
+      NPD_ST_LOAD(CHEM, npb_chem_t, ch0, 0);
+      NPD_ST_LOAD(PH, npb_ph_t, ph, 0);
+      const npb_chem_t ch0_old = ch0; const npb_ph_t ph_old = ph;
+      npd_chemistry_sidecar(&ch0, &ph, dt);
+      NPD4_ST_STORE(CHEM, npb_chem_t, ch0, ch0_old, 0);
+      NPD4_ST_STORE(PH, npb_ph_t, ph, ph_old, 0);
+    }
     if (wave == 0) {
       npd_maint_due_t maint_due = {};
       if (maint) npd_maint_due_load(&maint_due, f64, N, p);
@@ -461,47 +551,22 @@ __device__ __forceinline__ void npd_step4_body(
       XW(Y_PRIM + 0, power_reward + temp_penalty + pressure_penalty + scram_penalty); XW(Y_PRIM + 1, s.power_level);
       XW(Y_PRIM + 2, s.thermal_power_mw); XW(Y_PRIM + 3, s.total_reactivity_pcm); XW(Y_PRIM + 4, primary_thermal_power);
       XW(Y_PRIM + 5, (double)scram_bits); XW(Y_TIME, s.sim_time);
-      NPD4_FLAG_SET(2, 1);
+      NPD4_FLAG_SET(FL_PRIM, 1);
       s.has_heat_removal_factor = 1;
       NPD_ST_STORE_ELIDE_PRIM(s, s_old);
       if (maint) {   /* sim.py:208-216 as far as no work order is involved; t = the clock after this step */
         const bool work = npd_maint_due_decide(&maint_due, s.sim_time, MH.tab[2 * NPB_MAINT_NPARAM + 1]);
         maint_due_with_orders = __builtin_amdgcn_ballot_w64(work) != 0 ? 1u : 0u;
       }
-    } else if (wave == 1) {
-      /* ---- turbine lubrication pre-step: reads the previous step's rotor / bearing members, owns the lub_* ones */
-      npb_turb_t t;
-      NPD_ST_LOAD(TURB, npb_turb_t, t, 0);
-      const npb_turb_t t_old = t;
-      npd_turbine_lube(&t, tdt);
-      constexpr int L0 = NPB_F64_SLOT(npb_turb_t, lub_oil_temperature), L1 = NPB_F64_SLOT(npb_turb_t, thermal_expansion);
-      const double *d = reinterpret_cast<const double *>(&t), *od = reinterpret_cast<const double *>(&t_old);
-  #pragma unroll
-      for (int k = L0; k < L1; k++) {
-        if ((NPD_ELIDE_TURB_F >> k) & 1) {
-          if (__builtin_amdgcn_ballot_w64(npd_real_bits(d[k]) != npd_real_bits(od[k])) != 0) *NPD_RP(NPD_SEC_COL(TURB, 0) + k) = (npd_real_t)d[k];
-        } else {
-          *NPD_RP(NPD_SEC_COL(TURB, 0) + k) = (npd_real_t)d[k];
-        }
-      }
-      *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NPB_TURB_NCARRY + 3 / NPD_NPC, 3 % NPD_NPC) = (float)t.lub_effectiveness;
-    } else {
-      /* ---- chemistry sidecar: shared WaterChemistry + pH controller (secondary/__init__.py:634-665) */
-      npb_chem_t ch0; npb_ph_t ph;
-      NPD_ST_LOAD(CHEM, npb_chem_t, ch0, 0);
-      NPD_ST_LOAD(PH, npb_ph_t, ph, 0);
-      const npb_chem_t ch0_old = ch0; const npb_ph_t ph_old = ph;
-      npd_chemistry_sidecar(&ch0, &ph, dt);
-      NPD_ST_STORE_ELIDE(CHEM, npb_chem_t, ch0, ch0_old, 0);
-      NPD_ST_STORE_ELIDE(PH, npb_ph_t, ph, ph_old, 0);
     }
-    NPD4_GATE_VERDICT();
-    NPD4_SYNCJ(1);                                                                                        /* #1 */
-    NPD4_PUMP_SEGMENT();
-    NPD4_SYNCJ(2);                                                                                        /* #2 */
+    NPD4_STAMP(1);
+    NPD4_PUMP(my_pump);
+    NPD4_STAMP(2);
     {
-      /* ---- steam generator `wave` (enhanced_physics.py:433-547): part 1 needs no feedwater flow, part 2 waits for wave 3's */
       const int i = wave;
+      NPD4_FLAG_WAIT(FL_PRIM, 1);
+      NPD4_STAMP(3);
+      /* ---- steam generator i (enhanced_physics.py:433-547): part 1 needs the primary side only, part 2 waits for wave 3's feedwater flow */
       const double c_flow = XR(Y_CFLOW + i), c_in = XR(Y_CIN + i), c_out = XR(Y_COUT + i);
       const double load_demand_fraction = XR(Y_LDF), feedwater_temp = XR(Y_FWTEMP);
       double total_primary_flow = 0.0;
@@ -513,7 +578,9 @@ __device__ __forceinline__ void npd_step4_body(
       const npb_sg_t g_old = g;
       const double level_old = (double)NPD_ST_F64(SEC, npb_sec_t, prev_sg_levels, 0, i);
       const double heat_transfer = npd_sg_part1(&g, &P, c_in, c_out, c_flow, dt * 60);
-      NPD4_FLAG_WAIT(1, 1);
+      NPD4_STAMP(4);
+      NPD4_FLAG_WAIT(FL_FWFLOW, 1);
+      NPD4_STAMP(5);
       const double fw_flow = XR(Y_FWFLOW);
       npd_sg_result_t r;
       r.heat_transfer_rate = 0.0; r.steam_flow_rate = 0.0; r.thermal_efficiency = 0.0;
@@ -521,68 +588,22 @@ __device__ __forceinline__ void npd_step4_body(
       const int b = Y_SG + 6 * i;
       XW(b + 0, r.heat_transfer_rate); XW(b + 1, r.steam_flow_rate); XW(b + 2, g.secondary_pressure);
       XW(b + 3, g.secondary_temperature); XW(b + 4, g.steam_quality); XW(b + 5, r.thermal_efficiency > 0.1 ? 1.0 : 0.0);
-      NPD_ST_STORE_ELIDE(SG, npb_sg_t, g, g_old, i);
+      NPD4_ST_STORE(SG, npb_sg_t, g, g_old, i);
       NPD_ST_F64_ELIDE(SEC, npb_sec_t, prev_sg_levels, 0, i, g.water_level, level_old);
       NPD_ST_F64(SEC, npb_sec_t, prev_sg_steam_flows, 0, i) = (npd_real_t)r.steam_flow_rate;
       NPD_ST_F64(SEC, npb_sec_t, prev_sg_qualities, 0, i) = (npd_real_t)g.steam_quality;
+      NPD4_FLAG_SET(FL_SG + i, 1);
     }
-    NPD4_SYNCJ(3);                                                                                        /* #3 */
+    NPD4_STAMP(6);
     npd4_old_t old;
-    if (wave == 0) npd4_stage_preload<0>(st, old);
-    else if (wave == 1) npd4_stage_preload<1>(st, old);
-    else npd4_stage_preload<2>(st, old);
-    NPD4_SYNCJ(4);                                                                                        /* #4 */
-    {
-      const double p_in0 = XR(Y_PIN);
-      const bool seq = __builtin_amdgcn_ballot_w64(isnan(p_in0)) != 0;
-      if (!seq) {
-        if (wave == 2) {
-  #pragma unroll
-          for (int e = 0; e < 5; e++) XW(Y_HGEXT + e, npd_hg_from_tsat(npd_tsat_antoine(XR(Y_PEXT + e))));
-        } else {
-          const int k0 = (wave == 0) ? 4 : 9;           /* stages k0 .. k0 + 4 */
-  #pragma unroll
-          for (int j = 0; j < 5; j++) {
-            const double pk = XR(Y_PSELF + k0 + j), pkm = XR(Y_PSELF + k0 + j - 1);
-            const double sat = npd_tsat_antoine(pk);
-            XW(Y_SAT + k0 + j - 4, sat); XW(Y_HG + k0 + j - 4, npd_hg_from_tsat(sat)); XW(Y_TRATIO + k0 + j - 4, npd_sqrt(npd_sqrt(pk / pkm)));
-          }
-        }
-      }
-    }
-    NPD4_SYNCJ(5);                                                                                        /* #5 */
-    npb_cond_t cd; npb_cond_t cd_old; npb_chem_t chc; npb_chem_t chc_old;   /* wave 1 */
-    if (wave == 0) npd4_stage_post<0>(st, old, xch, lane, tdt);
-    else if (wave == 1) {
-      npd4_stage_post<1>(st, old, xch, lane, tdt);
-      NPD_ST_LOAD(COND, npb_cond_t, cd, 0);
-      NPD_ST_LOAD(CHEM, npb_chem_t, chc, 1);
-      cd_old = cd; chc_old = chc;
-    } else npd4_stage_post<2>(st, old, xch, lane, tdt);
-    NPD4_SYNCJ(6);                                                                                        /* #6 */
-    if (wave == 1) {
-      /* ---- condenser (secondary/__init__.py:591-621) */
-      const double effective_steam_flow = XR(Y_EFFLOW), lp6_outlet_enthalpy = XR(Y_LP6H), cwt = XR(Y_CWT);
-      double lp_exhaust_quality = 0.90;
-      {
-        double h_f = npd_cond_hf(0.007), h_g = npd_cond_hg(0.007);
-        double h_fg = h_g - h_f;
-        if (h_fg > 0) {
-          lp_exhaust_quality = (lp6_outlet_enthalpy - h_f) / h_fg;
-          lp_exhaust_quality = npd_pymax(0.0, npd_pymin(1.0, lp_exhaust_quality));
-        }
-      }
-      npd_condenser_result_t cr;
-      npd_condenser_update(&cd, &chc, 0.007, effective_steam_flow, lp_exhaust_quality, 45000.0, cwt, 1.2, 185.0, tdt, &cr);
-      NPD_ST_STORE_ELIDE(COND, npb_cond_t, cd, cd_old, 0);
-      NPD_ST_STORE_ELIDE(CHEM, npb_chem_t, chc, chc_old, 1);
-      XW(Y_CONDP, cr.condenser_pressure);
-    }
-    NPD4_SYNCJ(7);                                                                                        /* #7 */
+    if (wave == 0) { npd4_stage_preload<0>(st, old); NPD4_STAMP(7); npd4_pass_b_units<0>(xch, lane); NPD4_STAMP(8); npd4_stage_post<0>(st, old, xch, lane, tdt); }
+    else if (wave == 1) { npd4_stage_preload<1>(st, old); NPD4_STAMP(7); npd4_pass_b_units<1>(xch, lane); NPD4_STAMP(8); npd4_stage_post<1>(st, old, xch, lane, tdt); }
+    else { npd4_stage_preload<2>(st, old); NPD4_STAMP(7); npd4_pass_b_units<2>(xch, lane); NPD4_STAMP(8); npd4_stage_post<2>(st, old, xch, lane, tdt); }
+    NPD4_STAMP(9);
     if (wave == 0) {
-      /* ---- observation, done, trip flags: the primary part (sim.py:290-333) from the primary section as stored in segment 1
-       * (carried members: the stored value is the value; power_level, an output member, was published in fp64) */
-      const double ld = XR(Y_PRIM + 1), sg_total_steam_t = XR(Y_TAIL + 3), fw_flow_t = XR(Y_TAIL + 4);
+      /* ---- observation, done, trip flags: the primary part (sim.py:290-333) from the primary section as stored by this wave
+       * at the start (carried members: the stored value is the value; power_level, an output member, was published in fp64);
+       * loaded before the wait for the tail */
       double obs[NPB_OBS_DIM];
       obs[0] = (double)NPD_ST_F64(PRIM, npb_prim_t, neutron_flux, 0, 0) / 1e12;
       obs[1] = (double)NPD_ST_F64(PRIM, npb_prim_t, fuel_temperature, 0, 0) / 1000;
@@ -593,8 +614,12 @@ __device__ __forceinline__ void npd_step4_body(
       obs[6] = (double)NPD_ST_F64(PRIM, npb_prim_t, steam_pressure, 0, 0) / 10;
       obs[8] = (double)NPD_ST_F64(PRIM, npb_prim_t, control_rod_position, 0, 0) / 100;
       obs[9] = (double)NPD_ST_F64(PRIM, npb_prim_t, steam_valve_position, 0, 0) / 100;
-      obs[10] = ld / 100;                          /* load_demand IS state.power_level (sim.py:161) */
       obs[11] = (double)(scram_bits & 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      NPD4_FLAG_WAIT(FL_TAIL, 1);
+      NPD4_STAMP(10);
+      const double ld = XR(Y_PRIM + 1), sg_total_steam_t = XR(Y_TAIL + 3), fw_flow_t = XR(Y_TAIL + 4);
+      obs[10] = ld / 100;                          /* load_demand IS state.power_level (sim.py:161) */
       obs[7] = sg_total_steam_t / 3000;
       obs[12] = XR(Y_TAIL + 0) / 1100; obs[13] = XR(Y_TAIL + 1) / 0.35; obs[14] = sg_total_steam_t / 1665;
       obs[15] = ld / 100; obs[16] = 227.0 / 250; obs[17] = XR(Y_CWT) / 35;
@@ -608,7 +633,34 @@ __device__ __forceinline__ void npd_step4_body(
         if (trip_out) __builtin_nontemporal_store(flags, &trip_out[p]);
       }
       if (obs_out) npd2_store_rows<NPB_OBS_DIM>(obs, obs_out, xch + Y_OBS * NPB_WAVE, lane, block_base, (size_t)n_plants);
+      NPD4_STAMP(11);
     } else if (wave == 1) {
+      npb_cond_t cd; npb_chem_t chc;
+      NPD_ST_LOAD(COND, npb_cond_t, cd, 0);
+      NPD_ST_LOAD(CHEM, npb_chem_t, chc, 1);
+      const npb_cond_t cd_old = cd; const npb_chem_t chc_old = chc;
+      NPD4_FLAG_WAIT(FL_TURBOUT, 1);
+      NPD4_STAMP(10);
+      /* ---- condenser (secondary/__init__.py:591-621) */
+      const double effective_steam_flow = XR(Y_EFFLOW), lp6_outlet_enthalpy = XR(Y_LP6H), cwt = XR(Y_CWT);
+      double lp_exhaust_quality = 0.90;
+      {
+        double h_f = npd_cond_hf(0.007), h_g = npd_cond_hg(0.007);
+        double h_fg = h_g - h_f;
+        if (h_fg > 0) {
+          lp_exhaust_quality = (lp6_outlet_enthalpy - h_f) / h_fg;
+          lp_exhaust_quality = npd_pymax(0.0, npd_pymin(1.0, lp_exhaust_quality));
+        }
+      }
+      npd_condenser_result_t cr;
+      npd_condenser_update(&cd, &chc, 0.007, effective_steam_flow, lp_exhaust_quality, 45000.0, cwt, 1.2, 185.0, tdt, &cr);
+      NPD4_ST_STORE(COND, npb_cond_t, cd, cd_old, 0);
+      NPD4_ST_STORE(CHEM, npb_chem_t, chc, chc_old, 1);
+      XW(Y_CONDP, cr.condenser_pressure);
+      NPD4_FLAG_SET(FL_CONDP, 1);
+      NPD4_STAMP(11);
+      NPD4_FLAG_WAIT(FL_TAIL, 1);
+      NPD4_STAMP(12);
       /* ---- reward (sim.py:521-542), secondary-level state write-back, feedback into the primary state (sim.py:429-498) */
       const double condenser_pressure = XR(Y_CONDP);
       const double base_reward = XR(Y_PRIM + 0), ld = XR(Y_PRIM + 1);
@@ -637,7 +689,25 @@ __device__ __forceinline__ void npd_step4_body(
       if (!(avail & 2)) heat_removal_factor *= 0.5;
       NPD_ST_F64(PRIM, npb_prim_t, steam_flow_rate, 0, 0) = (npd_real_t)sg_total_steam_t;
       NPD_ST_F64(PRIM, npb_prim_t, last_heat_removal_factor, 0, 0) = (npd_real_t)heat_removal_factor;
+      NPD4_STAMP(13);
     } else {
+      /* ---- turbine lubrication pre-step: reads the PREVIOUS step's rotor / bearing members (wave 3 holds its store of them back
+       * until they have landed here), owns the lub_* ones */
+      {
+        npb_turb_t t;
+        NPD_ST_LOAD(TURB, npb_turb_t, t, 0);
+        const npb_turb_t t_old = t;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NPD4_FLAG_SET(FL_LUBE, 1);
+        npd_turbine_lube(&t, tdt);
+        constexpr int L0 = NPB_F64_SLOT(npb_turb_t, lub_oil_temperature), L1 = NPB_F64_SLOT(npb_turb_t, thermal_expansion);
+        static_assert(L1 == NPB_TURB_NCARRY, "lub_* carried members close the section");
+        npd4_store_turb_range<L0, L1>(st, t, t_old);
+        *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NPB_TURB_NCARRY + 3 / NPD_NPC, 3 % NPD_NPC) = (float)t.lub_effectiveness;
+      }
+      NPD4_STAMP(10);
+      NPD4_FLAG_WAIT(FL_TAIL, 1); NPD4_FLAG_WAIT(FL_CONDP, 1);
+      NPD4_STAMP(11);
       if (info_out) {   /* info (sim.py:199-250) */
         const double condenser_pressure = XR(Y_CONDP), electrical_power = XR(Y_TAIL + 0), thermal_efficiency = XR(Y_TAIL + 1);
         const double sg_avg_pressure_t = XR(Y_TAIL + 2), sg_total_steam_t = XR(Y_TAIL + 3), heat_rejection = XR(Y_TAIL + 5);
@@ -655,6 +725,7 @@ __device__ __forceinline__ void npd_step4_body(
         info[NPB_INFO_TURBINE_EFFICIENCY] = XR(Y_TAIL + 15); info[NPB_INFO_TURBINE_HP_POWER] = XR(Y_TAIL + 16); info[NPB_INFO_TURBINE_LP_POWER] = XR(Y_TAIL + 17);
         npd2_store_rows<NPB_INFO_DIM>(info, info_out, xch + Y_INFO * NPB_WAVE, lane, block_base, (size_t)n_plants);
       }
+      NPD4_STAMP(12);
     }
   }
   NPD4_STAMP(31);
