@@ -132,7 +132,7 @@ def step_kernel_name(n, storage="f64", forced=None, mode="full", maintenance=Fal
     if mode == "primary":
         return "npb_step_primary_kernel"
     if variant == 0:
-        variant = 2 if npad <= 57344 else (4 if npad * (8 if storage == "f64" else 4) > 90112 * 8 else 1)
+        variant = 5 if npad <= 32768 else (2 if npad <= 57344 else (4 if npad * (8 if storage == "f64" else 4) > 90112 * 8 else 1))
     m = "_maint" if (maintenance and mode == "full") else ""       # the builds with the automatic maintenance compiled in
     if variant == 4:
         return "npb_step_nt%s_kernel" % m

@@ -235,7 +235,9 @@ NPB_API int npb_set_diagnostics(NpbHandle *h, double *buf, size_t pitch);
  * 64 plants with an LDS-DMA staging pipeline, 2 = two wavefronts per 64 plants that own different subsystems (two builds of
  * it: the whole register file up to 32 768 plants, where a SIMD holds one wave anyway, 256 registers above), 3 = the
  * 256-register build at any size, 4 = the one-wavefront kernel with streaming (non-temporal) state stores, which 0 takes
- * above ~90 000 plants of fp64 storage, where nothing a step writes is still cached when the next step reads it. */
+ * above ~90 000 plants of fp64 storage, where nothing a step writes is still cached when the next step reads it, 5 = four
+ * wavefronts per 64 plants handing values to each other through progress words in LDS (what 0 takes up to 32 768 plants,
+ * where all of its 2 048 wavefronts are resident at once). */
 NPB_API int npb_set_step_kernel(NpbHandle *h, int variant);
 /* Which kernel the handle's last npb_step actually launched (NPB_KERNEL_NONE before the first step): the selection above is by
  * batch size, mode, storage and override, and a test or a benchmark that means to exercise one kernel asserts it here instead

@@ -777,18 +777,19 @@ extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t np
     return NPB_KERNEL_STEP_DIAG;
   }
   /* two kernels, one result (the same device functions in the same order per plant; tests/test_gpu_parity.py,
-   * test_the_two_step_kernels_agree).  The two-wave kernel
-   * (npd_step2.h) fills the chip from half the batch and has the shorter critical path; once the one-wave kernel has a
-   * wave for every SIMD (> ~57 k plants) its LDS-DMA pipeline wins (measured crossover).
+   * test_the_two_step_kernels_agree).  The more waves share a plant, the shorter the critical path of a step and the more of
+   * the chip a small batch fills: four waves (npd_step4.h) while they are all resident, two (npd_step2.h) up to ~57 k plants;
+   * once the one-wave kernel has a wave for every SIMD its LDS-DMA pipeline wins (measured crossovers).
    * variant: 0 = by batch size, 1 = one wave per 64 plants, 2 = two waves, 3 = their two-per-SIMD build, 4 = one wave with
-   * streaming state stores (what 0 picks once the sweep is far past the Infinity Cache).  The primary + steam-generator
+   * streaming state stores (what 0 picks once the sweep is far past the Infinity Cache), 5 = four waves (npd_step4.h: what 0
+   * picks while all its waves are resident at once, up to 32 768 plants).  The primary + steam-generator
    * mode always takes a one-wave kernel.  The return value names the kernel that was launched (npb_debug_last_step_kernel). */
   if (P->mode == NPB_MODE_PRIMARY) {
     hipLaunchKernelGGL(npb_step_primary_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, obs, reward, done, trip_flags, info);
     return NPB_KERNEL_STEP_PRIMARY;
   }
-  if (variant == 0) variant = npad <= 57344 ? 2 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1);
+  if (variant == 0) variant = npad <= 32768 ? 5 : (npad <= 57344 ? 2 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1));
   const bool with_maint = maint_rc != nullptr;     /* the builds with the automatic maintenance compiled in */
   if (variant == 4) {
     hipLaunchKernelGGL(with_maint ? npb_step_nt_maint_kernel : npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,

@@ -116,7 +116,8 @@ def test_bench_names_the_kernel_the_launcher_picks():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "nuclear_sim_amd", "csrc", "npb_kernels.hip")).read()
-    two_wave_up_to = int(re.search(r"variant = npad <= (\d+) \? 2", src).group(1))
+    four_wave_up_to = int(re.search(r"variant = npad <= (\d+) \? 5", src).group(1))
+    two_wave_up_to = int(re.search(r"\(npad <= (\d+) \? 2", src).group(1))
     nt_above = int(re.search(r"#define NPB_NT_STORE_ABOVE \(\(size_t\)(\d+)\)", src).group(1))
     wide_up_to = int(re.search(r"const bool wide = .* npad <= (\d+);", src).group(1))
     assert re.search(r"const bool wide = two_wave && variant == 2 && npad <= \d+;", src)      # variant 3 never takes the wide build
@@ -124,8 +125,10 @@ def test_bench_names_the_kernel_the_launcher_picks():
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     old = os.environ.pop("NPB_STEP_KERNEL", None)
     try:
-        assert bench.step_kernel_name(wide_up_to) == "npb_step2_wide_kernel"
-        assert bench.step_kernel_name(wide_up_to + 64) == "npb_step2_kernel"
+        assert four_wave_up_to == wide_up_to == 32768      # both are "every wave resident at once": 2 048 waves of 256 registers / 1 024 of 512
+        assert bench.step_kernel_name(64) == bench.step_kernel_name(four_wave_up_to) == "npb_step4_kernel"
+        assert bench.step_kernel_name(four_wave_up_to, maintenance=True) == "npb_step4_maint_kernel"
+        assert bench.step_kernel_name(four_wave_up_to + 64) == "npb_step2_kernel"
         assert bench.step_kernel_name(two_wave_up_to) == "npb_step2_kernel"
         assert bench.step_kernel_name(two_wave_up_to + 64) == "npb_step_kernel"
         assert bench.step_kernel_name(65536) == "npb_step_kernel"
@@ -139,6 +142,7 @@ def test_bench_names_the_kernel_the_launcher_picks():
             assert bench.step_kernel_name(n, forced="4") == "npb_step_nt_kernel"
             assert bench.step_kernel_name(n, forced="3") == "npb_step2_kernel"
             assert bench.step_kernel_name(n, forced="2") == ("npb_step2_wide_kernel" if n <= wide_up_to else "npb_step2_kernel")
+            assert bench.step_kernel_name(n, forced="5") == "npb_step4_kernel"
         os.environ["NPB_STEP_KERNEL"] = "3"
         assert bench.step_kernel_name(64) == "npb_step2_kernel"
     finally:

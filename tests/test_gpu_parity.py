@@ -54,7 +54,7 @@ def test_construction_state_matches_reference():
 
 # which kernel npb_step must have launched for a forced variant (include/npb.h npb_set_step_kernel) at a batch of <= 32 768
 # plants in full mode; 0 = by batch size
-KERNEL_OF_VARIANT = {0: "npb_step2_wide_kernel", 1: "npb_step_kernel", 2: "npb_step2_wide_kernel", 3: "npb_step2_kernel", 4: "npb_step_nt_kernel",
+KERNEL_OF_VARIANT = {0: "npb_step4_kernel", 1: "npb_step_kernel", 2: "npb_step2_wide_kernel", 3: "npb_step2_kernel", 4: "npb_step_nt_kernel",
                      5: "npb_step4_kernel"}
 # fixtures replayed on EVERY shipped step kernel: reactor and constant heat sources, load following, pump trips, the data-gen
 # runner with maintenance, handler promotion, fuzzed states (flags flipped, maintenance under fire), reset(), pump start / stop,
@@ -71,7 +71,7 @@ def test_hip_replays_golden(name):
     _replay_golden(name, 0)
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 @pytest.mark.parametrize("name", EVERY_KERNEL_FIXTURES)
 def test_hip_replays_golden_on_every_step_kernel(name, variant):
     """The reference's fixtures against each shipped step kernel, not only the one a 64-plant batch selects: the one-wave
@@ -681,11 +681,11 @@ def test_full_size_against_the_oracle_on_a_sample(oracle_lib, storage, n, T):
     those with their own inputs.  Every state member, observation, reward and flag of the sampled plants.  (fp32 storage: against
     the oracle with its state rounded to float after every step, the same algorithm.)  At 131 072 plants npb_step takes the
     streaming build of the one-wave kernel (two rounds of waves, state stores past the caches), at 40 960 the 256-register
-    build of the two-wave kernel (32 769 .. 57 344 plants), at 32 768 -- BASELINE config 4's share per GPU -- its
-    whole-register-file build; each run asserts that kernel."""
+    build of the two-wave kernel (32 769 .. 57 344 plants), at 32 768 -- BASELINE config 4's share per GPU -- the
+    four-wave kernel; each run asserts that kernel."""
     import torch
     import bench
-    want_kernel = {65536: "npb_step_kernel", 131072: "npb_step_nt_kernel", 40960: "npb_step2_kernel", 32768: "npb_step2_wide_kernel"}[n]
+    want_kernel = {65536: "npb_step_kernel", 131072: "npb_step_nt_kernel", 40960: "npb_step2_kernel", 32768: "npb_step4_kernel"}[n]
     assert bench.step_kernel_name(n, storage, forced="0") == want_kernel
     rng = np.random.default_rng(2024)
     sample = np.unique(np.concatenate([[0, 1, 63, 64, 65, 127, n - 65, n - 64, n - 1], rng.choice(n, 183, replace=False)]))

@@ -60,12 +60,12 @@ def summarize(out):
     total = 0.0
     for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         avg, cnt = counter_per_kernel(os.path.join(out, sub), counter)
-        touch = avg.get("npb_touch_kernel"); step = next((avg[k] for k in ("npb_step_kernel", "npb_step2_kernel", "npb_step2_wide_kernel") if k in avg), None)
+        touch = avg.get("npb_touch_kernel"); step = next((avg[k] for k in ("npb_step_kernel", "npb_step2_kernel", "npb_step2_wide_kernel", "npb_step4_kernel") if k in avg), None)
         if touch is None or step is None:
             res[counter] = "missing"; continue
         raw_unit_bytes = 1024.0  # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB
         scale = known / (touch * raw_unit_bytes)
-        res[counter] = {"touch_raw_kib": touch, "step_raw_kib": step, "launches": next((cnt[k] for k in ("npb_step_kernel", "npb_step2_kernel", "npb_step2_wide_kernel") if k in cnt), None),
+        res[counter] = {"touch_raw_kib": touch, "step_raw_kib": step, "launches": next((cnt[k] for k in ("npb_step_kernel", "npb_step2_kernel", "npb_step2_wide_kernel", "npb_step4_kernel") if k in cnt), None),
                         "calibration_scale": scale, "step_bytes_calibrated": step * raw_unit_bytes * scale}
         total += step * raw_unit_bytes * scale
     res["step_hbm_bytes_per_launch"] = total
@@ -83,7 +83,7 @@ def summarize_sq(out):
     res = {}
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if not row["Kernel_Name"].startswith(("npb_step_kernel", "npb_step2_kernel", "npb_step2_wide_kernel")):
+            if not row["Kernel_Name"].startswith(("npb_step_kernel", "npb_step2_kernel", "npb_step2_wide_kernel", "npb_step4_kernel")):
                 continue
             res.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
     print("%-28s %16s %14s" % ("counter", "per launch", "per wave"))
