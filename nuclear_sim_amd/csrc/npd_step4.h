@@ -13,15 +13,16 @@
  * progress word in LDS that the producer raises behind its data (a wave's LDS operations complete in order) and the consumer polls,
  * so each wave runs as far ahead as its inputs allow:
  *
- *   wave 3  prelude, level control -> pump 0 -> [pumps 1-3] pump tails, system level -> turbine section, stage efficiencies ->
- *           [SG 0-2] SG sums, stage pass A (publishing each stage's pressure as it is known) -> [pass B] stage chain -> rotor ->
- *           [stage post] protection, power gates, tail scalars
- *   wave 0  primary side -> [level control] pump 3 -> SG 0 part 1, [feedwater flow] part 2 -> pass B units 0,3,6,.. as pass A
- *           reaches them -> stage post 0,3,6,.. behind the chain -> [tail] observation, done, trip flags
- *   wave 1  chemistry sidecar -> [level control] pump 1 -> [primary] SG 1 -> units 1,4,.. -> stage post 1,4,.. -> [turbine exhaust] condenser ->
- *           [tail] reward, secondary write-back
- *   wave 2  [level control] pump 2 -> [primary] SG 2 -> units 2,5,.. -> stage post 2,5,.. -> turbine lubrication pre-step ->
- *           [tail, condenser] info
+ *   wave 3  prelude, level control -> pump 0 -> [pumps 1-3] pump tails, system level -> turbine section -> [SG 0-2] SG sums,
+ *           stage pass A (publishing each stage's pressure as it is known), its verdict -> pass B units 12-14 -> stage post 2,5,8,11
+ *           -> [chain] rotor -> [stage post] protection, power gates, tail scalars -> turbine section to the arena
+ *   wave 0  primary side -> [level control] pump 3 -> SG 0 part 1, [feedwater flow] part 2 -> pass B units 0,2,..,10 as pass A
+ *           reaches them -> [verdict] stage post 0,3,6,.. behind the chain -> [tail] observation, done, trip flags
+ *   wave 1  chemistry sidecar -> [level control] pump 1 -> [primary] SG 1 -> stage efficiencies -> the stage chain, each stage as
+ *           soon as its pass B unit is there (i.e. while pass A still runs) -> [verdict] -> turbine lubrication pre-step ->
+ *           [tail, condenser] reward, write-back
+ *   wave 2  [level control] pump 2 -> [primary] SG 2 -> units 1,3,..,11 -> [verdict] stage post 1,4,7,.. -> [chain] condenser ->
+ *           [tail] info
  *
  * ([..] = what the wave waits for.)  Exactness: every device function is the one the other kernels call, sums over pumps / steam
  * generators / stages are taken in the reference's order by one wave from the values the others publish, and the one sequential
@@ -48,15 +49,17 @@
 #endif
 /* progress words: one 16-byte cell each in slot Y_FLAGS; raised behind the data they announce, polled by the consumer */
 enum { FL_CHAIN = 0, FL_FWFLOW = 1, FL_PRIM = 2, FL_FWCTL = 3, FL_PUMP = 4 /* +pump */, FL_SG = 8 /* +sg */, FL_PASSA = 11, FL_UNIT = 12 /* +wave */,
-       FL_POST = 15 /* +wave */, FL_TURBOUT = 18, FL_TAIL = 19, FL_CONDP = 20, FL_LUBE = 21, FL_COUNT = 22 };
+       FL_POST = 15 /* +R */, FL_VERDICT = 18, FL_TAIL = 19, FL_CONDP = 20, FL_LUBE = 21, FL_CHAINDONE = 22, FL_COUNT = 23 };
 #define NPD4_FLAGP(n) ((volatile int *)&xch[Y_FLAGS * NPB_WAVE + 2 * (n)])
 /* (a wave's LDS operations execute in issue order, so the word needs no wait behind the data, only the compiler's respect) */
 #define NPD4_FLAG_SET(n, v) do { asm volatile("" ::: "memory"); *NPD4_FLAGP(n) = (v); asm volatile("" ::: "memory"); } while (0)
 #define NPD4_FLAG_WAIT(n, v) do { while (__builtin_amdgcn_readfirstlane(*NPD4_FLAGP(n)) < (v)) __builtin_amdgcn_s_sleep(1); asm volatile("" ::: "memory"); } while (0)
-/* pass B unit u (0 = the turbine inlet, k + 1 = stage k): wave u % 3 works through its units in rising order and counts them */
-#define NPD4_UNIT_WAIT(u) NPD4_FLAG_WAIT(FL_UNIT + (u) % 3, (u) / 3 + 1)
+/* pass B unit u (0 = the turbine inlet, k + 1 = stage k): up to 11 the even units are wave 0's and the odd ones wave 2's, the last
+ * three wave 3's own once its pass A is through; each wave works through its units in rising order and counts them */
+#define NPD4_UNIT_WAIT(u) do { if ((u) < 12) NPD4_FLAG_WAIT(FL_UNIT + (u) % 2, (u) / 2 + 1); else NPD4_FLAG_WAIT(FL_UNIT + 2, (u) - 11); } while (0)
 
 enum {
+  Y_EXTF = 0, Y_TIN = 5, Y_STEAM = 6, Y_CHRES = 7,   /* pass A / the chain's results, once the steam generators are done with this region */
   Y_CFLOW = 0, Y_CIN = 3, Y_COUT = 6, Y_LDF = 9, Y_FWTEMP = 10, Y_NPREV = 11, Y_FPP = 12, Y_MAXLVL = 13, Y_RUNCOUNT = 14, Y_FWFLOW = 15,
   Y_PRIM = 16,                                /* base reward, load demand, thermal power, reactivity, primary thermal power, scram bits */
   Y_TIME = 22, Y_FLAGS = 23, Y_MAINT_TAB = 24,
@@ -67,10 +70,10 @@ enum {
   Y_TOUT = 77,                                /* per stage, written by the chain (the SG results were summed before pass A) */
   Y_PSELF = 95, Y_PEXT = 109, Y_PIN = 114,
   Y_TAIL = 95,                                /* 21 tail scalars, after the chain (every pass B unit has been consumed) */
-  Y_LOADING = 116, Y_STRESS = 130, Y_EFFLOW = 138, Y_LP6H = 139, Y_CWT = 140, Y_CONDP = 141
+  Y_LOADING = 116, Y_STRESS = 130, Y_CWT = 140, Y_CONDP = 141
 };
 static_assert(Y_PUMP + 4 * X_PUMP_N <= Y_SG && Y_HGEXT + 5 <= Y_SG && Y_INFO + NPB_OBS_PAD <= Y_SG && Y_OBS + NPB_OBS_PAD <= Y_INFO && Y_SG + 18 <= Y_PSELF &&
-              Y_TOUT + 14 <= Y_PSELF && Y_TAIL + 21 <= Y_LOADING && Y_PIN < Y_LOADING && Y_LOADING + 14 <= Y_STRESS && Y_STRESS + 8 <= Y_EFFLOW &&
+              Y_TOUT + 14 <= Y_PSELF && Y_TAIL + 21 <= Y_LOADING && Y_PIN < Y_LOADING && Y_LOADING + 14 <= Y_STRESS && Y_STRESS + 8 <= Y_CWT && Y_CHRES + 7 <= Y_FWFLOW &&
               Y_CONDP < NPD4_SLOTS && 2 * FL_COUNT <= NPB_WAVE && NPD_MH_N + 8 <= NPB_WAVE, "exchange slot plan");
 
 /* carried members [K0, K1) of the turbine section back to the arena, with the other kernels' unchanged-column elision: the section
@@ -109,11 +112,15 @@ __device__ __forceinline__ void npd4_stage_preload(const npd_stage_t &st, npd4_o
 }
 template <int R>
 __device__ __forceinline__ void npd4_stage_post(const npd_stage_t &st, const npd4_old_t &old, double *xch, int lane, double tdt) {
+  /* the chain runs ahead of pass A's verdict on the fast path; the arena is only written once the verdict is in (a group that
+   * takes the sequential chain gets its stages a second time, counted from 100) */
+  NPD4_FLAG_WAIT(FL_VERDICT, 1);
+  const int base = (__builtin_amdgcn_readfirstlane(*NPD4_FLAGP(FL_VERDICT)) == 2) ? 100 : 0;
 #pragma unroll
   for (int j = 0; j < 5; j++) {
     const int k = R + 3 * j;
     if (k >= 14) continue;
-    NPD4_FLAG_WAIT(FL_CHAIN, k + 1);
+    NPD4_FLAG_WAIT(FL_CHAIN, base + k + 1);
     double stress = 0.0;
     npd2_stage_post_vals(st, k, old.eff_deg[j], old.deposit[j], old.blade_wear[j], old.rotor_t[j], old.casing_t[j], old.blade_t[j],
                          XR(Y_LOADING + (k < 14 ? k : 0)), XR(Y_TOUT + (k < 14 ? k : 0)), tdt, &stress);
@@ -124,14 +131,13 @@ __device__ __forceinline__ void npd4_stage_post(const npd_stage_t &st, const npd
 /* this wave's pass B units u = R, R + 3, .. (npd_stage_system_update's pass B, npd_turbine.h): each as soon as wave 3's pass A has
  * published the pressures it needs (progress word FL_PASSA: 1 = the inlet pressure, k + 2 = stage k's outlet and, where the stage
  * has one, its extraction pressure) */
-template <int R>
+template <int U0, int STEP, int COUNT, int WHOSE>
 __device__ __forceinline__ void npd4_pass_b_units(double *xch, int lane) {
 #define NPD_EXT_IDX(k) ((k) == 2 ? 0 : (k) == 3 ? 1 : (k) == 4 ? 2 : (k) == 8 ? 3 : 4)
 #define NPD_IS_EXT(k) ((k) == 2 || (k) == 3 || (k) == 4 || (k) == 8 || (k) == 9)
 #pragma unroll
-  for (int j = 0; j < 5; j++) {
-    const int u = R + 3 * j;
-    if (u > 14) continue;
+  for (int j = 0; j < COUNT; j++) {
+    const int u = U0 + STEP * j;
     if (u == 0) {
       NPD4_FLAG_WAIT(FL_PASSA, 1);
       const double sat = npd_tsat_antoine(XR(Y_PIN));
@@ -144,7 +150,7 @@ __device__ __forceinline__ void npd4_pass_b_units(double *xch, int lane) {
       XW(Y_SAT + u, sat); XW(Y_HG + u, npd_hg_from_tsat(sat)); XW(Y_TRATIO + (k >= 0 ? k : 0), npd_sqrt(npd_sqrt(pk / pkm)));
       if (NPD_IS_EXT(k)) XW(Y_HGEXT + NPD_EXT_IDX(k), npd_hg_from_tsat(npd_tsat_antoine(XR(Y_PEXT + NPD_EXT_IDX(k)))));
     }
-    NPD4_FLAG_SET(FL_UNIT + R, j + 1);
+    NPD4_FLAG_SET(FL_UNIT + WHOSE, j + 1);
   }
 #undef NPD_EXT_IDX
 #undef NPD_IS_EXT
@@ -292,7 +298,6 @@ __device__ __forceinline__ void npd_step4_body(
     NPD4_FLAG_WAIT(FL_PUMP + 1, 1); NPD4_FLAG_WAIT(FL_PUMP + 2, 1); NPD4_FLAG_WAIT(FL_PUMP + 3, 1);
     NPD4_STAMP(3);
     npb_turb_t t; npb_turb_t t_old;
-    double stage_eff[14];
     double fw_total_flow = 0.0, fw_total_power = 0.0;
     int fw_available = 0; uint32_t trip_flags = 0;
     /* ---- diagnostics + protection passes over the four pumps, system level (feedwater/physics.py:720-863) */
@@ -312,25 +317,17 @@ __device__ __forceinline__ void npd_step4_body(
     NPD4_FLAG_SET(FL_FWFLOW, 1);
     NPD4_STAMP(4);
     NPD4_ST_STORE(FW, npb_fw_t, fw, fw_old, 0);
-    /* while the steam generators run: the turbine section and the 14 stages' efficiency products (TurbineStage state as the
-     * previous step left it, stage_system.py:128-133, 294-339) */
+    /* while the steam generators run: the turbine section */
     NPD_ST_LOAD(TURB, npb_turb_t, t, 0);          /* wave 2 owns the lub_* members; they are neither used nor stored here */
     t_old = t;
-#pragma unroll
-    for (int k = 0; k < 14; k++) {
-      double fouling_factor = 1.0 / (1.0 + (double)NPD2_TSTG(stage_deposit_thickness, k) / 0.5);
-      double blade_wear_factor = (double)NPD2_TSTG(stage_blade_wear_factor, k);
-      double blade_condition_factor = npd_pymin(fouling_factor, blade_wear_factor);
-      double actual_efficiency = npd_pymax(0.7, 0.88 - (double)NPD2_TSTG(stage_efficiency_degradation, k));
-      stage_eff[k] = (actual_efficiency * blade_condition_factor * fouling_factor * blade_wear_factor * 1.0);
-    }
+    npd4_old_t old;
+    npd4_stage_preload<2>(st, old);               /* this wave's share of the stage post-pass: stages 2, 5, 8, 11 */
     NPD4_STAMP(5);
     NPD4_FLAG_WAIT(FL_SG + 0, 1); NPD4_FLAG_WAIT(FL_SG + 1, 1); NPD4_FLAG_WAIT(FL_SG + 2, 1);
     NPD4_STAMP(6);
     double sg_total_thermal = 0.0, sg_total_steam = 0.0, sg_avg_pressure = 0.0, sg_avg_temperature = 0.0, sg_avg_quality = 0.0;
     int sg_system_availability = 0;
     double pressure_stability_factor = 1.0, load_demand = 0.0;
-    double p_self[14], flow_out[14], ext_flow[5];
     bool seq = false;
     double sg_ap = 0.0, sg_at = 0.0, sg_aq = 0.0, sg_pressures[NPB_NUM_SG];
     int sg_effective = 0;
@@ -349,7 +346,7 @@ __device__ __forceinline__ void npd_step4_body(
     t.load_demand = load_demand;
     pressure_stability_factor = npd_pressure_stability_factor(sg_pressures);
     XW(Y_CWT, cooling_water_temperature);
-    XW(Y_PIN, sg_avg_pressure);
+    XW(Y_PIN, sg_avg_pressure); XW(Y_TIN, sg_avg_temperature); XW(Y_STEAM, sg_total_steam);
     NPD4_FLAG_SET(FL_PASSA, 1);
     {   /* stage pass A (npd2_stage_pass_a, npd_step2.h: pressures and flows, no transcendentals), each stage's outlet pressure
          * published as it is known so that the other waves' pass B runs behind this loop instead of behind its end */
@@ -377,78 +374,29 @@ __device__ __forceinline__ void npd_step4_body(
           ef = npd_clip(extraction_demand, 5.0, npd_pymin(50.0, cur_flow * 0.3));
           pe = cur_p * 0.7 + outlet_pressure * (1 - 0.7);
         }
-        if (NPD_IS_EXT(k)) { ext_flow[NPD_EXT_IDX(k)] = ef; XW(Y_PEXT + NPD_EXT_IDX(k), pe); }
-        p_self[k] = self_out;
-        flow_out[k] = cur_flow - ef;
+        if (NPD_IS_EXT(k)) { XW(Y_EXTF + NPD_EXT_IDX(k), ef); XW(Y_PEXT + NPD_EXT_IDX(k), pe); }
+        const double flow_out_k = cur_flow - ef;
         rare = rare || !(self_out >= 0.001 && self_out <= 22.0) || !(pe >= 0.001 && pe <= 22.0) || !(outlet_pressure >= 0.001);
-        cur_p = self_out; cur_flow = flow_out[k];
+        cur_p = self_out; cur_flow = flow_out_k;
         XW(Y_PSELF + k, self_out);
         NPD4_FLAG_SET(FL_PASSA, k + 2);
       }
-      seq = __builtin_amdgcn_ballot_w64(rare) != 0;   /* any lane off the fast path: the group takes the sequential chain (the others' pass B is then not used) */
+      seq = __builtin_amdgcn_ballot_w64(rare) != 0;   /* any lane off the fast path: the group takes the sequential chain (pass B and wave 1's chain so far are then not used) */
+      NPD4_FLAG_SET(FL_VERDICT, seq ? 2 : 1);
 #undef NPD_EXT_IDX
 #undef NPD_IS_EXT
     }
     NPD4_STAMP(7);
-    double stage_power_mw = 0.0, turbine_efficiency = 0.0, hp_power = 0.0, lp_power = 0.0, max_bearing_metal = 0.0, total_displacement = 0.0;
-    npd2_chain_t ch;
-    ch.T_in = sg_avg_temperature; ch.total_power = 0.0; ch.total_extraction = 0.0; ch.lp6_outlet_enthalpy = 0.0;
-    ch.hp_power = 0.0; ch.lp_power = 0.0; ch.h_in0 = 0.0;
-#define NPD_EXT_IDX(k) ((k) == 2 ? 0 : (k) == 3 ? 1 : (k) == 4 ? 2 : (k) == 8 ? 3 : 4)
-#define NPD_IS_EXT(k) ((k) == 2 || (k) == 3 || (k) == 4 || (k) == 8 || (k) == 9)
-    if (!seq) {
-      NPD4_UNIT_WAIT(0);                           /* the inlet's saturation state */
-      ch.sat_in = XR(Y_SAT + 0); ch.hg_in = XR(Y_HG + 0);
-#pragma unroll
-      for (int k = 0; k < 14; k++) {
-        const double p_in = (k == 0) ? sg_avg_pressure : p_self[k > 0 ? k - 1 : 0];
-        NPD4_UNIT_WAIT(k + 1);                     /* stage k's, and its extraction's if it has one */
-        const double sat_k = XR(Y_SAT + k + 1), hg_k = XR(Y_HG + k + 1), tr_k = XR(Y_TRATIO + k);
-        const double ef = NPD_IS_EXT(k) ? ext_flow[NPD_EXT_IDX(k)] : 0.0;
-        const double hgx = NPD_IS_EXT(k) ? XR(Y_HGEXT + NPD_EXT_IDX(k)) : 0.0;
-        double T_out, loading;
-        npd2_chain_stage(k, ch, p_in, p_self[k], sat_k, hg_k, tr_k, flow_out[k], ef, hgx, stage_eff[k], &T_out, &loading);
-        XW(Y_TOUT + k, T_out); XW(Y_LOADING + k, loading);
-        NPD4_FLAG_SET(FL_CHAIN, k + 1);
-      }
-      {   /* _steam_enthalpy at the last stage's outlet, whose saturation state pass B has */
-        const double T_c = npd_pymax(0.0, npd_pymin(ch.T_in, 800.0));
-        const double cp = (p_self[13] > 10.0) ? 2.5 : ((p_self[13] > 1.0) ? 2.2 : 2.0);
-        const double h_out = (T_c <= ch.sat_in) ? ch.hg_in : ch.hg_in + cp * (T_c - ch.sat_in);
-        if (sg_total_steam > 0) turbine_efficiency = (ch.h_in0 - h_out) / ch.h_in0;
-      }
-    } else {
-      double cur_p = sg_avg_pressure, cur_T = sg_avg_temperature, cur_flow = sg_total_steam;
-#pragma unroll
-      for (int k = 0; k < 14; k++) {
-        double T_out, loading;
-        npd2_seq_stage(k, cur_p, cur_T, cur_flow, sg_total_steam, load_demand, stage_eff[k], ch, &T_out, &loading);
-        XW(Y_TOUT + k, T_out); XW(Y_LOADING + k, loading);
-        NPD4_FLAG_SET(FL_CHAIN, k + 1);
-      }
-      if (sg_total_steam > 0) {
-        const double h_in = npd_stage_steam_enthalpy(sg_avg_temperature, sg_avg_pressure);
-        turbine_efficiency = (h_in - npd_stage_steam_enthalpy(cur_T, cur_p)) / h_in;
-      }
-    }
-#undef NPD_EXT_IDX
-#undef NPD_IS_EXT
-    stage_power_mw = ch.total_power * pressure_stability_factor;
-    hp_power = ch.hp_power; lp_power = ch.lp_power;
-    XW(Y_EFFLOW, sg_total_steam - ch.total_extraction); XW(Y_LP6H, ch.lp6_outlet_enthalpy);
+    npd4_pass_b_units<12, 1, 3, 2>(xch, lane);     /* the last three saturation states, which the other two waves would reach last */
+    npd4_stage_post<2>(st, old, xch, lane, tdt);
     NPD4_STAMP(8);
+    NPD4_FLAG_WAIT(FL_CHAINDONE, 1);               /* wave 1's chain: total power, extraction, efficiency ... */
+    const double stage_power_mw = XR(Y_CHRES + 0) * pressure_stability_factor;
+    const double turbine_efficiency = XR(Y_CHRES + 5), hp_power = XR(Y_CHRES + 3), lp_power = XR(Y_CHRES + 4);
+    double max_bearing_metal = 0.0, total_displacement = 0.0;
     npd_turbine_rotor(&t, stage_power_mw, sg_avg_temperature, load_demand, tdt, &max_bearing_metal, &total_displacement);
-    NPD4_FLAG_SET(FL_TURBOUT, 1);
-    {   /* the rotor's members are final: to the arena while the stage-post waves finish -- behind wave 2's load of the PREVIOUS
-         * step's rotor state for the lubrication pre-step (update_with_lubrication reads it before the rotor moves) */
-      constexpr int T0 = NPB_F64_SLOT(npb_turb_t, timer_overspeed), T1 = NPB_F64_SLOT(npb_turb_t, load_demand);
-      static_assert(T1 - T0 == 3 && NPB_F64_SLOT(npb_turb_t, lub_oil_temperature) == T1 + 1, "turbine section layout");
-      NPD4_FLAG_WAIT(FL_LUBE, 1);
-      npd4_store_turb_range<0, T0>(st, t, t_old);
-      npd4_store_turb_range<T1, T1 + 1>(st, t, t_old);
-    }
     NPD4_STAMP(9);
-    NPD4_FLAG_WAIT(FL_POST + 0, 1); NPD4_FLAG_WAIT(FL_POST + 1, 1); NPD4_FLAG_WAIT(FL_POST + 2, 1);
+    NPD4_FLAG_WAIT(FL_POST + 0, 1); NPD4_FLAG_WAIT(FL_POST + 1, 1);
     NPD4_STAMP(10);
     double max_stress = 0.0;      /* MetalTemperatureTracker's max over the rotor points, in their order */
 #pragma unroll
@@ -476,9 +424,12 @@ __device__ __forceinline__ void npd_step4_body(
     XW(Y_TAIL + 19, actual_feedwater_temp); XW(Y_TAIL + 20, (double)fw_available);
     NPD4_FLAG_SET(FL_TAIL, 1);
     NPD4_STAMP(11);
-    {   /* what the protection system moved: its timers, the narrow members but the lubrication's */
-      constexpr int T0 = NPB_F64_SLOT(npb_turb_t, timer_overspeed), T1 = NPB_F64_SLOT(npb_turb_t, load_demand);
-      npd4_store_turb_range<T0, T1>(st, t, t_old);
+    {   /* the turbine section but for the lubrication's members, behind the tail (nobody waits for it) and behind wave 2's load of
+         * the PREVIOUS step's rotor state for the lubrication pre-step (update_with_lubrication reads it before the rotor moves) */
+      constexpr int L0 = NPB_F64_SLOT(npb_turb_t, lub_oil_temperature);
+      static_assert(NPB_F64_SLOT(npb_turb_t, load_demand) + 1 == L0, "turbine section layout");
+      NPD4_FLAG_WAIT(FL_LUBE, 1);
+      npd4_store_turb_range<0, L0>(st, t, t_old);
       static_assert(NPB_TURB_NOUT == 4 && NPB_TURB_NI32 == 2, "turbine narrow layout");
       constexpr int NC = NPB_TURB_NCARRY;
       *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NC + 0 / NPD_NPC, 0 % NPD_NPC) = (float)t.thermal_expansion;
@@ -596,9 +547,89 @@ __device__ __forceinline__ void npd_step4_body(
     }
     NPD4_STAMP(6);
     npd4_old_t old;
-    if (wave == 0) { npd4_stage_preload<0>(st, old); NPD4_STAMP(7); npd4_pass_b_units<0>(xch, lane); NPD4_STAMP(8); npd4_stage_post<0>(st, old, xch, lane, tdt); }
-    else if (wave == 1) { npd4_stage_preload<1>(st, old); NPD4_STAMP(7); npd4_pass_b_units<1>(xch, lane); NPD4_STAMP(8); npd4_stage_post<1>(st, old, xch, lane, tdt); }
-    else { npd4_stage_preload<2>(st, old); NPD4_STAMP(7); npd4_pass_b_units<2>(xch, lane); NPD4_STAMP(8); npd4_stage_post<2>(st, old, xch, lane, tdt); }
+    npb_cond_t cd, cd_old; npb_chem_t chc, chc_old;   /* wave 2: the condenser's sections, loaded ahead of its stage post-pass */
+    if (wave == 1) {
+      /* ---- the stage chain (npd_stage_system_update's pass C, npd_turbine.h), behind the other waves' pass B units, i.e. while
+       * wave 3's pass A is still walking the later stages.  The 14 stages' efficiency products first (TurbineStage state as the
+       * previous step left it, stage_system.py:128-133, 294-339: loaded before any stage post-pass writes) */
+      double stage_eff[14];
+#pragma unroll
+      for (int k = 0; k < 14; k++) {
+        double fouling_factor = 1.0 / (1.0 + (double)NPD2_TSTG(stage_deposit_thickness, k) / 0.5);
+        double blade_wear_factor = (double)NPD2_TSTG(stage_blade_wear_factor, k);
+        double blade_condition_factor = npd_pymin(fouling_factor, blade_wear_factor);
+        double actual_efficiency = npd_pymax(0.7, 0.88 - (double)NPD2_TSTG(stage_efficiency_degradation, k));
+        stage_eff[k] = (actual_efficiency * blade_condition_factor * fouling_factor * blade_wear_factor * 1.0);
+      }
+      NPD4_STAMP(7);
+      NPD4_FLAG_WAIT(FL_PASSA, 1);
+      const double sg_avg_pressure = XR(Y_PIN), sg_avg_temperature = XR(Y_TIN), sg_total_steam = XR(Y_STEAM), load_demand = XR(Y_PRIM + 1);
+      npd2_chain_t ch;
+      ch.T_in = sg_avg_temperature; ch.total_power = 0.0; ch.total_extraction = 0.0; ch.lp6_outlet_enthalpy = 0.0;
+      ch.hp_power = 0.0; ch.lp_power = 0.0; ch.h_in0 = 0.0;
+      double turbine_efficiency = 0.0;   /* stage_system.py:983-993 (info only) */
+#define NPD_EXT_IDX(k) ((k) == 2 ? 0 : (k) == 3 ? 1 : (k) == 4 ? 2 : (k) == 8 ? 3 : 4)
+#define NPD_IS_EXT(k) ((k) == 2 || (k) == 3 || (k) == 4 || (k) == 8 || (k) == 9)
+      {   /* the fast path, ahead of pass A's verdict (a group that turns out to need the sequential chain runs it below) */
+        NPD4_UNIT_WAIT(0);                           /* the inlet's saturation state */
+        ch.sat_in = XR(Y_SAT + 0); ch.hg_in = XR(Y_HG + 0);
+        double cur_flow = sg_total_steam;
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+          NPD4_UNIT_WAIT(k + 1);                     /* stage k's, and its extraction's if it has one (pass A has then published stage k) */
+          const double p_in = (k == 0) ? sg_avg_pressure : XR(Y_PSELF + (k > 0 ? k - 1 : 0)), p_self_k = XR(Y_PSELF + k);
+          const double sat_k = XR(Y_SAT + k + 1), hg_k = XR(Y_HG + k + 1), tr_k = XR(Y_TRATIO + k);
+          const double ef = NPD_IS_EXT(k) ? XR(Y_EXTF + NPD_EXT_IDX(k)) : 0.0;
+          const double hgx = NPD_IS_EXT(k) ? XR(Y_HGEXT + NPD_EXT_IDX(k)) : 0.0;
+          const double flow_out_k = cur_flow - ef;   /* pass A's own recurrence (npd2_stage_pass_a) */
+          cur_flow = flow_out_k;
+          double T_out, loading;
+          npd2_chain_stage(k, ch, p_in, p_self_k, sat_k, hg_k, tr_k, flow_out_k, ef, hgx, stage_eff[k], &T_out, &loading);
+          XW(Y_TOUT + k, T_out); XW(Y_LOADING + k, loading);
+          NPD4_FLAG_SET(FL_CHAIN, k + 1);
+        }
+        {   /* _steam_enthalpy at the last stage's outlet, whose saturation state pass B has */
+          const double p13 = XR(Y_PSELF + 13);
+          const double T_c = npd_pymax(0.0, npd_pymin(ch.T_in, 800.0));
+          const double cp = (p13 > 10.0) ? 2.5 : ((p13 > 1.0) ? 2.2 : 2.0);
+          const double h_out = (T_c <= ch.sat_in) ? ch.hg_in : ch.hg_in + cp * (T_c - ch.sat_in);
+          if (sg_total_steam > 0) turbine_efficiency = (ch.h_in0 - h_out) / ch.h_in0;
+        }
+      }
+      NPD4_FLAG_WAIT(FL_VERDICT, 1);
+      if (__builtin_amdgcn_readfirstlane(*NPD4_FLAGP(FL_VERDICT)) == 2) {   /* some lane left the fast path's assumptions: the reference's own order, stage by stage */
+        ch.T_in = sg_avg_temperature; ch.total_power = 0.0; ch.total_extraction = 0.0; ch.lp6_outlet_enthalpy = 0.0;
+        ch.hp_power = 0.0; ch.lp_power = 0.0; ch.h_in0 = 0.0;
+        turbine_efficiency = 0.0;
+        double cur_p = sg_avg_pressure, cur_T = sg_avg_temperature, cur_flow = sg_total_steam;
+#pragma unroll
+        for (int k = 0; k < 14; k++) {
+          double T_out, loading;
+          npd2_seq_stage(k, cur_p, cur_T, cur_flow, sg_total_steam, load_demand, stage_eff[k], ch, &T_out, &loading);
+          XW(Y_TOUT + k, T_out); XW(Y_LOADING + k, loading);
+          NPD4_FLAG_SET(FL_CHAIN, 100 + k + 1);
+        }
+        if (sg_total_steam > 0) {
+          const double h_in = npd_stage_steam_enthalpy(sg_avg_temperature, sg_avg_pressure);
+          turbine_efficiency = (h_in - npd_stage_steam_enthalpy(cur_T, cur_p)) / h_in;
+        }
+      }
+#undef NPD_EXT_IDX
+#undef NPD_IS_EXT
+      XW(Y_CHRES + 0, ch.total_power); XW(Y_CHRES + 1, ch.total_extraction); XW(Y_CHRES + 2, ch.lp6_outlet_enthalpy);
+      XW(Y_CHRES + 3, ch.hp_power); XW(Y_CHRES + 4, ch.lp_power); XW(Y_CHRES + 5, turbine_efficiency);
+      XW(Y_CHRES + 6, sg_total_steam - ch.total_extraction);     /* the effective steam flow the condenser sees */
+      NPD4_FLAG_SET(FL_CHAINDONE, 1);
+      NPD4_STAMP(8);
+    } else if (wave == 0) {
+      npd4_stage_preload<0>(st, old); NPD4_STAMP(7); npd4_pass_b_units<0, 2, 6, 0>(xch, lane); NPD4_STAMP(8); npd4_stage_post<0>(st, old, xch, lane, tdt);
+    } else {
+      npd4_stage_preload<1>(st, old); NPD4_STAMP(7); npd4_pass_b_units<1, 2, 6, 1>(xch, lane); NPD4_STAMP(8);
+      NPD_ST_LOAD(COND, npb_cond_t, cd, 0);        /* for the condenser, which this wave runs as soon as the chain is through */
+      NPD_ST_LOAD(CHEM, npb_chem_t, chc, 1);
+      cd_old = cd; chc_old = chc;
+      npd4_stage_post<1>(st, old, xch, lane, tdt);
+    }
     NPD4_STAMP(9);
     if (wave == 0) {
       /* ---- observation, done, trip flags: the primary part (sim.py:290-333) from the primary section as stored by this wave
@@ -635,31 +666,23 @@ __device__ __forceinline__ void npd_step4_body(
       if (obs_out) npd2_store_rows<NPB_OBS_DIM>(obs, obs_out, xch + Y_OBS * NPB_WAVE, lane, block_base, (size_t)n_plants);
       NPD4_STAMP(11);
     } else if (wave == 1) {
-      npb_cond_t cd; npb_chem_t chc;
-      NPD_ST_LOAD(COND, npb_cond_t, cd, 0);
-      NPD_ST_LOAD(CHEM, npb_chem_t, chc, 1);
-      const npb_cond_t cd_old = cd; const npb_chem_t chc_old = chc;
-      NPD4_FLAG_WAIT(FL_TURBOUT, 1);
-      NPD4_STAMP(10);
-      /* ---- condenser (secondary/__init__.py:591-621) */
-      const double effective_steam_flow = XR(Y_EFFLOW), lp6_outlet_enthalpy = XR(Y_LP6H), cwt = XR(Y_CWT);
-      double lp_exhaust_quality = 0.90;
+      /* ---- turbine lubrication pre-step: reads the PREVIOUS step's rotor / bearing members (wave 3 holds its store of them back
+       * until they have landed here), owns the lub_* ones */
       {
-        double h_f = npd_cond_hf(0.007), h_g = npd_cond_hg(0.007);
-        double h_fg = h_g - h_f;
-        if (h_fg > 0) {
-          lp_exhaust_quality = (lp6_outlet_enthalpy - h_f) / h_fg;
-          lp_exhaust_quality = npd_pymax(0.0, npd_pymin(1.0, lp_exhaust_quality));
-        }
+        npb_turb_t t;
+        NPD_ST_LOAD(TURB, npb_turb_t, t, 0);
+        const npb_turb_t t_old = t;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NPD4_FLAG_SET(FL_LUBE, 1);
+        npd_turbine_lube(&t, tdt);
+        constexpr int L0 = NPB_F64_SLOT(npb_turb_t, lub_oil_temperature), L1 = NPB_F64_SLOT(npb_turb_t, thermal_expansion);
+        static_assert(L1 == NPB_TURB_NCARRY, "lub_* carried members close the section");
+        npd4_store_turb_range<L0, L1>(st, t, t_old);
+        *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NPB_TURB_NCARRY + 3 / NPD_NPC, 3 % NPD_NPC) = (float)t.lub_effectiveness;
       }
-      npd_condenser_result_t cr;
-      npd_condenser_update(&cd, &chc, 0.007, effective_steam_flow, lp_exhaust_quality, 45000.0, cwt, 1.2, 185.0, tdt, &cr);
-      NPD4_ST_STORE(COND, npb_cond_t, cd, cd_old, 0);
-      NPD4_ST_STORE(CHEM, npb_chem_t, chc, chc_old, 1);
-      XW(Y_CONDP, cr.condenser_pressure);
-      NPD4_FLAG_SET(FL_CONDP, 1);
+      NPD4_STAMP(10);
       NPD4_STAMP(11);
-      NPD4_FLAG_WAIT(FL_TAIL, 1);
+      NPD4_FLAG_WAIT(FL_TAIL, 1); NPD4_FLAG_WAIT(FL_CONDP, 1);
       NPD4_STAMP(12);
       /* ---- reward (sim.py:521-542), secondary-level state write-back, feedback into the primary state (sim.py:429-498) */
       const double condenser_pressure = XR(Y_CONDP);
@@ -691,20 +714,24 @@ __device__ __forceinline__ void npd_step4_body(
       NPD_ST_F64(PRIM, npb_prim_t, last_heat_removal_factor, 0, 0) = (npd_real_t)heat_removal_factor;
       NPD4_STAMP(13);
     } else {
-      /* ---- turbine lubrication pre-step: reads the PREVIOUS step's rotor / bearing members (wave 3 holds its store of them back
-       * until they have landed here), owns the lub_* ones */
+      NPD4_FLAG_WAIT(FL_CHAINDONE, 1);
+      /* ---- condenser (secondary/__init__.py:591-621) */
+      const double effective_steam_flow = XR(Y_CHRES + 6), lp6_outlet_enthalpy = XR(Y_CHRES + 2), cwt = XR(Y_CWT);
+      double lp_exhaust_quality = 0.90;
       {
-        npb_turb_t t;
-        NPD_ST_LOAD(TURB, npb_turb_t, t, 0);
-        const npb_turb_t t_old = t;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        NPD4_FLAG_SET(FL_LUBE, 1);
-        npd_turbine_lube(&t, tdt);
-        constexpr int L0 = NPB_F64_SLOT(npb_turb_t, lub_oil_temperature), L1 = NPB_F64_SLOT(npb_turb_t, thermal_expansion);
-        static_assert(L1 == NPB_TURB_NCARRY, "lub_* carried members close the section");
-        npd4_store_turb_range<L0, L1>(st, t, t_old);
-        *NPD_NP(float, NPD_SEC_COL(TURB, 0) + NPB_TURB_NCARRY + 3 / NPD_NPC, 3 % NPD_NPC) = (float)t.lub_effectiveness;
+        double h_f = npd_cond_hf(0.007), h_g = npd_cond_hg(0.007);
+        double h_fg = h_g - h_f;
+        if (h_fg > 0) {
+          lp_exhaust_quality = (lp6_outlet_enthalpy - h_f) / h_fg;
+          lp_exhaust_quality = npd_pymax(0.0, npd_pymin(1.0, lp_exhaust_quality));
+        }
       }
+      npd_condenser_result_t cr;
+      npd_condenser_update(&cd, &chc, 0.007, effective_steam_flow, lp_exhaust_quality, 45000.0, cwt, 1.2, 185.0, tdt, &cr);
+      XW(Y_CONDP, cr.condenser_pressure);
+      NPD4_FLAG_SET(FL_CONDP, 1);
+      NPD4_ST_STORE(COND, npb_cond_t, cd, cd_old, 0);
+      NPD4_ST_STORE(CHEM, npb_chem_t, chc, chc_old, 1);
       NPD4_STAMP(10);
       NPD4_FLAG_WAIT(FL_TAIL, 1); NPD4_FLAG_WAIT(FL_CONDP, 1);
       NPD4_STAMP(11);

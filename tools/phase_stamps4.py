@@ -15,14 +15,15 @@ os.environ["NPB_STEP_KERNEL"] = "5"
 
 # stamp k of each wave (npd_step4.h, NPD4_STAMP): what the wave did between stamp k-1 and stamp k ("wait: ..." = polling a progress word)
 LABELS = {
-    0: ["primary side", "pump 3", "wait: primary (own)", "SG 0 part 1", "wait: feedwater flow", "SG 0 part 2", "stage arrays preload", "pass B units",
-        "stage post (behind the chain)", "wait: tail", "observation, flags"],
-    1: ["chemistry sidecar", "wait: level control; pump 1", "wait: primary", "SG 1 part 1", "wait: feedwater flow", "SG 1 part 2", "stage arrays preload", "pass B units",
-        "stage post (behind the chain)", "load condenser; wait: turbine exhaust", "condenser", "wait: tail", "reward, write-back"],
-    2: ["-", "wait: level control; pump 2", "wait: primary", "SG 2 part 1", "wait: feedwater flow", "SG 2 part 2", "stage arrays preload", "pass B units",
-        "stage post (behind the chain)", "turbine lubrication pre-step", "wait: tail, condenser", "info"],
-    3: ["prelude, level control", "pump 0", "wait: pumps 1-3", "pump tails, system level", "fw store, turbine load, stage efficiencies",
-        "wait: steam generators", "SG sums, stage pass A", "stage chain (behind pass B)", "rotor, store of its members", "wait: stage post", "protection, store, gates, tail"],
+    0: ["primary side", "pump 3", "wait: primary (own)", "SG 0 part 1", "wait: feedwater flow", "SG 0 part 2", "stage arrays preload", "pass B units 0,2,..",
+        "wait: verdict; stage post (behind the chain)", "wait: tail", "observation, flags"],
+    1: ["chemistry sidecar", "wait: level control; pump 1", "wait: primary", "SG 1 part 1", "wait: feedwater flow", "SG 1 part 2", "stage efficiencies",
+        "stage chain (behind pass B), wait: verdict", "-", "turbine lubrication pre-step", "-", "wait: tail, condenser", "reward, write-back"],
+    2: ["-", "wait: level control; pump 2", "wait: primary", "SG 2 part 1", "wait: feedwater flow", "SG 2 part 2", "stage arrays preload", "pass B units 1,3,..",
+        "load condenser; wait: verdict; stage post (behind the chain)", "wait: chain; condenser", "wait: tail", "info"],
+    3: ["prelude, level control", "pump 0", "wait: pumps 1-3", "pump tails, system level", "fw store, turbine load, stage arrays preload",
+        "wait: steam generators", "SG sums, stage pass A, verdict", "pass B units 12-14, stage post 2,5,8,11 (behind the chain)", "wait: chain; rotor", "wait: stage post",
+        "protection, gates, tail"],
 }
 
 
