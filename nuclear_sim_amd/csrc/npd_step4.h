@@ -159,9 +159,11 @@ __device__ __forceinline__ void npd4_pass_b_units(double *xch, int lane) {
 /* pump i of FeedwaterPumpSystem.update_system, by whichever wave has it: waits for the level control's hand-out (and, with the
  * automatic maintenance, for the plants' clock from the primary side); if the demand gate could close (npd_step2.h), for the pump
  * before it and its count */
-#define NPD4_PUMP(i_) \
+#define NPD4_PUMP(i_, BEFORE_THE_STORE) \
   { \
     const int i = (i_); \
+    npb_pump_t pm; \
+    NPD_ST_LOAD(PUMP, npb_pump_t, pm, i);      /* on its way while this wave polls */ \
     NPD4_FLAG_WAIT(FL_FWCTL, 1); \
     if (maint) NPD4_FLAG_WAIT(FL_PRIM, 1); \
     const int n_prev_running = (int)XR(Y_NPREV); \
@@ -172,8 +174,6 @@ __device__ __forceinline__ void npd4_pass_b_units(double *xch, int lane) {
     if (maint) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); npd_maint_cache_landed(maint_cache); } \
     const uint32_t cooling_mask = (i & 1) ? maint_cache.z : maint_cache.x; \
     const float cooling_until = __uint_as_float((i & 1) ? maint_cache.w : maint_cache.y); \
-    npb_pump_t pm; \
-    NPD_ST_LOAD(PUMP, npb_pump_t, pm, i); \
     const npb_pump_t pm_old = pm; \
     if (!serial_pumps) { \
       npd2_pump(&pm, 1, n_prev_running, flow_per_pump, &sc, dt);        /* the gate cannot close: its outcome needs no count */ \
@@ -195,6 +195,7 @@ __device__ __forceinline__ void npd4_pass_b_units(double *xch, int lane) {
     if (maint) {   /* anything new at this pump, for any plant of the group?  (npd_maintenance.h) */ \
       if (__builtin_amdgcn_ballot_w64(npd_maint_pump_hit(&pm, maint_tab, cooling_mask, cooling_until, maint_time)) != 0) maint_hit_bits |= 1u << i; \
     } \
+    BEFORE_THE_STORE; \
     NPD4_ST_STORE(PUMP, npb_pump_t, pm, pm_old, i); \
   }
 
@@ -293,7 +294,7 @@ __device__ __forceinline__ void npd_step4_body(
     if (maint && lane < NPD_MH_N) maint_tab[lane] = maint_entry;
     NPD4_FLAG_SET(FL_FWCTL, 1);
     NPD4_STAMP(1);
-    NPD4_PUMP(0);
+    NPD4_PUMP(0, (void)0);
     NPD4_STAMP(2);
     NPD4_FLAG_WAIT(FL_PUMP + 1, 1); NPD4_FLAG_WAIT(FL_PUMP + 2, 1); NPD4_FLAG_WAIT(FL_PUMP + 3, 1);
     NPD4_STAMP(3);
@@ -316,9 +317,9 @@ __device__ __forceinline__ void npd_step4_body(
     XW(Y_FWFLOW, fw_total_flow);
     NPD4_FLAG_SET(FL_FWFLOW, 1);
     NPD4_STAMP(4);
+    /* while the steam generators run: the turbine section (asked for before the feedwater section goes back) */
+    NPD_ST_LOAD(TURB, npb_turb_t, t, 0);          /* wave 1 owns the lub_* members; they are neither used nor stored here */
     NPD4_ST_STORE(FW, npb_fw_t, fw, fw_old, 0);
-    /* while the steam generators run: the turbine section */
-    NPD_ST_LOAD(TURB, npb_turb_t, t, 0);          /* wave 2 owns the lub_* members; they are neither used nor stored here */
     t_old = t;
     npd4_old_t old;
     npd4_stage_preload<2>(st, old);               /* this wave's share of the stage post-pass: stages 2, 5, 8, 11 */
@@ -511,7 +512,8 @@ __device__ __forceinline__ void npd_step4_body(
       }
     }
     NPD4_STAMP(1);
-    NPD4_PUMP(my_pump);
+    npb_sg_t g;                                       /* this wave's steam generator: its section is asked for before the pump's goes back */
+    NPD4_PUMP(my_pump, NPD_ST_LOAD(SG, npb_sg_t, g, wave));
     NPD4_STAMP(2);
     {
       const int i = wave;
@@ -524,8 +526,6 @@ __device__ __forceinline__ void npd_step4_body(
       total_primary_flow += XR(Y_CFLOW + 0); total_primary_flow += XR(Y_CFLOW + 1); total_primary_flow += XR(Y_CFLOW + 2);
       const double actual_total_steam_flow = P.sg_design_total_steam_flow * load_demand_fraction;
       const double demand = (total_primary_flow > 0) ? actual_total_steam_flow * (c_flow / total_primary_flow) : actual_total_steam_flow / NPB_NUM_SG;
-      npb_sg_t g;
-      NPD_ST_LOAD(SG, npb_sg_t, g, i);
       const npb_sg_t g_old = g;
       const double level_old = (double)NPD_ST_F64(SEC, npb_sec_t, prev_sg_levels, 0, i);
       const double heat_transfer = npd_sg_part1(&g, &P, c_in, c_out, c_flow, dt * 60);
