@@ -6,15 +6,22 @@ provider's `get_state_dict()` and `pd.concat`s the row (simulator/state/state_ma
 Here a sample is one gather kernel (`npb_gather_fields`): the chosen members of every plant, widened to double, land
 in a device buffer `[sample, field, plant]`; nothing touches the host until `table()` / `write_parquet()`.
 
-Columns carry the reference's own log names: `state_names.json` (made by running the reference through three eventful
-runs and matching whole series value for value; the generator script is named in DESIGN.md section 6) maps 265 of the reference's 784
-numeric log columns onto 193 state members -- several log columns can show one member (the reference logs the total
-feedwater flow three times), a few through a unit factor -- and `derived_log_columns()` adds the columns that are plain
-functions of the end-of-step state (pump performance factors, wear sums, steam-generator system averages, TSP deposit
-aggregates, level-control errors).  `StateLog(env)` without a field list records the members all of these need and `table()`
-emits every such column; members selected by name that the reference does not log come
-out as `npb.<section>.<member>`.  Not reproduced: the reference's diagnostics that are left over from inside the step (per-stage turbine conditions, SG
-capacities and heat fluxes, bearing loads ...: ~225 columns) and the 268 columns that never vary in any of the runs.
+Columns carry the reference's own log names, all 784 of its numeric log columns (checked at every step against the reference's
+own log of a quiet and of an eventful run, tests/test_gpu_parity.py):
+  * `state_names.json` (made by running the reference through three eventful runs and matching whole series value for value; the
+    generator script is named in DESIGN.md section 6) maps 276 log columns onto state members -- several log columns can show one
+    member (the reference logs the total feedwater flow three times), a few through a unit factor, the idle spare pump by analogy;
+  * `derived_log_columns()`: 99 columns that are plain functions of the end-of-step state (pump performance factors, wear sums,
+    steam-generator system averages, TSP deposit aggregates, level-control errors ...);
+  * `result_log_columns()`: 15 keys of the step's secondary result; `clock_log_columns()`: 4 step counters;
+  * `_all_diagnostic_columns()`: 137 step-internal values from the diagnostics build of the step kernel (`StateLog(env,
+    diagnostics=True)`: per-stage turbine conditions, SG capacities and heat fluxes, pump health, alarm counts, bearing oil
+    temperatures ...);
+  * `history_log_columns()`: 1 column that is a window over another logged column's history (emitted when the log holds every
+    step since the reset);
+  * `constant_log_columns()`: 252 columns that hold one value in every row of both reference logs, with that value.
+`StateLog(env)` without a field list records the members all of these need and `table()` emits every such column; members
+selected by name that the reference does not log come out as `npb.<section>.<member>`.
 
     log = StateLog(env, fields=["pump.oil_level", "sec.electrical_power_output"], every=12, capacity=64)
     for t in range(steps):
