@@ -127,16 +127,16 @@ def step_kernel_name(n, storage="f64", forced=None, mode="full", maintenance=Fal
     tests/test_abi.py and the GPU tests hold the two together."""
     if forced is None:
         forced = os.environ.get("NPB_STEP_KERNEL", "0")
-    variant = int(forced) if str(forced) in ("1", "2", "3", "4", "5") else 0
+    variant = int(forced) if str(forced) in ("1", "2", "3", "4", "5", "6") else 0
     npad = (n + 63) // 64 * 64
     if mode == "primary":
         return "npb_step_primary_kernel"
     if variant == 0:
-        variant = 5 if npad <= 32768 else (2 if npad <= 57344 else (4 if npad * (8 if storage == "f64" else 4) > 90112 * 8 else 1))
+        variant = 5 if npad <= 32768 else (2 if npad <= 57344 else (1 if npad <= 65536 else (6 if npad <= 98304 else (4 if npad * (8 if storage == "f64" else 4) > 90112 * 8 else 1))))
     m = "_maint" if (maintenance and mode == "full") else ""       # the builds with the automatic maintenance compiled in
     if variant == 4:
         return "npb_step_nt%s_kernel" % m
-    if variant == 5 and mode == "full":
+    if variant in (5, 6) and mode == "full":
         return "npb_step4%s_kernel" % m
     if variant in (2, 3) and mode == "full":
         return ("npb_step2_wide%s_kernel" if (variant == 2 and npad <= 32768) else "npb_step2%s_kernel") % m

@@ -737,6 +737,9 @@ extern "C" void NPB_LAUNCHER(field_set)(void *arena, size_t npad, int col, int s
 /* fp64-storage plants above which the sweep of a step (4 221 B per plant) is so far past the 256 MB Infinity Cache that streaming
  * state stores win (measured: even at 81 920, -5 % at 98 304, -10 % at 131 072); fp32 storage moves half the bytes */
 #define NPB_NT_STORE_ABOVE ((size_t)90112)
+/* plants (of either storage type) up to which a batch past one round of the one-wave kernel's waves goes to the four-wave kernel in
+ * several launches instead (three launches; measured: 98 304 plants 0.158 ms against the streaming build's 0.177; four launches at 106 496: 0.204) */
+#define NPB_SHARED_UP_TO ((size_t)98304)
 /* the table as the step kernels' pump phase evaluates it (npd_maintenance.h): a strict comparison as the sign of fma(value, sgn, c);
  * any other comparison kind in the scan makes every (wave, pump) "look properly" */
 static void npd_maint_fold_table(const npb_params_t *P, const npb_maint_table_t *T, npd_maint_hot_t *H) {
@@ -782,24 +785,36 @@ extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t np
    * once the one-wave kernel has a wave for every SIMD its LDS-DMA pipeline wins (measured crossovers).
    * variant: 0 = by batch size, 1 = one wave per 64 plants, 2 = two waves, 3 = their two-per-SIMD build, 4 = one wave with
    * streaming state stores (what 0 picks once the sweep is far past the Infinity Cache), 5 = four waves (npd_step4.h: what 0
-   * picks while all its waves are resident at once, up to 32 768 plants).  The primary + steam-generator
+   * picks while all its waves are resident at once, up to 32 768 plants), 6 = the same in launches of at most 32 768 plants (what 0
+   * picks between 65 537 and 98 304 plants).  The return value's low byte names the kernel, the next byte the number of launches.
+   * The primary + steam-generator
    * mode always takes a one-wave kernel.  The return value names the kernel that was launched (npb_debug_last_step_kernel). */
   if (P->mode == NPB_MODE_PRIMARY) {
     hipLaunchKernelGGL(npb_step_primary_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, obs, reward, done, trip_flags, info);
     return NPB_KERNEL_STEP_PRIMARY;
   }
-  if (variant == 0) variant = npad <= 32768 ? 5 : (npad <= 57344 ? 2 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1));
+  if (variant == 0) variant = npad <= 32768 ? 5 : (npad <= 57344 ? 2 : (npad <= 65536 ? 1 : (npad <= NPB_SHARED_UP_TO ? 6 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1))));
   const bool with_maint = maint_rc != nullptr;     /* the builds with the automatic maintenance compiled in */
   if (variant == 4) {
     hipLaunchKernelGGL(with_maint ? npb_step_nt_maint_kernel : npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
     return with_maint ? NPB_KERNEL_STEP_NT_MAINT : NPB_KERNEL_STEP_NT;
   }
-  if (variant == 5 && P->mode == NPB_MODE_FULL) {     /* four waves per 64 plants (npd_step4.h) */
-    hipLaunchKernelGGL(with_maint ? npb_step4_maint_kernel : npb_step4_kernel, grid, dim3(NPD4_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
-                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
-    return with_maint ? NPB_KERNEL_STEP4_MAINT : NPB_KERNEL_STEP4;
+  if ((variant == 5 || variant == 6) && P->mode == NPB_MODE_FULL) {
+    /* four waves per 64 plants (npd_step4.h).  Variant 6: in launches of at most 32 768 plants each, so that every wave of a launch
+     * is resident at once: past 65 536 plants the one-wave kernel needs a second round of waves (69 632 plants: 0.166 ms), three
+     * such launches step 81 920 plants in 0.140 ms (profiles/r3_shared_launches.txt, which is about the sizes where
+     * this does NOT pay).  The launches share the batch in runs of NPD4_RUN groups of 64 plants. */
+    const size_t groups = npad / NPB_WAVE;
+    const uint32_t parts = variant == 6 ? (uint32_t)((npad + 32767) / 32768) : 1;
+    for (uint32_t part = 0; part < parts; part++) {
+      const size_t grid4 = parts == 1 ? groups : (groups + (size_t)NPD4_RUN * parts - 1) / ((size_t)NPD4_RUN * parts) * NPD4_RUN;
+      hipLaunchKernelGGL(with_maint ? npb_step4_maint_kernel : npb_step4_kernel, dim3((unsigned)grid4), dim3(NPD4_THREADS), 0, stream, *P, n_plants, npad,
+                         (npd_real_t *)arena, action, magnitude, setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC,
+                         parts == 1 ? 0u : (part | (parts << 8)));
+    }
+    return (with_maint ? NPB_KERNEL_STEP4_MAINT : NPB_KERNEL_STEP4) | ((int)parts << 8);
   }
   const bool two_wave = (variant == 2 || variant == 3) && P->mode == NPB_MODE_FULL;
   const bool wide = two_wave && variant == 2 && npad <= 32768;   /* the whole register file while one wave per SIMD is all there is; variant 3 = never */

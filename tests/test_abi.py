@@ -132,8 +132,11 @@ def test_bench_names_the_kernel_the_launcher_picks():
         assert bench.step_kernel_name(two_wave_up_to) == "npb_step2_kernel"
         assert bench.step_kernel_name(two_wave_up_to + 64) == "npb_step_kernel"
         assert bench.step_kernel_name(65536) == "npb_step_kernel"
-        assert bench.step_kernel_name(nt_above) == "npb_step_kernel"
-        assert bench.step_kernel_name(nt_above + 64) == "npb_step_nt_kernel"
+        # past one round of the one-wave kernel's waves: the four-wave kernel in several launches, then the streaming build
+        shared_up_to = int(re.search(r"#define NPB_SHARED_UP_TO \(\(size_t\)(\d+)\)", src).group(1))
+        assert re.search(r"\(npad <= 65536 \? 1 : \(npad <= NPB_SHARED_UP_TO \? 6", src) and shared_up_to > nt_above
+        assert bench.step_kernel_name(65536 + 64) == bench.step_kernel_name(shared_up_to) == "npb_step4_kernel"
+        assert bench.step_kernel_name(shared_up_to + 64) == "npb_step_nt_kernel" and bench.step_kernel_name(shared_up_to + 64, "f32") == "npb_step_kernel"
         assert bench.step_kernel_name(2 * nt_above, "f32") == "npb_step_kernel" and bench.step_kernel_name(2 * nt_above + 64, "f32") == "npb_step_nt_kernel"
         # forced variants (npb_set_step_kernel / NPB_STEP_KERNEL): 1 and 4 at any size, 2 = the wide build only while it fits,
         # 3 = the 256-register build at ANY size (the round-2 launcher folded 3 into 2 before deciding `wide`)
@@ -142,7 +145,7 @@ def test_bench_names_the_kernel_the_launcher_picks():
             assert bench.step_kernel_name(n, forced="4") == "npb_step_nt_kernel"
             assert bench.step_kernel_name(n, forced="3") == "npb_step2_kernel"
             assert bench.step_kernel_name(n, forced="2") == ("npb_step2_wide_kernel" if n <= wide_up_to else "npb_step2_kernel")
-            assert bench.step_kernel_name(n, forced="5") == "npb_step4_kernel"
+            assert bench.step_kernel_name(n, forced="5") == bench.step_kernel_name(n, forced="6") == "npb_step4_kernel"
         os.environ["NPB_STEP_KERNEL"] = "3"
         assert bench.step_kernel_name(64) == "npb_step2_kernel"
     finally:
