@@ -198,8 +198,13 @@ NPB_API int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int
  * the request is remembered, so repeating it costs one kernel launch. */
 NPB_API int npb_gather_fields(NpbHandle *h, int n_fields, const int *kinds, const int *slots, double *out, void *stream);
 /* raw arena (checkpointing, external kernels): one allocation of equally wide columns, column-major with `pitch`
- * plants per column; the members of the schema are mapped onto columns as include/npb_fields.h describes */
+ * plants per column; the members of the schema are mapped onto columns as include/npb_fields.h describes.  A handle of
+ * 53 249 .. 98 304 plants keeps its arena in SEGMENTS (npb_state_arena_segment(h) plants each, 0 = not segmented): the
+ * allocation is then consecutive [columns][pitch] blocks, pitch = the segment size, block s holding plants s * pitch ..
+ * (s + 1) * pitch - 1 -- plant p's element of column c is at (p / pitch) * pitch * columns + c * pitch + p % pitch --
+ * so that each of the launches npb_step splits such a batch into sweeps one dense range of memory. */
 NPB_API int npb_state_arena(NpbHandle *h, void **arena, size_t *pitch, int *storage);
+NPB_API size_t npb_state_arena_segment(const NpbHandle *h);
 /* (With params.maint_enabled the step kernels consult a cache of which maintenance thresholds are inside their cooldown; every
  * entry point that can change state, the table or the clock invalidates it, this one included.  A caller that keeps the pointer
  * and writes the arena between later steps calls npb_state_arena again after each such write.) */
@@ -238,7 +243,7 @@ NPB_API int npb_set_diagnostics(NpbHandle *h, double *buf, size_t pitch);
  * above ~90 000 plants of fp64 storage, where nothing a step writes is still cached when the next step reads it, 5 = four
  * wavefronts per 64 plants handing values to each other through progress words in LDS (what 0 takes up to 32 768 plants,
  * where all of its 2 048 wavefronts are resident at once), 6 = that kernel in launches of at most 32 768 plants each (what 0
- * takes between 65 537 and 98 304 plants, where the one-wavefront kernel needs a second round of wavefronts). */
+ * takes between 53 249 and 98 304 plants, one launch per segment of the handle's arena, npb_state_arena). */
 NPB_API int npb_set_step_kernel(NpbHandle *h, int variant);
 /* Which kernel the handle's last npb_step actually launched (NPB_KERNEL_NONE before the first step): the selection above is by
  * batch size, mode, storage and override, and a test or a benchmark that means to exercise one kernel asserts it here instead
@@ -258,7 +263,7 @@ enum {
   NPB_KERNEL_COUNT_
 };
 NPB_API int npb_debug_last_step_kernel(const NpbHandle *h);
-/* ... and in how many launches of it (0 before the first step): a batch between 65 537 and 98 304 plants goes to the four-wave
+/* ... and in how many launches of it (0 before the first step): a batch between 53 249 and 98 304 plants goes to the four-wave
  * kernel in launches of at most 32 768 plants each, back to back on the caller's stream */
 NPB_API int npb_debug_last_step_launches(const NpbHandle *h);
 NPB_API const char *npb_step_kernel_name(int kernel_id);

@@ -177,6 +177,9 @@ def load():
     L.npb_get_field.argtypes = [vp, ci, ci, vp, ci, vp]
     L.npb_set_field.argtypes = [vp, ci, ci, vp, ci, vp]
     L.npb_state_arena.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ci)]
+    if hasattr(L, "npb_state_arena_segment"):    # ABI 141
+        L.npb_state_arena_segment.argtypes = [vp]
+        L.npb_state_arena_segment.restype = ctypes.c_size_t
     L.npb_gather_fields.argtypes = [vp, ci, vp, vp, vp, vp]
     L.npb_locate_field.argtypes = [vp, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.npb_step.argtypes = [vp] + [vp] * 11

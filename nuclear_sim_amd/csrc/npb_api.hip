@@ -16,6 +16,7 @@ struct NpbHandle {
   int n_plants;
   int device;
   size_t pitch;        /* n_plants rounded up to a multiple of the wave size */
+  size_t seg;          /* plants per arena segment (npb_kernels.hip, "segmented arena"), 0 = the arena is one [column][pitch] block */
   int storage;         /* NPB_STORAGE_F64 | NPB_STORAGE_F32: element type of the real-valued columns */
   size_t real_bytes;   /* 8 | 4 */
   void *f64;           /* the arena: [NPB_TOTAL_COL64][pitch] 8-byte columns, or [NPB_TOTAL_COL32][pitch] 4-byte ones */
@@ -84,6 +85,10 @@ static bool locate(int storage, int kind, int slot, int *col, int *sub, int *aki
   return false;
 }
 static size_t arena_columns(int storage) { return storage == NPB_STORAGE_F32 ? (size_t)NPB_TOTAL_COL32 : (size_t)NPB_TOTAL_COL64; }
+/* plants the arena has room for: whole segments when it is segmented */
+static size_t arena_plants(const NpbHandle *h) { return h->seg ? (h->pitch + h->seg - 1) / h->seg * h->seg : h->pitch; }
+/* what the launchers take as the column pitch: the pitch with the segment size in the upper half (npb_kernels.hip, NPD_SEGMENT) */
+#define NPB_N(h) ((size_t)(h)->pitch | ((size_t)(h)->seg << 32))
 
 /* Where an arena lands in physical memory changes the step kernel's time when the bytes a step touches are about the
  * size of the 256 MB Infinity Cache (65 536 fp64 plants: 276 MB): handles created one after another in one process run
@@ -98,7 +103,7 @@ static void probe_placement(NpbHandle *h, size_t step_columns) {
   const double touched_mb = (double)step_columns * h->real_bytes * h->pitch / 1.0e6;
   if (touched_mb < 200.0 || touched_mb > 340.0 || h->params.mode == NPB_MODE_PRIMARY) return;
   const bool narrow = h->storage == NPB_STORAGE_F32;
-  const size_t bytes = arena_columns(h->storage) * h->pitch * h->real_bytes;
+  const size_t bytes = arena_columns(h->storage) * arena_plants(h) * h->real_bytes;
   const int max_candidates = 4, launches = 12;
   void *cand[max_candidates] = {h->f64, nullptr, nullptr, nullptr};
   float ms[max_candidates] = {0, 0, 0, 0};
@@ -108,19 +113,19 @@ static void probe_placement(NpbHandle *h, size_t step_columns) {
   /* the clocks first: after an idle period the step kernel needs ~170 launches to reach its steady time (bench.py,
    * "preconditioning"), and the first candidate would otherwise be timed on the ramp -- a 5-7 % bias against it, half of
    * the effect being selected on.  Untimed launches on candidate 0 until ~20 ms have passed. */
-  (narrow ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, h->pitch, cand[0], nullptr, nullptr);
+  (narrow ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, NPB_N(h), cand[0], nullptr, nullptr);
   for (int k = 0; k < 200; k++)
-    (void)(narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, cand[0], nullptr, nullptr, nullptr, nullptr, nullptr,
+    (void)(narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, NPB_N(h), cand[0], nullptr, nullptr, nullptr, nullptr, nullptr,
                                                          nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
   if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(a); (void)hipEventDestroy(b); return; }
   int n = 0;
   for (; n < max_candidates; n++) {
     if (n > 0 && hipMalloc(&cand[n], bytes) != hipSuccess) { cand[n] = nullptr; (void)hipGetLastError(); break; }
-    (narrow ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, h->pitch, cand[n], nullptr, nullptr);
+    (narrow ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, NPB_N(h), cand[n], nullptr, nullptr);
     float best = 1e30f;
     for (int k = 0; k < launches; k++) {
       (void)hipEventRecord(a, nullptr);
-      (void)(narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, cand[n], nullptr, nullptr, nullptr, nullptr, nullptr,
+      (void)(narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, NPB_N(h), cand[n], nullptr, nullptr, nullptr, nullptr, nullptr,
                                                            nullptr, nullptr, nullptr, nullptr, nullptr, h->step_kernel, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
       (void)hipEventRecord(b, nullptr);
       if (hipEventSynchronize(b) != hipSuccess) { best = 1e30f; break; }
@@ -218,7 +223,10 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   h->pitch = ((size_t)n_plants + 63) / 64 * 64;
   h->storage = storage; h->real_bytes = real_bytes;
   h->f64 = nullptr; h->convert = nullptr; h->plan_dev = nullptr;
-  e = hipMalloc(&h->f64, arena_columns(storage) * h->pitch * real_bytes);
+  /* batches that npb_step gives to the four-wave kernel in several launches keep their arena in segments of one launch's plants each
+   * (npb_kernels.hip, "segmented arena"); NPB_ARENA_SEGMENT=0 turns it off (an A/B aid) */
+  { const char *e2 = getenv("NPB_ARENA_SEGMENT"); h->seg = (h->pitch > 53248 && h->pitch <= 98304 && !(e2 && atoi(e2) == 0)) ? 32768 : 0; }     /* = NPB_SHARED_FROM .. NPB_SHARED_UP_TO of npb_kernels.hip */
+  e = hipMalloc(&h->f64, arena_columns(storage) * arena_plants(h) * real_bytes);
   if (e == hipSuccess) probe_placement(h, step_columns);
   if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double) + npb_launch_maint_side_bytes(h->pitch));
   if (e != hipSuccess) {
@@ -229,7 +237,7 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   }
   h->maint_side = (void *)(h->convert + h->pitch);
   h->maint_cache_stale = true;
-  (storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, n_plants, h->pitch, h->f64, nullptr, nullptr);
+  (storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, n_plants, NPB_N(h), h->f64, nullptr, nullptr);
   e = hipDeviceSynchronize();
   if (caller_device >= 0 && caller_device != device) (void)hipSetDevice(caller_device); /* the caller's current device is left as it was */
   if (e != hipSuccess) {
@@ -307,7 +315,7 @@ int npb_reset(NpbHandle *h, const uint8_t *mask, void *stream) {
   if (!h) return NPB_EINVAL;
   NPB_USE_DEVICE(h);
   h->maint_cache_stale = true;
-  (h->storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, h->pitch, h->f64, mask, (hipStream_t)stream);
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_init : npb_launch_init)(&h->params, h->n_plants, NPB_N(h), h->f64, mask, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
   return NPB_OK;
 }
@@ -316,7 +324,7 @@ int npb_reset_reference(NpbHandle *h, const uint8_t *mask, int start_at_steady_s
   if (!h) return NPB_EINVAL;
   NPB_USE_DEVICE(h);
   h->maint_cache_stale = true;
-  (h->storage == NPB_STORAGE_F32 ? npb32_launch_reset : npb_launch_reset)(&h->params, h->n_plants, h->pitch, h->f64, mask, start_at_steady_state != 0, (hipStream_t)stream);
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_reset : npb_launch_reset)(&h->params, h->n_plants, NPB_N(h), h->f64, mask, start_at_steady_state != 0, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
   return NPB_OK;
 }
@@ -337,7 +345,7 @@ int npb_get_field(NpbHandle *h, int kind, int slot, void *buf, int buf_is_device
   if (rc) return rc;
   NPB_USE_DEVICE(h);
   void *dst = buf_is_device ? buf : (void *)h->convert;
-  (h->storage == NPB_STORAGE_F32 ? npb32_launch_field_get : npb_launch_field_get)(h->f64, h->pitch, col, sub, akind, dst, h->n_plants, (hipStream_t)stream);
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_field_get : npb_launch_field_get)(h->f64, NPB_N(h), col, sub, akind, dst, h->n_plants, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
   if (!buf_is_device) {
     NPB_HIP(h, hipMemcpyAsync(buf, dst, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -358,7 +366,7 @@ int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int buf_is_
     NPB_HIP(h, hipMemcpyAsync(h->convert, buf, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     src = h->convert;
   }
-  (h->storage == NPB_STORAGE_F32 ? npb32_launch_field_set : npb_launch_field_set)(h->f64, h->pitch, col, sub, akind, src, h->n_plants, (hipStream_t)stream);
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_field_set : npb_launch_field_set)(h->f64, NPB_N(h), col, sub, akind, src, h->n_plants, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
   if (!buf_is_device) NPB_HIP(h, hipStreamSynchronize((hipStream_t)stream));
   return NPB_OK;
@@ -379,7 +387,7 @@ int npb_gather_fields(NpbHandle *h, int n_fields, const int *kinds, const int *s
     NPB_HIP(h, hipStreamSynchronize((hipStream_t)stream));
     h->plan_key = key;
   }
-  (h->storage == NPB_STORAGE_F32 ? npb32_launch_gather : npb_launch_gather)(h->f64, h->pitch, h->plan_dev, n_fields, out, h->n_plants, (hipStream_t)stream);
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_gather : npb_launch_gather)(h->f64, NPB_N(h), h->plan_dev, n_fields, out, h->n_plants, (hipStream_t)stream);
   NPB_HIP(h, hipGetLastError());
   return NPB_OK;
 }
@@ -388,10 +396,12 @@ int npb_state_arena(NpbHandle *h, void **arena, size_t *pitch, int *storage) {
   if (!h) return NPB_EINVAL;
   h->maint_cache_stale = true;      /* the caller may write the arena through this pointer (before the next step) */
   if (arena) *arena = h->f64;
-  if (pitch) *pitch = h->pitch;
+  if (pitch) *pitch = h->seg ? h->seg : h->pitch;      /* a segmented arena: consecutive [columns][pitch] blocks of `pitch` plants each */
   if (storage) *storage = h->storage;
   return NPB_OK;
 }
+
+size_t npb_state_arena_segment(const NpbHandle *h) { return h ? h->seg : 0; }
 
 int npb_locate_field(const NpbHandle *h, int kind, int slot, int *column, int *sub, int *access) {
   if (!h) return NPB_EINVAL;
@@ -429,17 +439,17 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
       if (h->maint_counts) {       /* the caller's event-count column: whole once, then kept by the rule for the plants whose count it moves */
         int col, sub, akind;
         if (locate(h->storage, NPB_KIND_I32, NPB_MAINT_I32_BASE + NPB_I32_SLOT(npb_maint_t, MAINT, maintenance_actions_performed), &col, &sub, &akind))
-          (narrow ? npb32_launch_field_get : npb_launch_field_get)(h->f64, h->pitch, col, sub, akind, h->maint_counts, h->n_plants, (hipStream_t)stream);
+          (narrow ? npb32_launch_field_get : npb_launch_field_get)(h->f64, NPB_N(h), col, sub, akind, h->maint_counts, h->n_plants, (hipStream_t)stream);
       }
       h->maint_cache_stale = false;
     }
   }
-  const int launched = (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, h->pitch, h->f64, action, magnitude, power_setpoint,
+  const int launched = (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, NPB_N(h), h->f64, action, magnitude, power_setpoint,
                                                  noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, h->step_kernel, h->diag, h->diag_pitch,
                                                  maint ? &table : nullptr, maint ? h->maint_side : nullptr, maint ? h->maint_counts : nullptr, (hipStream_t)stream);
   h->last_kernel = launched & 0xff; h->last_launches = (launched >> 8) ? (launched >> 8) : 1;
   if (maint && h->params.mode != NPB_MODE_FULL)   /* a full-mode step kernel has run the rule itself, for the waves whose pump phase found something */
-    (narrow ? npb32_launch_maint : npb_launch_maint)(h->pitch, h->f64, h->maint_side, h->maint_counts, h->n_plants, (hipStream_t)stream);
+    (narrow ? npb32_launch_maint : npb_launch_maint)(NPB_N(h), h->f64, h->maint_side, h->maint_counts, h->n_plants, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_step: kernel launch failed", e);
   return NPB_OK;
@@ -449,7 +459,7 @@ int npb_debug_touch(NpbHandle *h, void *stream) {
   if (!h) return NPB_EINVAL;
   if (h->storage != NPB_STORAGE_F64) return fail(h, NPB_EINVAL, "npb_debug_touch: fp64-storage handles only");
   NPB_USE_DEVICE(h);
-  npb_launch_touch(h->pitch, (double *)h->f64, (hipStream_t)stream);
+  npb_launch_touch(NPB_N(h), (double *)h->f64, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_debug_touch: kernel launch failed", e);
   return NPB_OK;
@@ -458,7 +468,7 @@ int npb_debug_touch(NpbHandle *h, void *stream) {
 int npb_observe(NpbHandle *h, double *obs, void *stream) {
   if (!h || !obs) return NPB_EINVAL;
   NPB_USE_DEVICE(h);
-  (h->storage == NPB_STORAGE_F32 ? npb32_launch_observe : npb_launch_observe)(h->params.mode, h->n_plants, h->pitch, h->f64, obs, (hipStream_t)stream);
+  (h->storage == NPB_STORAGE_F32 ? npb32_launch_observe : npb_launch_observe)(h->params.mode, h->n_plants, NPB_N(h), h->f64, obs, (hipStream_t)stream);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(h, NPB_EHIP, "npb_observe: kernel launch failed", e);
   return NPB_OK;

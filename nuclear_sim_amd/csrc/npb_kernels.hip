@@ -55,6 +55,24 @@ extern "C" __attribute__((visibility("default"))) int npb_debug_set_stamp_buffer
 
 #define NPB_OBS_PAD 23 /* LDS row stride in doubles: 22 + 1 keeps the transpose at <= 2-way bank conflicts */
 
+/* ---- segmented arena.  A handle of more than NPB_SEGMENT_PLANTS plants keeps its arena in SEGMENTS of that many plants: segment s
+ * is the whole [column][plant] block of plants s * seg .. (s + 1) * seg - 1, so a launch over one segment sweeps one dense range of
+ * memory (two handles of 32 768 plants step 4-6 % faster than one of 65 536 laid out column by column over all plants, and the same
+ * two launches inside one arena only do when each has its segment to itself: profiles/r3_shared_launches.txt).  Every kernel takes
+ * the arena pointer and "N", the column pitch in plants, whose upper 32 bits carry the segment size (0 = one segment); with
+ *   address(column, plant p) = arena + s * seg * columns + column * seg + (p - s * seg) = [arena + s * seg * (columns - 1)] + column * seg + p
+ * a kernel only has to move its base pointer once, by its plant's segment, and use the segment size as its pitch. */
+#ifdef NPB_BUILD_F32
+#define NPD_ARENA_COLS NPB_TOTAL_COL32
+#else
+#define NPD_ARENA_COLS NPB_TOTAL_COL64
+#endif
+#define NPD_SEGMENT(arena, N, p) do { const size_t seg__ = (size_t)(N) >> 32; (N) = (size_t)(N) & 0xffffffffu; \
+    if (seg__) { (arena) += ((size_t)(p) / seg__) * seg__ * (size_t)(NPD_ARENA_COLS - 1); (N) = seg__; } } while (0)
+/* launcher side: the pitch and the segment size out of a packed N */
+#define NPD_NPAD(npad) ((size_t)(npad) & 0xffffffffu)
+#define NPD_SEG_OF(npad) ((size_t)(npad) >> 32)
+
 /* ---- section <-> arena movers outside the step kernel (init, observe, maintenance): plain global accesses.
  * A section struct is NF doubles (the last NO of them outputs) followed by NI int32s (include/npb_fields.h); in the
  * arena the NF - NO carried doubles take one column each and the narrow members share columns (npd_stage.h). */
@@ -328,6 +346,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_step_primary_kernel(
     uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out, double *__restrict__ info_out) {
   __shared__ double lds[NPB_WAVE * NPB_OBS_PAD];
   const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
+  NPD_SEGMENT(f64, N, block_base);
   const size_t p = block_base + threadIdx.x;
   const bool live = p < (size_t)n_plants;
   npd_inputs_t in;
@@ -518,6 +537,7 @@ __device__ __attribute__((noinline)) void npd_maint_rule_for_wave(const npd_main
 /* the same rule as a launch of its own, every wave looked at in full: for the modes whose step kernels do not step the pumps
  * (primary-only, primary + steam generators), where nothing has screened anything */
 __global__ __launch_bounds__(NPB_WAVE) void npb_maint_kernel(const npd_maint_rule_consts_t *RC, npd_maint_cache_t MC, size_t N, npd_real_t *__restrict__ f64) {
+  NPD_SEGMENT(f64, N, (size_t)blockIdx.x * NPB_WAVE);
   npd_maint_rule_for_wave<0>(RC, MC, f64, N, (size_t)blockIdx.x * NPB_WAVE + threadIdx.x, 0xFu, 1u);
 }
 
@@ -571,6 +591,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_observe_kernel(int mode, int n_p
   __shared__ double lds[NPB_WAVE * NPB_OBS_PAD];
   npd_real_t *f64 = const_cast<npd_real_t *>(f64c);
   const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
+  NPD_SEGMENT(f64, N, block_base);
   const size_t p = block_base + threadIdx.x;
   double obs[NPB_OBS_DIM];
   npb_prim_t s;
@@ -608,6 +629,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size
                                                             const uint8_t *__restrict__ mask,
                                                             int n_plants) {
   const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
+  NPD_SEGMENT(f64, N, p);
   if (mask && p < (size_t)n_plants && !mask[p]) return;
   if (mask && p >= (size_t)n_plants) return;
   { npb_prim_t s; npd_prim_init(&s); NPD_STORE(PRIM, npb_prim_t, s, 0); }
@@ -635,6 +657,7 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_init_kernel(npb_params_t P, size
 __global__ __launch_bounds__(NPB_WAVE) void npb_reset_kernel(npb_params_t P, size_t N, npd_real_t *__restrict__ f64,
                                                              const uint8_t *__restrict__ mask, int n_plants, int steady) {
   const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
+  NPD_SEGMENT(f64, N, p);
   if (mask && (p >= (size_t)n_plants || !mask[p])) return;
   { npb_prim_t s; NPD_LOAD(PRIM, npb_prim_t, s, 0); npd_prim_reset(&s); NPD_STORE(PRIM, npb_prim_t, s, 0); }
   npb_sec_t sec;
@@ -677,12 +700,14 @@ __global__ __launch_bounds__(NPB_WAVE) void npb_reset_kernel(npb_params_t P, siz
  * so that FETCH_SIZE / WRITE_SIZE can be scaled against a known byte count (2 * state_bytes * pitch) */
 __global__ __launch_bounds__(NPB_WAVE) void npb_touch_kernel(size_t N, double *__restrict__ f64) {
   const size_t p = (size_t)blockIdx.x * NPB_WAVE + threadIdx.x;
+  { const size_t seg = N >> 32; N &= 0xffffffffu; if (seg) { f64 += (p / seg) * seg * (size_t)(NPB_TOTAL_COL64 - 1); N = seg; } }
 #pragma unroll 8
   for (int k = 0; k < NPB_TOTAL_COL64; k++) { double v = f64[(size_t)k * N + p]; f64[(size_t)k * N + p] = v + 0.0; }
 }
-extern "C" void npb_launch_touch(size_t npad, double *f64, hipStream_t stream) {
+extern "C" void npb_launch_touch(size_t npad_seg, double *f64, hipStream_t stream) {
+  const size_t npad = NPD_NPAD(npad_seg);
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
-  hipLaunchKernelGGL(npb_touch_kernel, grid, block, 0, stream, npad, f64);
+  hipLaunchKernelGGL(npb_touch_kernel, grid, block, 0, stream, npad_seg, f64);
 }
 #endif
 
@@ -699,6 +724,7 @@ extern "C" void npb_launch_touch(size_t npad, double *f64, hipStream_t stream) {
 __global__ void npb_field_get_kernel(const npd_real_t *__restrict__ arena, size_t N, int col, int sub, int kind, void *__restrict__ out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  NPD_SEGMENT(arena, N, i);
   const char *e = (const char *)(arena + (size_t)col * N + i);
   if (kind == 0) ((double *)out)[i] = (double)*(const npd_real_t *)e;
   else if (kind == 1) ((double *)out)[i] = (double)*(const float *)(e + sub * 4);
@@ -707,6 +733,7 @@ __global__ void npb_field_get_kernel(const npd_real_t *__restrict__ arena, size_
 __global__ void npb_field_set_kernel(npd_real_t *__restrict__ arena, size_t N, int col, int sub, int kind, const void *__restrict__ in, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  NPD_SEGMENT(arena, N, i);
   char *e = (char *)(arena + (size_t)col * N + i);
   if (kind == 0) *(npd_real_t *)e = (npd_real_t)((const double *)in)[i];
   else if (kind == 1) *(float *)(e + sub * 4) = (float)((const double *)in)[i];
@@ -718,6 +745,7 @@ __global__ void npb_gather_kernel(const npd_real_t *__restrict__ arena, size_t N
   const int i = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
   if (i >= n) return;
   const int col = plan[3 * f], sub = plan[3 * f + 1], kind = plan[3 * f + 2];
+  NPD_SEGMENT(arena, N, i);
   const char *e = (const char *)(arena + (size_t)col * N + i);
   double v;
   if (kind == 0) v = (double)*(const npd_real_t *)e;
@@ -737,8 +765,11 @@ extern "C" void NPB_LAUNCHER(field_set)(void *arena, size_t npad, int col, int s
 /* fp64-storage plants above which the sweep of a step (4 221 B per plant) is so far past the 256 MB Infinity Cache that streaming
  * state stores win (measured: even at 81 920, -5 % at 98 304, -10 % at 131 072); fp32 storage moves half the bytes */
 #define NPB_NT_STORE_ABOVE ((size_t)90112)
-/* plants (of either storage type) up to which a batch past one round of the one-wave kernel's waves goes to the four-wave kernel in
- * several launches instead (three launches; measured: 98 304 plants 0.158 ms against the streaming build's 0.177; four launches at 106 496: 0.204) */
+/* plants (of either storage type) between which a batch goes to the four-wave kernel in one launch per arena segment of 32 768 plants
+ * (two or three launches; npb_api.hip segments the arena of exactly these handles).  Measured (profiles/r3_segment_sweep.txt): 49 152 plants
+ * the two-wave kernel 0.079 ms against 0.081, 57 344 0.090 against 0.087, 65 536 the one-wave kernel 0.0954 against 0.0930, 81 920 0.166
+ * against 0.135, 98 304 the streaming build 0.177 against 0.156; with four launches (106 496: 0.204) the streaming build is ahead again */
+#define NPB_SHARED_FROM ((size_t)53248)
 #define NPB_SHARED_UP_TO ((size_t)98304)
 /* the table as the step kernels' pump phase evaluates it (npd_maintenance.h): a strict comparison as the sign of fma(value, sgn, c);
  * any other comparison kind in the scan makes every (wave, pump) "look properly" */
@@ -764,18 +795,19 @@ static npd_maint_cache_t npd_maint_cache_of(void *maint_side, int32_t *counts, i
   return C;
 }
 /* maint_table / maint_side (the handle's maintenance side buffer, rule constants uploaded): NULL unless the automatic maintenance is on (npb_step) */
-extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad, void *arena,
+extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t npad_seg, void *arena,
                                 const int32_t *action, const double *magnitude, const double *setpoint,
                                 const double *noise_z, const double *cw_temp, double *obs, double *reward, uint8_t *done,
                                 uint32_t *trip_flags, double *info, int variant, double *diag, size_t diag_pitch,
                                 const npb_maint_table_t *maint_table, void *maint_side, int32_t *maint_counts, hipStream_t stream) {
+  const size_t npad = NPD_NPAD(npad_seg), seg = NPD_SEG_OF(npad_seg);   /* column pitch in plants / plants per arena segment (0: one segment) */
   npd_maint_hot_t MH;
   npd_maint_fold_table(P, maint_side ? maint_table : nullptr, &MH);
   const npd_maint_cache_t MC = npd_maint_cache_of(maint_side, maint_counts, n_plants, diag, diag_pitch);
   const npd_maint_rule_consts_t *maint_rc = (const npd_maint_rule_consts_t *)maint_side;     /* NULL = off */
   dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
   if (diag && P->mode == NPB_MODE_FULL) {   /* npb_set_diagnostics: the diagnostics build of the one-wave kernel at any size */
-    hipLaunchKernelGGL(npb_step_diag_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
+    hipLaunchKernelGGL(npb_step_diag_kernel, grid, block, 0, stream, *P, n_plants, npad_seg, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC, diag, diag_pitch);
     return NPB_KERNEL_STEP_DIAG;
   }
@@ -786,18 +818,18 @@ extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t np
    * variant: 0 = by batch size, 1 = one wave per 64 plants, 2 = two waves, 3 = their two-per-SIMD build, 4 = one wave with
    * streaming state stores (what 0 picks once the sweep is far past the Infinity Cache), 5 = four waves (npd_step4.h: what 0
    * picks while all its waves are resident at once, up to 32 768 plants), 6 = the same in launches of at most 32 768 plants (what 0
-   * picks between 65 537 and 98 304 plants).  The return value's low byte names the kernel, the next byte the number of launches.
+   * picks between 53 249 and 98 304 plants).  The return value's low byte names the kernel, the next byte the number of launches.
    * The primary + steam-generator
    * mode always takes a one-wave kernel.  The return value names the kernel that was launched (npb_debug_last_step_kernel). */
   if (P->mode == NPB_MODE_PRIMARY) {
-    hipLaunchKernelGGL(npb_step_primary_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
+    hipLaunchKernelGGL(npb_step_primary_kernel, grid, block, 0, stream, *P, n_plants, npad_seg, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, obs, reward, done, trip_flags, info);
     return NPB_KERNEL_STEP_PRIMARY;
   }
-  if (variant == 0) variant = npad <= 32768 ? 5 : (npad <= 57344 ? 2 : (npad <= 65536 ? 1 : (npad <= NPB_SHARED_UP_TO ? 6 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1))));
+  if (variant == 0) variant = npad <= 32768 ? 5 : (npad <= NPB_SHARED_FROM ? 2 : (npad <= NPB_SHARED_UP_TO ? 6 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1)));
   const bool with_maint = maint_rc != nullptr;     /* the builds with the automatic maintenance compiled in */
   if (variant == 4) {
-    hipLaunchKernelGGL(with_maint ? npb_step_nt_maint_kernel : npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
+    hipLaunchKernelGGL(with_maint ? npb_step_nt_maint_kernel : npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad_seg, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
     return with_maint ? NPB_KERNEL_STEP_NT_MAINT : NPB_KERNEL_STEP_NT;
   }
@@ -805,36 +837,36 @@ extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t np
     /* four waves per 64 plants (npd_step4.h).  Variant 6: in launches of at most 32 768 plants each, so that every wave of a launch
      * is resident at once: past 65 536 plants the one-wave kernel needs a second round of waves (69 632 plants: 0.166 ms), three
      * such launches step 81 920 plants in 0.140 ms (profiles/r3_shared_launches.txt, which is about the sizes where
-     * this does NOT pay).  The launches share the batch in runs of NPD4_RUN groups of 64 plants. */
-    const size_t groups = npad / NPB_WAVE;
-    const uint32_t parts = variant == 6 ? (uint32_t)((npad + 32767) / 32768) : 1;
+     * this does NOT pay).  One launch per arena segment (above), so each sweeps one dense range of memory. */
+    const size_t groups = npad / NPB_WAVE, per = (seg ? seg : (size_t)32768) / NPB_WAVE;       /* groups of 64 plants: all, per launch */
+    const uint32_t parts = variant == 6 ? (uint32_t)((groups + per - 1) / per) : 1;
     for (uint32_t part = 0; part < parts; part++) {
-      const size_t grid4 = parts == 1 ? groups : (groups + (size_t)NPD4_RUN * parts - 1) / ((size_t)NPD4_RUN * parts) * NPD4_RUN;
-      hipLaunchKernelGGL(with_maint ? npb_step4_maint_kernel : npb_step4_kernel, dim3((unsigned)grid4), dim3(NPD4_THREADS), 0, stream, *P, n_plants, npad,
+      const size_t first = parts == 1 ? 0 : part * per, count = parts == 1 ? groups : (groups - first < per ? groups - first : per);
+      hipLaunchKernelGGL(with_maint ? npb_step4_maint_kernel : npb_step4_kernel, dim3((unsigned)count), dim3(NPD4_THREADS), 0, stream, *P, n_plants, npad_seg,
                          (npd_real_t *)arena, action, magnitude, setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC,
-                         parts == 1 ? 0u : (part | (parts << 8)));
+                         (uint32_t)first);
     }
     return (with_maint ? NPB_KERNEL_STEP4_MAINT : NPB_KERNEL_STEP4) | ((int)parts << 8);
   }
   const bool two_wave = (variant == 2 || variant == 3) && P->mode == NPB_MODE_FULL;
   const bool wide = two_wave && variant == 2 && npad <= 32768;   /* the whole register file while one wave per SIMD is all there is; variant 3 = never */
   if (wide) {
-    hipLaunchKernelGGL(with_maint ? npb_step2_wide_maint_kernel : npb_step2_wide_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
+    hipLaunchKernelGGL(with_maint ? npb_step2_wide_maint_kernel : npb_step2_wide_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad_seg, (npd_real_t *)arena, action, magnitude,
                        setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
     return with_maint ? NPB_KERNEL_STEP2_WIDE_MAINT : NPB_KERNEL_STEP2_WIDE;
   }
   if (two_wave) {
-    hipLaunchKernelGGL(with_maint ? npb_step2_maint_kernel : npb_step2_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude,
+    hipLaunchKernelGGL(with_maint ? npb_step2_maint_kernel : npb_step2_kernel, grid, dim3(NPD2_THREADS), 0, stream, *P, n_plants, npad_seg, (npd_real_t *)arena, action, magnitude,
                        setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
     return with_maint ? NPB_KERNEL_STEP2_MAINT : NPB_KERNEL_STEP2;
   }
-  hipLaunchKernelGGL(with_maint ? npb_step_maint_kernel : npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad, (npd_real_t *)arena, action, magnitude, setpoint,
+  hipLaunchKernelGGL(with_maint ? npb_step_maint_kernel : npb_step_kernel, grid, block, 0, stream, *P, n_plants, npad_seg, (npd_real_t *)arena, action, magnitude, setpoint,
                      noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
   return with_maint ? NPB_KERNEL_STEP_MAINT : NPB_KERNEL_STEP;
 }
 /* the rule as a launch of its own (modes that do not step the pumps) */
 extern "C" void NPB_LAUNCHER(maint)(size_t npad, void *arena, void *maint_side, int32_t *counts, int n_plants, hipStream_t stream) {
-  hipLaunchKernelGGL(npb_maint_kernel, dim3((unsigned)(npad / NPB_WAVE)), dim3(NPB_WAVE), 0, stream, (const npd_maint_rule_consts_t *)maint_side,
+  hipLaunchKernelGGL(npb_maint_kernel, dim3((unsigned)(NPD_NPAD(npad) / NPB_WAVE)), dim3(NPB_WAVE), 0, stream, (const npd_maint_rule_consts_t *)maint_side,
                      npd_maint_cache_of(maint_side, counts, n_plants), npad, (npd_real_t *)arena);
 }
 /* the rule's constants as the device reads them: host_out = NPB_LAUNCHER(maint_consts_bytes)() bytes */
@@ -858,17 +890,17 @@ extern "C" void NPB_LAUNCHER(maint_consts)(const npb_params_t *P, const npb_main
 }
 extern "C" size_t NPB_LAUNCHER(maint_consts_bytes)(void) { return sizeof(npd_maint_rule_consts_t); }
 /* rule constants + cooldown cache (npd_maint_cache_of); a zeroed cache = "nothing known: look" */
-extern "C" size_t NPB_LAUNCHER(maint_side_bytes)(size_t npad) { return NPD_MAINT_CONSTS_BYTES + (size_t)NPB_NUM_PUMPS * npad * (sizeof(float) + sizeof(uint32_t)); }
+extern "C" size_t NPB_LAUNCHER(maint_side_bytes)(size_t npad) { return NPD_MAINT_CONSTS_BYTES + (size_t)NPB_NUM_PUMPS * NPD_NPAD(npad) * (sizeof(float) + sizeof(uint32_t)); }
 extern "C" size_t NPB_LAUNCHER(maint_cache_offset)(void) { return NPD_MAINT_CONSTS_BYTES; }
 extern "C" void NPB_LAUNCHER(observe)(int mode, int n_plants, size_t npad, const void *arena, double *obs, hipStream_t stream) {
-  dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
+  dim3 grid((unsigned)(NPD_NPAD(npad) / NPB_WAVE)), block(NPB_WAVE);
   hipLaunchKernelGGL(npb_observe_kernel, grid, block, 0, stream, mode, n_plants, npad, (const npd_real_t *)arena, obs);
 }
 extern "C" void NPB_LAUNCHER(reset)(const npb_params_t *P, int n_plants, size_t npad, void *arena, const uint8_t *mask, int steady, hipStream_t stream) {
-  dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
+  dim3 grid((unsigned)(NPD_NPAD(npad) / NPB_WAVE)), block(NPB_WAVE);
   hipLaunchKernelGGL(npb_reset_kernel, grid, block, 0, stream, *P, npad, (npd_real_t *)arena, mask, n_plants, steady);
 }
 extern "C" void NPB_LAUNCHER(init)(const npb_params_t *P, int n_plants, size_t npad, void *arena, const uint8_t *mask, hipStream_t stream) {
-  dim3 grid((unsigned)(npad / NPB_WAVE)), block(NPB_WAVE);
+  dim3 grid((unsigned)(NPD_NPAD(npad) / NPB_WAVE)), block(NPB_WAVE);
   hipLaunchKernelGGL(npb_init_kernel, grid, block, 0, stream, *P, npad, (npd_real_t *)arena, mask, n_plants);
 }

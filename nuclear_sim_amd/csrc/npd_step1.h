@@ -17,6 +17,7 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
   __shared__ __attribute__((aligned(16))) double lds[NPB_STAGE_BYTES / 8];
   static_assert(NPB_STAGE_SLOTS >= NPB_OBS_PAD, "the transposes alias the staging region");
   const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
+  NPD_SEGMENT(f64, N, block_base);
   const size_t p = block_base + threadIdx.x; /* always < N (arena is padded to a multiple of 64) */
   const bool live = p < (size_t)n_plants;
   const double dt = P.dt;

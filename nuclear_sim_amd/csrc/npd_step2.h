@@ -320,6 +320,7 @@ __device__ __forceinline__ void npd_step2_body(
   const int lane = threadIdx.x & (NPB_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform role: 0 = A, 1 = B */
   const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
+  NPD_SEGMENT(f64, N, block_base);
   const size_t p = block_base + lane;
   const bool live = p < (size_t)n_plants;
   const double dt = P.dt;

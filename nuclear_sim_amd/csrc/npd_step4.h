@@ -33,7 +33,6 @@
 #define NPD_STEP4_H
 
 #define NPD4_THREADS 256
-#define NPD4_RUN 8                            /* groups of 64 plants per run when several launches share a batch (npb_kernels.hip) */
 /* a section back to the arena.  The unchanged-column elision of the other kernels (npb_kernels.hip); -DNPD4_NO_ELIDE:
  * plain stores, which spare the registers of the old copies (measured: 51 -> 43 spilled registers, +1.2 % kernel time at 32 768
  * plants, nothing at 8 192: profiles/r3_step4_ab_elide.txt) */
@@ -206,18 +205,16 @@ __device__ __forceinline__ void npd_step4_body(
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
     const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,
     double *__restrict__ reward_out, uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out,
-    double *__restrict__ info_out, const npd_maint_hot_t &MH, const npd_maint_rule_consts_t *maint_rc, const npd_maint_cache_t &MC, uint32_t split) {
+    double *__restrict__ info_out, const npd_maint_hot_t &MH, const npd_maint_rule_consts_t *maint_rc, const npd_maint_cache_t &MC, uint32_t first_group) {
   __shared__ __attribute__((aligned(16))) double xch[NPD4_SLOTS * NPB_WAVE];
   const int lane = threadIdx.x & (NPB_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform role 0 .. 3 */
   const int my_pump = (wave == 3) ? 0 : (wave == 0 ? 3 : wave);         /* the primary side's wave takes the spare pump, normally the cheap one */
-  /* which 64 plants: all of the batch in one launch (split == 0), or one of `parts` launches that share it in runs of NPD4_RUN groups
-   * (split = part | parts << 8): every launch then sweeps every column end to end (each taking one contiguous part of every column
-   * instead measured 6 % slower at 65 536 plants) and has all its waves resident at once */
-  const uint32_t part = split & 0xff, parts = split >> 8;
-  const size_t group = parts <= 1 ? (size_t)blockIdx.x : ((size_t)(blockIdx.x / NPD4_RUN) * parts + part) * NPD4_RUN + blockIdx.x % NPD4_RUN;
-  const size_t block_base = group * NPB_WAVE;
-  if (block_base >= N) return;                      /* the last run of a part may reach past the batch: the whole group leaves */
+  /* which 64 plants: `first_group` is 0 when one launch takes the whole batch; a batch past 65 536 plants goes in one launch per arena
+   * segment (npb_kernels.hip), each with all its waves resident at once */
+  const size_t block_base = ((size_t)first_group + blockIdx.x) * NPB_WAVE;
+  if (block_base >= (size_t)n_plants) return;       /* a group of padding only: the whole group leaves */
+  NPD_SEGMENT(f64, N, block_base);
   const size_t p = block_base + lane;
   const bool live = p < (size_t)n_plants;
   const double dt = P.dt, tdt = dt / 60.0;
@@ -780,7 +777,7 @@ __device__ __forceinline__ void npd_step4_body(
 }
 
 /* two waves per SIMD (<= 256 registers each): 2 048 waves = 32 768 plants resident at once */
-__global__ __launch_bounds__(NPD4_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void npb_step4_kernel(NPD2_KERNEL_ARGS, uint32_t split) { npd_step4_body<6, false>(NPD2_KERNEL_PASS, split); }
-__global__ __launch_bounds__(NPD4_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void npb_step4_maint_kernel(NPD2_KERNEL_ARGS, uint32_t split) { npd_step4_body<6, true>(NPD2_KERNEL_PASS, split); }
+__global__ __launch_bounds__(NPD4_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void npb_step4_kernel(NPD2_KERNEL_ARGS, uint32_t first_group) { npd_step4_body<6, false>(NPD2_KERNEL_PASS, first_group); }
+__global__ __launch_bounds__(NPD4_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void npb_step4_maint_kernel(NPD2_KERNEL_ARGS, uint32_t first_group) { npd_step4_body<6, true>(NPD2_KERNEL_PASS, first_group); }
 
 #endif

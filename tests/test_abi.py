@@ -117,10 +117,15 @@ def test_bench_names_the_kernel_the_launcher_picks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "nuclear_sim_amd", "csrc", "npb_kernels.hip")).read()
     four_wave_up_to = int(re.search(r"variant = npad <= (\d+) \? 5", src).group(1))
-    two_wave_up_to = int(re.search(r"\(npad <= (\d+) \? 2", src).group(1))
+    shared_from = int(re.search(r"#define NPB_SHARED_FROM \(\(size_t\)(\d+)\)", src).group(1))
+    shared_up_to = int(re.search(r"#define NPB_SHARED_UP_TO \(\(size_t\)(\d+)\)", src).group(1))
+    assert re.search(r"\(npad <= NPB_SHARED_FROM \? 2 : \(npad <= NPB_SHARED_UP_TO \? 6", src)
     nt_above = int(re.search(r"#define NPB_NT_STORE_ABOVE \(\(size_t\)(\d+)\)", src).group(1))
     wide_up_to = int(re.search(r"const bool wide = .* npad <= (\d+);", src).group(1))
     assert re.search(r"const bool wide = two_wave && variant == 2 && npad <= \d+;", src)      # variant 3 never takes the wide build
+    # the handles whose arena npb_create segments are exactly the ones npb_step splits into one launch per segment
+    api = open(os.path.join(root, "nuclear_sim_amd", "csrc", "npb_api.hip")).read()
+    assert re.search(r"h->pitch > %d && h->pitch <= %d" % (shared_from, shared_up_to), api)
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     old = os.environ.pop("NPB_STEP_KERNEL", None)
@@ -128,14 +133,10 @@ def test_bench_names_the_kernel_the_launcher_picks():
         assert four_wave_up_to == wide_up_to == 32768      # both are "every wave resident at once": 2 048 waves of 256 registers / 1 024 of 512
         assert bench.step_kernel_name(64) == bench.step_kernel_name(four_wave_up_to) == "npb_step4_kernel"
         assert bench.step_kernel_name(four_wave_up_to, maintenance=True) == "npb_step4_maint_kernel"
-        assert bench.step_kernel_name(four_wave_up_to + 64) == "npb_step2_kernel"
-        assert bench.step_kernel_name(two_wave_up_to) == "npb_step2_kernel"
-        assert bench.step_kernel_name(two_wave_up_to + 64) == "npb_step_kernel"
-        assert bench.step_kernel_name(65536) == "npb_step_kernel"
-        # past one round of the one-wave kernel's waves: the four-wave kernel in several launches, then the streaming build
-        shared_up_to = int(re.search(r"#define NPB_SHARED_UP_TO \(\(size_t\)(\d+)\)", src).group(1))
-        assert re.search(r"\(npad <= 65536 \? 1 : \(npad <= NPB_SHARED_UP_TO \? 6", src) and shared_up_to > nt_above
-        assert bench.step_kernel_name(65536 + 64) == bench.step_kernel_name(shared_up_to) == "npb_step4_kernel"
+        assert bench.step_kernel_name(four_wave_up_to + 64) == bench.step_kernel_name(shared_from) == "npb_step2_kernel"
+        # the four-wave kernel in one launch per arena segment, then the one-wave kernel's streaming build
+        assert bench.step_kernel_name(shared_from + 64) == bench.step_kernel_name(65536) == bench.step_kernel_name(shared_up_to) == "npb_step4_kernel"
+        assert shared_up_to > nt_above
         assert bench.step_kernel_name(shared_up_to + 64) == "npb_step_nt_kernel" and bench.step_kernel_name(shared_up_to + 64, "f32") == "npb_step_kernel"
         assert bench.step_kernel_name(2 * nt_above, "f32") == "npb_step_kernel" and bench.step_kernel_name(2 * nt_above + 64, "f32") == "npb_step_nt_kernel"
         # forced variants (npb_set_step_kernel / NPB_STEP_KERNEL): 1 and 4 at any size, 2 = the wide build only while it fits,

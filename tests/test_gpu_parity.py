@@ -682,11 +682,11 @@ def test_full_size_against_the_oracle_on_a_sample(oracle_lib, storage, n, T):
     the oracle with its state rounded to float after every step, the same algorithm.)  At 131 072 plants npb_step takes the
     streaming build of the one-wave kernel (two rounds of waves, state stores past the caches), at 40 960 the 256-register
     build of the two-wave kernel (32 769 .. 57 344 plants), at 32 768 -- BASELINE config 4's share per GPU -- the
-    four-wave kernel, at 81 900 (ragged: the last group of 64 is partly padding, the last run of the third launch reaches past
-    the batch) the four-wave kernel in three launches that share the batch in runs of eight groups; each run asserts that kernel."""
+    four-wave kernel, at 65 536 and at 81 900 (ragged: the last group of 64 is partly padding) the four-wave kernel in two / three
+    launches, one per segment of the handle's segmented arena; each run asserts that kernel and the number of launches."""
     import torch
     import bench
-    want_kernel = {65536: "npb_step_kernel", 131072: "npb_step_nt_kernel", 40960: "npb_step2_kernel", 32768: "npb_step4_kernel", 81900: "npb_step4_kernel"}[n]
+    want_kernel = {65536: "npb_step4_kernel", 131072: "npb_step_nt_kernel", 40960: "npb_step2_kernel", 32768: "npb_step4_kernel", 81900: "npb_step4_kernel"}[n]
     assert bench.step_kernel_name(n, storage, forced="0") == want_kernel
     rng = np.random.default_rng(2024)
     sample = np.unique(np.concatenate([[0, 1, 63, 64, 65, 127, n - 65, n - 64, n - 1], rng.choice(n, 183, replace=False)]))
@@ -706,7 +706,7 @@ def test_full_size_against_the_oracle_on_a_sample(oracle_lib, storage, n, T):
         z = rng.standard_normal(n)
         obs, rew, done, info = env.step(power_setpoint=sp, noise_z=z)
         assert env.last_step_kernel() == want_kernel
-        assert env.last_step_launches() == (3 if n == 81900 else 1)
+        assert env.last_step_launches() == {81900: 3, 65536: 2}.get(n, 1)
         o_obs, o_rew, o_done, o_flags, _ = ora.step(setpoint=sp[sample], noise_z=z[sample])
         if narrow:
             ora.round_state_f32()
