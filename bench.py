@@ -127,16 +127,16 @@ def step_kernel_name(n, storage="f64", forced=None, mode="full", maintenance=Fal
     tests/test_abi.py and the GPU tests hold the two together."""
     if forced is None:
         forced = os.environ.get("NPB_STEP_KERNEL", "0")
-    variant = int(forced) if str(forced) in ("1", "2", "3", "4", "5", "6") else 0
+    variant = int(forced) if str(forced) in ("1", "2", "3", "4", "5") else 0
     npad = (n + 63) // 64 * 64
     if mode == "primary":
         return "npb_step_primary_kernel"
     if variant == 0:
-        variant = 5 if npad <= 32768 else (2 if npad <= 53248 else (6 if npad <= 98304 else (4 if npad * (8 if storage == "f64" else 4) > 90112 * 8 else 1)))
+        variant = 5 if npad <= 32768 else (2 if npad <= 45056 else (5 if npad <= 114688 else (4 if npad * (8 if storage == "f64" else 4) > 90112 * 8 else 1)))
     m = "_maint" if (maintenance and mode == "full") else ""       # the builds with the automatic maintenance compiled in
     if variant == 4:
         return "npb_step_nt%s_kernel" % m
-    if variant in (5, 6) and mode == "full":
+    if variant == 5 and mode == "full":
         return "npb_step4%s_kernel" % m
     if variant in (2, 3) and mode == "full":
         return ("npb_step2_wide%s_kernel" if (variant == 2 and npad <= 32768) else "npb_step2%s_kernel") % m
@@ -302,7 +302,6 @@ def main():
     torch.cuda.synchronize(dev)
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
     launched_kernel = env.last_step_kernel()       # what npb_step launched, asked of the library (npb_debug_last_step_kernel)
-    launches = max(1, env.last_step_launches())    # ... and in how many launches (53 249 .. 98 304 plants: one per arena segment of 32 768)
     assert launched_kernel == step_kernel_name(n, args.storage, maintenance=args.maintenance), (launched_kernel, step_kernel_name(n, args.storage, maintenance=args.maintenance))
     # self-check: the same loop as the timed region over >= 0.6 s of launches (the driver's --steps 20 is a 2 ms
     # timed region; one scheduling hiccup there is a 10 % error), inputs cycled
@@ -351,13 +350,7 @@ def main():
                          "traffic_source": ("%s: committed rocprofv3 PMC passes of an earlier run of this workload, "
                                             "not measured by this run" % traffic_src) if traffic_src else None,
                          "frac_of_peak_by_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "algorithmic_bytes_per_launch": bytes_per_plant * n / launches,
-                         "launches_per_step": launches,
-                         "launches_note": ("a step of this batch is %d back-to-back launches of the kernel, one per arena segment of 32 768 plants, each with "
-                                           "all its waves resident at once; kernel_ms is the step (HIP events around all of them), kernel_launch_ms one "
-                                           "launch's share, which is what rocprofv3 lists per dispatch; achieved = algorithmic_bytes_per_launch / "
-                                           "kernel_launch_ms" % launches) if launches > 1 else None,
-                         "kernel_launch_ms": kernel_ms / launches,
+                         "algorithmic_bytes_per_launch": bytes_per_plant * n,
                          "bytes_not_moved": "the algorithmic figure counts every carried column as read + written; the kernel "
                                             "skips the store of a column whose bits did not change for any plant of a wave "
                                             "(measured writes ~200 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "

@@ -153,9 +153,6 @@ def load():
     L.npb_set_step_kernel.argtypes = [vp, ci]
     if hasattr(L, "npb_debug_last_step_kernel"):    # ABI 140
         L.npb_debug_last_step_kernel.argtypes = [vp]
-    if hasattr(L, "npb_debug_last_step_launches"):    # ABI 141
-        L.npb_debug_last_step_launches.argtypes = [vp]
-        L.npb_debug_last_step_launches.restype = ctypes.c_int
         L.npb_step_kernel_name.argtypes = [ci]
         L.npb_step_kernel_name.restype = ctypes.c_char_p
         for f in ("npb_maint_param_name", "npb_maint_action_name"):

@@ -27,7 +27,6 @@ struct NpbHandle {
   int32_t *maint_counts;           /* npb_set_maintenance_count_buffer: the caller's [n_plants] int32 column, or NULL */
   bool maint_cache_stale;          /* the cooldown cache of the step kernels' maintenance screen must be zeroed before the next step */
   int last_kernel;                 /* NPB_KERNEL_*: what the last npb_step launched */
-  int last_launches;               /* ... and in how many launches */
   int step_kernel;                 /* 0 = chosen by batch size, 1 = one-wave kernel, 2 = two-wave kernel, 3 = its two-waves-per-SIMD build, 4 = one-wave with streaming stores, 5 = four-wave kernel (npb_set_step_kernel) */
   npb_maint_table_t maint_table;   /* thresholds of the automatic maintenance (include/npb_maint.h) */
   bool maint_table_custom;         /* set through npb_set_maintenance_table: the table is then taken as it is */
@@ -218,14 +217,18 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   if (params) h->params = *params; else npb_params_default(&h->params);
   npb_maint_table_default(&h->maint_table);
   h->maint_table_custom = false;
-  { const char *e = getenv("NPB_STEP_KERNEL"); h->step_kernel = e ? atoi(e) : 0; if (h->step_kernel < 0 || h->step_kernel > 6) h->step_kernel = 0; }
+  { const char *e = getenv("NPB_STEP_KERNEL"); h->step_kernel = e ? atoi(e) : 0; if (h->step_kernel < 0 || h->step_kernel > 5) h->step_kernel = 0; }
   h->n_plants = n_plants; h->device = device;
   h->pitch = ((size_t)n_plants + 63) / 64 * 64;
   h->storage = storage; h->real_bytes = real_bytes;
   h->f64 = nullptr; h->convert = nullptr; h->plan_dev = nullptr;
-  /* batches that npb_step gives to the four-wave kernel in several launches keep their arena in segments of one launch's plants each
-   * (npb_kernels.hip, "segmented arena"); NPB_ARENA_SEGMENT=0 turns it off (an A/B aid) */
-  { const char *e2 = getenv("NPB_ARENA_SEGMENT"); h->seg = (h->pitch > 53248 && h->pitch <= 98304 && !(e2 && atoi(e2) == 0)) ? 32768 : 0; }     /* = NPB_SHARED_FROM .. NPB_SHARED_UP_TO of npb_kernels.hip */
+  /* batches that npb_step gives to the four-wave kernel although they do not fit at once keep their arena in segments of 16 384 plants
+   * (npb_kernels.hip, "segmented arena") */
+  {   /* NPB_ARENA_SEGMENT=0 turns it off, =<plants> (a multiple of 64) forces that segment size at any batch size: A/B aids */
+    const char *e2 = getenv("NPB_ARENA_SEGMENT");
+    h->seg = (h->pitch > 45056 && h->pitch <= 114688) ? 16384 : 0;     /* = NPB_SEGMENTED_FROM .. NPB_SEGMENTED_UP_TO of npb_kernels.hip */
+    if (e2) { const long v = atol(e2); h->seg = (v > 0 && v % 64 == 0 && (size_t)v < h->pitch) ? (size_t)v : 0; }
+  }
   e = hipMalloc(&h->f64, arena_columns(storage) * arena_plants(h) * real_bytes);
   if (e == hipSuccess) probe_placement(h, step_columns);
   if (e == hipSuccess) e = hipMalloc((void **)&h->convert, h->pitch * sizeof(double) + npb_launch_maint_side_bytes(h->pitch));
@@ -268,13 +271,12 @@ int npb_set_params(NpbHandle *h, const npb_params_t *params) {
 }
 
 int npb_set_step_kernel(NpbHandle *h, int variant) {
-  if (!h || variant < 0 || variant > 6) return NPB_EINVAL;
+  if (!h || variant < 0 || variant > 5) return NPB_EINVAL;
   h->step_kernel = variant;
   return NPB_OK;
 }
 
 int npb_debug_last_step_kernel(const NpbHandle *h) { return h ? h->last_kernel : NPB_KERNEL_NONE; }
-int npb_debug_last_step_launches(const NpbHandle *h) { return h ? h->last_launches : 0; }
 const char *npb_step_kernel_name(int id) {
   static const char *const names[NPB_KERNEL_COUNT_] = {"", "npb_step_kernel", "npb_step2_wide_kernel", "npb_step2_kernel", "npb_step_nt_kernel",
                                                        "npb_step_diag_kernel", "npb_step_primary_kernel", "npb_step_maint_kernel", "npb_step2_wide_maint_kernel",
@@ -444,10 +446,9 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
       h->maint_cache_stale = false;
     }
   }
-  const int launched = (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, NPB_N(h), h->f64, action, magnitude, power_setpoint,
+  h->last_kernel = (narrow ? npb32_launch_step : npb_launch_step)(&h->params, h->n_plants, NPB_N(h), h->f64, action, magnitude, power_setpoint,
                                                  noise_z, cooling_water_temp, obs, reward, done, trip_flags, info, h->step_kernel, h->diag, h->diag_pitch,
                                                  maint ? &table : nullptr, maint ? h->maint_side : nullptr, maint ? h->maint_counts : nullptr, (hipStream_t)stream);
-  h->last_kernel = launched & 0xff; h->last_launches = (launched >> 8) ? (launched >> 8) : 1;
   if (maint && h->params.mode != NPB_MODE_FULL)   /* a full-mode step kernel has run the rule itself, for the waves whose pump phase found something */
     (narrow ? npb32_launch_maint : npb_launch_maint)(NPB_N(h), h->f64, h->maint_side, h->maint_counts, h->n_plants, (hipStream_t)stream);
   hipError_t e = hipGetLastError();

@@ -55,10 +55,11 @@ extern "C" __attribute__((visibility("default"))) int npb_debug_set_stamp_buffer
 
 #define NPB_OBS_PAD 23 /* LDS row stride in doubles: 22 + 1 keeps the transpose at <= 2-way bank conflicts */
 
-/* ---- segmented arena.  A handle of more than NPB_SEGMENT_PLANTS plants keeps its arena in SEGMENTS of that many plants: segment s
+/* ---- segmented arena.  A handle of 45 057 .. 114 688 plants keeps its arena in SEGMENTS of 16 384 plants: segment s
  * is the whole [column][plant] block of plants s * seg .. (s + 1) * seg - 1, so a launch over one segment sweeps one dense range of
- * memory (two handles of 32 768 plants step 4-6 % faster than one of 65 536 laid out column by column over all plants, and the same
- * two launches inside one arena only do when each has its segment to itself: profiles/r3_shared_launches.txt).  Every kernel takes
+ * memory (two handles of 32 768 plants step 4-6 % faster than one of 65 536 laid out column by column over all plants,
+ * profiles/r3_shared_launches.txt; what makes the difference is not the launch per handle but the layout: one launch of the four-wave kernel
+ * over a segmented arena is as fast, profiles/r3_segment_size.txt).  Every kernel takes
  * the arena pointer and "N", the column pitch in plants, whose upper 32 bits carry the segment size (0 = one segment); with
  *   address(column, plant p) = arena + s * seg * columns + column * seg + (p - s * seg) = [arena + s * seg * (columns - 1)] + column * seg + p
  * a kernel only has to move its base pointer once, by its plant's segment, and use the segment size as its pitch. */
@@ -765,12 +766,13 @@ extern "C" void NPB_LAUNCHER(field_set)(void *arena, size_t npad, int col, int s
 /* fp64-storage plants above which the sweep of a step (4 221 B per plant) is so far past the 256 MB Infinity Cache that streaming
  * state stores win (measured: even at 81 920, -5 % at 98 304, -10 % at 131 072); fp32 storage moves half the bytes */
 #define NPB_NT_STORE_ABOVE ((size_t)90112)
-/* plants (of either storage type) between which a batch goes to the four-wave kernel in one launch per arena segment of 32 768 plants
- * (two or three launches; npb_api.hip segments the arena of exactly these handles).  Measured (profiles/r3_segment_sweep.txt): 49 152 plants
- * the two-wave kernel 0.079 ms against 0.081, 57 344 0.090 against 0.087, 65 536 the one-wave kernel 0.0954 against 0.0930, 81 920 0.166
- * against 0.135, 98 304 the streaming build 0.177 against 0.156; with four launches (106 496: 0.204) the streaming build is ahead again */
-#define NPB_SHARED_FROM ((size_t)53248)
-#define NPB_SHARED_UP_TO ((size_t)98304)
+/* plants (of either storage type) between which npb_create segments the arena (NPB_ARENA_SEGMENT_PLANTS per segment, "segmented arena"
+ * above) and npb_step gives the batch to the four-wave kernel although its groups no longer fit at once.  Measured
+ * (profiles/r3_segment_sweep.txt, r3_segment_size.txt): 65 536 plants 0.0906 ms against the one-wave kernel's 0.0956 on a one-block arena
+ * (the four-wave kernel there: 0.0975); 49 152 0.0784 against the two-wave kernel's 0.0792, 40 960 level; 81 920 0.122 against 0.166;
+ * 106 496 0.169 against the streaming build's 0.175, 131 072 0.202 against 0.193 */
+#define NPB_SEGMENTED_FROM ((size_t)45056)
+#define NPB_SEGMENTED_UP_TO ((size_t)114688)
 /* the table as the step kernels' pump phase evaluates it (npd_maintenance.h): a strict comparison as the sign of fma(value, sgn, c);
  * any other comparison kind in the scan makes every (wave, pump) "look properly" */
 static void npd_maint_fold_table(const npb_params_t *P, const npb_maint_table_t *T, npd_maint_hot_t *H) {
@@ -817,36 +819,25 @@ extern "C" int NPB_LAUNCHER(step)(const npb_params_t *P, int n_plants, size_t np
    * once the one-wave kernel has a wave for every SIMD its LDS-DMA pipeline wins (measured crossovers).
    * variant: 0 = by batch size, 1 = one wave per 64 plants, 2 = two waves, 3 = their two-per-SIMD build, 4 = one wave with
    * streaming state stores (what 0 picks once the sweep is far past the Infinity Cache), 5 = four waves (npd_step4.h: what 0
-   * picks while all its waves are resident at once, up to 32 768 plants), 6 = the same in launches of at most 32 768 plants (what 0
-   * picks between 53 249 and 98 304 plants).  The return value's low byte names the kernel, the next byte the number of launches.
-   * The primary + steam-generator
+   * picks while all its waves are resident at once, up to 32 768 plants, and again on the segmented arenas of 45 057 .. 114 688
+   * plants).  The primary + steam-generator
    * mode always takes a one-wave kernel.  The return value names the kernel that was launched (npb_debug_last_step_kernel). */
   if (P->mode == NPB_MODE_PRIMARY) {
     hipLaunchKernelGGL(npb_step_primary_kernel, grid, block, 0, stream, *P, n_plants, npad_seg, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, obs, reward, done, trip_flags, info);
     return NPB_KERNEL_STEP_PRIMARY;
   }
-  if (variant == 0) variant = npad <= 32768 ? 5 : (npad <= NPB_SHARED_FROM ? 2 : (npad <= NPB_SHARED_UP_TO ? 6 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1)));
+  if (variant == 0) variant = npad <= 32768 ? 5 : (npad <= NPB_SEGMENTED_FROM ? 2 : (npad <= NPB_SEGMENTED_UP_TO ? 5 : (npad * sizeof(npd_real_t) > NPB_NT_STORE_ABOVE * 8 ? 4 : 1)));
   const bool with_maint = maint_rc != nullptr;     /* the builds with the automatic maintenance compiled in */
   if (variant == 4) {
     hipLaunchKernelGGL(with_maint ? npb_step_nt_maint_kernel : npb_step_nt_kernel, grid, block, 0, stream, *P, n_plants, npad_seg, (npd_real_t *)arena, action, magnitude, setpoint,
                        noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
     return with_maint ? NPB_KERNEL_STEP_NT_MAINT : NPB_KERNEL_STEP_NT;
   }
-  if ((variant == 5 || variant == 6) && P->mode == NPB_MODE_FULL) {
-    /* four waves per 64 plants (npd_step4.h).  Variant 6: in launches of at most 32 768 plants each, so that every wave of a launch
-     * is resident at once: past 65 536 plants the one-wave kernel needs a second round of waves (69 632 plants: 0.166 ms), three
-     * such launches step 81 920 plants in 0.140 ms (profiles/r3_shared_launches.txt, which is about the sizes where
-     * this does NOT pay).  One launch per arena segment (above), so each sweeps one dense range of memory. */
-    const size_t groups = npad / NPB_WAVE, per = (seg ? seg : (size_t)32768) / NPB_WAVE;       /* groups of 64 plants: all, per launch */
-    const uint32_t parts = variant == 6 ? (uint32_t)((groups + per - 1) / per) : 1;
-    for (uint32_t part = 0; part < parts; part++) {
-      const size_t first = parts == 1 ? 0 : part * per, count = parts == 1 ? groups : (groups - first < per ? groups - first : per);
-      hipLaunchKernelGGL(with_maint ? npb_step4_maint_kernel : npb_step4_kernel, dim3((unsigned)count), dim3(NPD4_THREADS), 0, stream, *P, n_plants, npad_seg,
-                         (npd_real_t *)arena, action, magnitude, setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC,
-                         (uint32_t)first);
-    }
-    return (with_maint ? NPB_KERNEL_STEP4_MAINT : NPB_KERNEL_STEP4) | ((int)parts << 8);
+  if (variant == 5 && P->mode == NPB_MODE_FULL) {     /* four waves per 64 plants (npd_step4.h) */
+    hipLaunchKernelGGL(with_maint ? npb_step4_maint_kernel : npb_step4_kernel, grid, dim3(NPD4_THREADS), 0, stream, *P, n_plants, npad_seg, (npd_real_t *)arena, action, magnitude,
+                       setpoint, noise_z, cw_temp, obs, reward, done, trip_flags, info, MH, maint_rc, MC);
+    return with_maint ? NPB_KERNEL_STEP4_MAINT : NPB_KERNEL_STEP4;
   }
   const bool two_wave = (variant == 2 || variant == 3) && P->mode == NPB_MODE_FULL;
   const bool wide = two_wave && variant == 2 && npad <= 32768;   /* the whole register file while one wave per SIMD is all there is; variant 3 = never */

@@ -205,14 +205,12 @@ __device__ __forceinline__ void npd_step4_body(
     const int32_t *__restrict__ action, const double *__restrict__ magnitude, const double *__restrict__ setpoint,
     const double *__restrict__ noise_z, const double *__restrict__ cw_temp, double *__restrict__ obs_out,
     double *__restrict__ reward_out, uint8_t *__restrict__ done_out, uint32_t *__restrict__ trip_out,
-    double *__restrict__ info_out, const npd_maint_hot_t &MH, const npd_maint_rule_consts_t *maint_rc, const npd_maint_cache_t &MC, uint32_t first_group) {
+    double *__restrict__ info_out, const npd_maint_hot_t &MH, const npd_maint_rule_consts_t *maint_rc, const npd_maint_cache_t &MC) {
   __shared__ __attribute__((aligned(16))) double xch[NPD4_SLOTS * NPB_WAVE];
   const int lane = threadIdx.x & (NPB_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* wave-uniform role 0 .. 3 */
   const int my_pump = (wave == 3) ? 0 : (wave == 0 ? 3 : wave);         /* the primary side's wave takes the spare pump, normally the cheap one */
-  /* which 64 plants: `first_group` is 0 when one launch takes the whole batch; a batch past 65 536 plants goes in one launch per arena
-   * segment (npb_kernels.hip), each with all its waves resident at once */
-  const size_t block_base = ((size_t)first_group + blockIdx.x) * NPB_WAVE;
+  const size_t block_base = (size_t)blockIdx.x * NPB_WAVE;
   if (block_base >= (size_t)n_plants) return;       /* a group of padding only: the whole group leaves */
   NPD_SEGMENT(f64, N, block_base);
   const size_t p = block_base + lane;
@@ -777,7 +775,7 @@ __device__ __forceinline__ void npd_step4_body(
 }
 
 /* two waves per SIMD (<= 256 registers each): 2 048 waves = 32 768 plants resident at once */
-__global__ __launch_bounds__(NPD4_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void npb_step4_kernel(NPD2_KERNEL_ARGS, uint32_t first_group) { npd_step4_body<6, false>(NPD2_KERNEL_PASS, first_group); }
-__global__ __launch_bounds__(NPD4_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void npb_step4_maint_kernel(NPD2_KERNEL_ARGS, uint32_t first_group) { npd_step4_body<6, true>(NPD2_KERNEL_PASS, first_group); }
+__global__ __launch_bounds__(NPD4_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void npb_step4_kernel(NPD2_KERNEL_ARGS) { npd_step4_body<6, false>(NPD2_KERNEL_PASS); }
+__global__ __launch_bounds__(NPD4_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void npb_step4_maint_kernel(NPD2_KERNEL_ARGS) { npd_step4_body<6, true>(NPD2_KERNEL_PASS); }
 
 #endif

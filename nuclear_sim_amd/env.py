@@ -199,19 +199,14 @@ class BatchedPlantEnv:
     # ------------------------------------------------------------------ helpers
     def set_step_kernel(self, variant: int) -> None:
         """0 = by batch size (default), 1 = one-wave kernel, 2 = two-wave kernel, 3 = its 256-register build at any size, 4 = the
-        one-wave kernel with streaming state stores (what 0 takes above 98 304 plants), 5 = four-wave kernel (what 0 takes up
-        to 32 768 plants), 6 = the same in launches of at most 32 768 plants (what 0 takes between 53 249 and 98 304); same
-        results to the last bit or two (include/npb.h)"""
+        one-wave kernel with streaming state stores (what 0 takes above 114 688 plants), 5 = four-wave kernel (what 0 takes up
+        to 32 768 plants and between 45 057 and 114 688, where the handle's arena is segmented); same results to the last bit
+        or two (include/npb.h)"""
         _lib.check(self.L.npb_set_step_kernel(self._h, int(variant)), self._h)
 
     def last_step_kernel(self) -> str:
         """the kernel the last step() actually launched, by the name rocprofv3 lists it under ("" before the first step)"""
         return self.L.npb_step_kernel_name(self.L.npb_debug_last_step_kernel(self._h)).decode()
-
-    def last_step_launches(self) -> int:
-        """in how many launches of that kernel (batches between 53 249 and 98 304 plants go to the four-wave kernel in launches of
-        at most 32 768 plants each)"""
-        return int(self.L.npb_debug_last_step_launches(self._h))
 
     def enable_diagnostics(self, on: bool = True):
         """Have every following step also write the step-internal diagnostics (include/npb.h NPB_DIAG_*: per turbine stage inlet /

@@ -117,13 +117,13 @@ def test_bench_names_the_kernel_the_launcher_picks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "nuclear_sim_amd", "csrc", "npb_kernels.hip")).read()
     four_wave_up_to = int(re.search(r"variant = npad <= (\d+) \? 5", src).group(1))
-    shared_from = int(re.search(r"#define NPB_SHARED_FROM \(\(size_t\)(\d+)\)", src).group(1))
-    shared_up_to = int(re.search(r"#define NPB_SHARED_UP_TO \(\(size_t\)(\d+)\)", src).group(1))
-    assert re.search(r"\(npad <= NPB_SHARED_FROM \? 2 : \(npad <= NPB_SHARED_UP_TO \? 6", src)
+    shared_from = int(re.search(r"#define NPB_SEGMENTED_FROM \(\(size_t\)(\d+)\)", src).group(1))
+    shared_up_to = int(re.search(r"#define NPB_SEGMENTED_UP_TO \(\(size_t\)(\d+)\)", src).group(1))
+    assert re.search(r"\(npad <= NPB_SEGMENTED_FROM \? 2 : \(npad <= NPB_SEGMENTED_UP_TO \? 5", src)
     nt_above = int(re.search(r"#define NPB_NT_STORE_ABOVE \(\(size_t\)(\d+)\)", src).group(1))
     wide_up_to = int(re.search(r"const bool wide = .* npad <= (\d+);", src).group(1))
     assert re.search(r"const bool wide = two_wave && variant == 2 && npad <= \d+;", src)      # variant 3 never takes the wide build
-    # the handles whose arena npb_create segments are exactly the ones npb_step splits into one launch per segment
+    # the handles whose arena npb_create segments are exactly the ones past 32 768 plants that npb_step gives to the four-wave kernel
     api = open(os.path.join(root, "nuclear_sim_amd", "csrc", "npb_api.hip")).read()
     assert re.search(r"h->pitch > %d && h->pitch <= %d" % (shared_from, shared_up_to), api)
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
@@ -134,7 +134,7 @@ def test_bench_names_the_kernel_the_launcher_picks():
         assert bench.step_kernel_name(64) == bench.step_kernel_name(four_wave_up_to) == "npb_step4_kernel"
         assert bench.step_kernel_name(four_wave_up_to, maintenance=True) == "npb_step4_maint_kernel"
         assert bench.step_kernel_name(four_wave_up_to + 64) == bench.step_kernel_name(shared_from) == "npb_step2_kernel"
-        # the four-wave kernel in one launch per arena segment, then the one-wave kernel's streaming build
+        # the four-wave kernel again, on a segmented arena, then the one-wave kernel's streaming build
         assert bench.step_kernel_name(shared_from + 64) == bench.step_kernel_name(65536) == bench.step_kernel_name(shared_up_to) == "npb_step4_kernel"
         assert shared_up_to > nt_above
         assert bench.step_kernel_name(shared_up_to + 64) == "npb_step_nt_kernel" and bench.step_kernel_name(shared_up_to + 64, "f32") == "npb_step_kernel"
@@ -146,7 +146,7 @@ def test_bench_names_the_kernel_the_launcher_picks():
             assert bench.step_kernel_name(n, forced="4") == "npb_step_nt_kernel"
             assert bench.step_kernel_name(n, forced="3") == "npb_step2_kernel"
             assert bench.step_kernel_name(n, forced="2") == ("npb_step2_wide_kernel" if n <= wide_up_to else "npb_step2_kernel")
-            assert bench.step_kernel_name(n, forced="5") == bench.step_kernel_name(n, forced="6") == "npb_step4_kernel"
+            assert bench.step_kernel_name(n, forced="5") == "npb_step4_kernel"
         os.environ["NPB_STEP_KERNEL"] = "3"
         assert bench.step_kernel_name(64) == "npb_step2_kernel"
     finally:

@@ -682,8 +682,8 @@ def test_full_size_against_the_oracle_on_a_sample(oracle_lib, storage, n, T):
     the oracle with its state rounded to float after every step, the same algorithm.)  At 131 072 plants npb_step takes the
     streaming build of the one-wave kernel (two rounds of waves, state stores past the caches), at 40 960 the 256-register
     build of the two-wave kernel (32 769 .. 57 344 plants), at 32 768 -- BASELINE config 4's share per GPU -- the
-    four-wave kernel, at 65 536 and at 81 900 (ragged: the last group of 64 is partly padding) the four-wave kernel in two / three
-    launches, one per segment of the handle's segmented arena; each run asserts that kernel and the number of launches."""
+    four-wave kernel, at 65 536 and at 81 900 (ragged: the last group of 64 is partly padding, the last segment of the arena partly
+    empty) the four-wave kernel on the handle's segmented arena; each run asserts that kernel."""
     import torch
     import bench
     want_kernel = {65536: "npb_step4_kernel", 131072: "npb_step_nt_kernel", 40960: "npb_step2_kernel", 32768: "npb_step4_kernel", 81900: "npb_step4_kernel"}[n]
@@ -706,7 +706,6 @@ def test_full_size_against_the_oracle_on_a_sample(oracle_lib, storage, n, T):
         z = rng.standard_normal(n)
         obs, rew, done, info = env.step(power_setpoint=sp, noise_z=z)
         assert env.last_step_kernel() == want_kernel
-        assert env.last_step_launches() == {81900: 3, 65536: 2}.get(n, 1)
         o_obs, o_rew, o_done, o_flags, _ = ora.step(setpoint=sp[sample], noise_z=z[sample])
         if narrow:
             ora.round_state_f32()
@@ -1209,6 +1208,46 @@ def test_state_log_reproduces_the_references_log_column_by_column(fixture):
                     if t < g.T:
                         ok[t] = True
             assert ok.all(), (name, int(np.argmin(ok)), mine[~ok, lane][:3], want[~ok][:3])
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_segmented_arena_is_only_a_layout(variant, monkeypatch):
+    """A handle of 45 057 .. 114 688 plants keeps its arena in segments of 16 384 plants (include/npb.h, npb_state_arena): every
+    kernel that addresses the arena -- init, field get / set, the gather, reset, observe, the step kernels, the maintenance rule --
+    moves its base pointer by its plant's segment and otherwise runs the same code, so a ragged batch stepped on a segmented arena
+    and on a one-block arena (NPB_ARENA_SEGMENT=0) must agree in every column and every output to the bit, with the four-wave
+    kernel npb_step picks there and with the one-wave kernel forced."""
+    import torch
+    n, T = 50000, 6          # ragged: the last group is partly padding, the last (fourth) segment 848 plants
+
+    def run(segment):
+        if segment is None:
+            monkeypatch.delenv("NPB_ARENA_SEGMENT", raising=False)
+        else:
+            monkeypatch.setenv("NPB_ARENA_SEGMENT", segment)
+        env = _env(n=n, dt=5.0, noise_enabled=True, maintenance=True)
+        assert int(env.L.npb_state_arena_segment(env._h)) == (16384 if segment is None else 0)
+        env.set_step_kernel(variant)
+        r = np.random.default_rng(3)
+        for k in range(4):
+            env.set_field("pump.oil_level", r.uniform(8.0, 100.0, n), instance=k)
+        env.set_field("prim.coolant_flow_rate", np.where(r.random(n) < 0.1, 4500.0, 20000.0))
+        outs = []
+        for t in range(T):
+            obs, rew, done, info = env.step(power_setpoint=r.uniform(60, 100, n), noise_z=r.standard_normal(n))
+            outs.append([x.cpu().numpy().copy() for x in (obs, rew, done, info["trip_flags"], info["electrical_power"], info["maintenance_event_count"])])
+        assert env.last_step_kernel() == ("npb_step4_maint_kernel" if variant == 0 else "npb_step_maint_kernel")
+        outs.append([env.reset(mask=torch.as_tensor(r.random(n) < 0.01, device=env.device), reference=True).cpu().numpy().copy()])
+        f, i = _host_state(env)
+        return outs, f, i
+
+    o_seg, f_seg, i_seg = run(None)
+    o_one, f_one, i_one = run("0")
+    assert np.array_equal(i_seg, i_one) and np.array_equal(f_seg.view(np.int64), f_one.view(np.int64))
+    for a, b in zip(o_seg, o_one):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)
+    assert (i_seg != 0).any()
 
 
 def test_largest_handle_uses_the_whole_32bit_offset_range():

@@ -72,11 +72,7 @@ def summarize(out):
     from nuclear_sim_amd.env import BatchedPlantEnv
     # this workload's handle runs a ConstantHeatSource (the 12 point-kinetics columns are neither read nor written:
     # -12 * 16 B) and passes action / magnitude / cooling-water temperature as NULL (-20 B), as bench.py does
-    # a batch of 53 249 .. 98 304 plants is one launch of the four-wave kernel per arena segment: K steps = K * launches dispatches
-    fetch = res.get("FETCH_SIZE")
-    per_step = max(1, round(fetch["launches"] / K)) if isinstance(fetch, dict) and fetch.get("launches") else 1
-    res["launches_per_step"] = per_step
-    res["algorithmic_bytes_per_launch"] = (BatchedPlantEnv.step_bytes_per_plant() - 12 * 16 - 20) * N / per_step
+    res["algorithmic_bytes_per_launch"] = (BatchedPlantEnv.step_bytes_per_plant() - 12 * 16 - 20) * N
     print(json.dumps(res, indent=1))
 
 
