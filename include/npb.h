@@ -199,10 +199,11 @@ NPB_API int npb_set_field(NpbHandle *h, int kind, int slot, const void *buf, int
 NPB_API int npb_gather_fields(NpbHandle *h, int n_fields, const int *kinds, const int *slots, double *out, void *stream);
 /* raw arena (checkpointing, external kernels): one allocation of equally wide columns, column-major with `pitch`
  * plants per column; the members of the schema are mapped onto columns as include/npb_fields.h describes.  A handle of
- * 45 057 .. 114 688 plants keeps its arena in SEGMENTS (npb_state_arena_segment(h) plants each -- 16 384 --, 0 = not
+ * more than 45 056 plants keeps its arena in SEGMENTS (npb_state_arena_segment(h) plants each -- 16 384 --, 0 = not
  * segmented): the allocation is then consecutive [columns][pitch] blocks, pitch = the segment size, block s holding
  * plants s * pitch .. (s + 1) * pitch - 1 -- plant p's element of column c is at (p / pitch) * pitch * columns +
- * c * pitch + p % pitch.  (Measured: the step of 65 536 plants is 5 % faster on such an arena than on one block.) */
+ * c * pitch + p % pitch.  (Measured: the step of 65 536 plants is 5 % faster on such an arena than on one block, that
+ * of 262 144 plants 10 %.) */
 NPB_API int npb_state_arena(NpbHandle *h, void **arena, size_t *pitch, int *storage);
 NPB_API size_t npb_state_arena_segment(const NpbHandle *h);
 /* (With params.maint_enabled the step kernels consult a cache of which maintenance thresholds are inside their cooldown; every
@@ -242,8 +243,8 @@ NPB_API int npb_set_diagnostics(NpbHandle *h, double *buf, size_t pitch);
  * 256-register build at any size, 4 = the one-wavefront kernel with streaming (non-temporal) state stores, which 0 takes
  * above ~90 000 plants of fp64 storage, where nothing a step writes is still cached when the next step reads it, 5 = four
  * wavefronts per 64 plants handing values to each other through progress words in LDS (what 0 takes up to 32 768 plants,
- * where all of its 2 048 wavefronts are resident at once, and again between 45 057 and 114 688 plants, whose handles keep
- * their arena in segments, npb_state_arena). */
+ * where all of its 2 048 wavefronts are resident at once, and again between 45 057 and 114 688 plants, on the segmented
+ * arena handles of that size have, npb_state_arena). */
 NPB_API int npb_set_step_kernel(NpbHandle *h, int variant);
 /* Which kernel the handle's last npb_step actually launched (NPB_KERNEL_NONE before the first step): the selection above is by
  * batch size, mode, storage and override, and a test or a benchmark that means to exercise one kernel asserts it here instead

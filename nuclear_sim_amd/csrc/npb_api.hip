@@ -222,11 +222,10 @@ int npb_create_storage(const npb_params_t *params, int n_plants, int device, int
   h->pitch = ((size_t)n_plants + 63) / 64 * 64;
   h->storage = storage; h->real_bytes = real_bytes;
   h->f64 = nullptr; h->convert = nullptr; h->plan_dev = nullptr;
-  /* batches that npb_step gives to the four-wave kernel although they do not fit at once keep their arena in segments of 16 384 plants
-   * (npb_kernels.hip, "segmented arena") */
+  /* batches past the two-wave kernel's range keep their arena in segments of 16 384 plants (npb_kernels.hip, "segmented arena") */
   {   /* NPB_ARENA_SEGMENT=0 turns it off, =<plants> (a multiple of 64) forces that segment size at any batch size: A/B aids */
     const char *e2 = getenv("NPB_ARENA_SEGMENT");
-    h->seg = (h->pitch > 45056 && h->pitch <= 114688) ? 16384 : 0;     /* = NPB_SEGMENTED_FROM .. NPB_SEGMENTED_UP_TO of npb_kernels.hip */
+    h->seg = h->pitch > 45056 ? 16384 : 0;     /* from NPB_SEGMENTED_FROM of npb_kernels.hip on: the four-wave kernel's second range and everything above it */
     if (e2) { const long v = atol(e2); h->seg = (v > 0 && v % 64 == 0 && (size_t)v < h->pitch) ? (size_t)v : 0; }
   }
   e = hipMalloc(&h->f64, arena_columns(storage) * arena_plants(h) * real_bytes);

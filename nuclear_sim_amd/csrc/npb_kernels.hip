@@ -55,7 +55,7 @@ extern "C" __attribute__((visibility("default"))) int npb_debug_set_stamp_buffer
 
 #define NPB_OBS_PAD 23 /* LDS row stride in doubles: 22 + 1 keeps the transpose at <= 2-way bank conflicts */
 
-/* ---- segmented arena.  A handle of 45 057 .. 114 688 plants keeps its arena in SEGMENTS of 16 384 plants: segment s
+/* ---- segmented arena.  A handle of more than 45 056 plants keeps its arena in SEGMENTS of 16 384 plants: segment s
  * is the whole [column][plant] block of plants s * seg .. (s + 1) * seg - 1, so a launch over one segment sweeps one dense range of
  * memory (two handles of 32 768 plants step 4-6 % faster than one of 65 536 laid out column by column over all plants,
  * profiles/r3_shared_launches.txt; what makes the difference is not the launch per handle but the layout: one launch of the four-wave kernel
@@ -766,11 +766,12 @@ extern "C" void NPB_LAUNCHER(field_set)(void *arena, size_t npad, int col, int s
 /* fp64-storage plants above which the sweep of a step (4 221 B per plant) is so far past the 256 MB Infinity Cache that streaming
  * state stores win (measured: even at 81 920, -5 % at 98 304, -10 % at 131 072); fp32 storage moves half the bytes */
 #define NPB_NT_STORE_ABOVE ((size_t)90112)
-/* plants (of either storage type) between which npb_create segments the arena (NPB_ARENA_SEGMENT_PLANTS per segment, "segmented arena"
- * above) and npb_step gives the batch to the four-wave kernel although its groups no longer fit at once.  Measured
+/* plants (of either storage type) from which on npb_create segments the arena ("segmented arena" above), and between which npb_step gives
+ * the batch to the four-wave kernel although its groups no longer fit at once.  Measured
  * (profiles/r3_segment_sweep.txt, r3_segment_size.txt): 65 536 plants 0.0906 ms against the one-wave kernel's 0.0956 on a one-block arena
  * (the four-wave kernel there: 0.0975); 49 152 0.0784 against the two-wave kernel's 0.0792, 40 960 level; 81 920 0.122 against 0.166;
- * 106 496 0.169 against the streaming build's 0.175, 131 072 0.202 against 0.193 */
+ * 106 496 0.169 against the streaming build's 0.175, 131 072 0.202 against 0.193; the streaming build itself gains 2 % at 131 072 plants
+ * and 10 % at 262 144 from the segments (profiles/r3_segment_size.txt) */
 #define NPB_SEGMENTED_FROM ((size_t)45056)
 #define NPB_SEGMENTED_UP_TO ((size_t)114688)
 /* the table as the step kernels' pump phase evaluates it (npd_maintenance.h): a strict comparison as the sign of fma(value, sgn, c);

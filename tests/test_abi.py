@@ -123,9 +123,9 @@ def test_bench_names_the_kernel_the_launcher_picks():
     nt_above = int(re.search(r"#define NPB_NT_STORE_ABOVE \(\(size_t\)(\d+)\)", src).group(1))
     wide_up_to = int(re.search(r"const bool wide = .* npad <= (\d+);", src).group(1))
     assert re.search(r"const bool wide = two_wave && variant == 2 && npad <= \d+;", src)      # variant 3 never takes the wide build
-    # the handles whose arena npb_create segments are exactly the ones past 32 768 plants that npb_step gives to the four-wave kernel
+    # npb_create segments the arena from the four-wave kernel's second range on
     api = open(os.path.join(root, "nuclear_sim_amd", "csrc", "npb_api.hip")).read()
-    assert re.search(r"h->pitch > %d && h->pitch <= %d" % (shared_from, shared_up_to), api)
+    assert re.search(r"h->seg = h->pitch > %d \? 16384 : 0;" % shared_from, api)
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
     old = os.environ.pop("NPB_STEP_KERNEL", None)
