@@ -257,6 +257,7 @@ __device__ __forceinline__ void npd_step4_body(
     npb_fw_t fw; npb_fw_t fw_old;
     double prev_levels[NPB_NUM_SG];
     double prev_feedwater_temp = 0.0, cw_old = 0.0, operating_hours = 0.0, cooling_water_temperature = 0.0, actual_feedwater_temp = 0.0;
+    __builtin_amdgcn_s_setprio(3);                 /* the level control gates all four pumps */
     /* ---- secondary prelude (secondary/__init__.py:371-453), feedwater level control */
     double maint_entry = 0.0;
     if (maint && lane < NPD_MH_N) maint_entry = MH.tab[lane];
@@ -295,11 +296,13 @@ __device__ __forceinline__ void npd_step4_body(
     XW(Y_MAXLVL, npd_pymax3(prev_levels[0], prev_levels[1], prev_levels[2]));
     if (maint && lane < NPD_MH_N) maint_tab[lane] = maint_entry;
     NPD4_FLAG_SET(FL_FWCTL, 1);
+    __builtin_amdgcn_s_setprio(0);
     NPD4_STAMP(1);
     NPD4_PUMP(0, (void)0);
     NPD4_STAMP(2);
     NPD4_FLAG_WAIT(FL_PUMP + 1, 1); NPD4_FLAG_WAIT(FL_PUMP + 2, 1); NPD4_FLAG_WAIT(FL_PUMP + 3, 1);
     NPD4_STAMP(3);
+    __builtin_amdgcn_s_setprio(3);                 /* the feedwater flow gates the steam generators' second halves */
     npb_turb_t t; npb_turb_t t_old;
     double fw_total_flow = 0.0, fw_total_power = 0.0;
     int fw_available = 0; uint32_t trip_flags = 0;
@@ -318,6 +321,7 @@ __device__ __forceinline__ void npd_step4_body(
     /* the steam generators wait for this in their part 2 */
     XW(Y_FWFLOW, fw_total_flow);
     NPD4_FLAG_SET(FL_FWFLOW, 1);
+    __builtin_amdgcn_s_setprio(0);
     NPD4_STAMP(4);
     /* while the steam generators run: the turbine section (asked for before the feedwater section goes back) */
     NPD_ST_LOAD(TURB, npb_turb_t, t, 0);          /* wave 1 owns the lub_* members; they are neither used nor stored here */
@@ -328,6 +332,7 @@ __device__ __forceinline__ void npd_step4_body(
     NPD4_STAMP(5);
     NPD4_FLAG_WAIT(FL_SG + 0, 1); NPD4_FLAG_WAIT(FL_SG + 1, 1); NPD4_FLAG_WAIT(FL_SG + 2, 1);
     NPD4_STAMP(6);
+    __builtin_amdgcn_s_setprio(3);                 /* pass A gates everything the other three waves do next */
     double sg_total_thermal = 0.0, sg_total_steam = 0.0, sg_avg_pressure = 0.0, sg_avg_temperature = 0.0, sg_avg_quality = 0.0;
     int sg_system_availability = 0;
     double pressure_stability_factor = 1.0, load_demand = 0.0;
@@ -389,11 +394,13 @@ __device__ __forceinline__ void npd_step4_body(
 #undef NPD_EXT_IDX
 #undef NPD_IS_EXT
     }
+    __builtin_amdgcn_s_setprio(0);
     NPD4_STAMP(7);
     npd4_pass_b_units<12, 1, 3, 2>(xch, lane);     /* the last three saturation states, which the other two waves would reach last */
     npd4_stage_post<2>(st, old, xch, lane, tdt);
     NPD4_STAMP(8);
     NPD4_FLAG_WAIT(FL_CHAINDONE, 1);               /* wave 1's chain: total power, extraction, efficiency ... */
+    __builtin_amdgcn_s_setprio(3);                 /* rotor -> protection -> tail: the critical path again */
     const double stage_power_mw = XR(Y_CHRES + 0) * pressure_stability_factor;
     const double turbine_efficiency = XR(Y_CHRES + 5), hp_power = XR(Y_CHRES + 3), lp_power = XR(Y_CHRES + 4);
     double max_bearing_metal = 0.0, total_displacement = 0.0;
@@ -426,6 +433,7 @@ __device__ __forceinline__ void npd_step4_body(
     XW(Y_TAIL + 15, turbine_efficiency); XW(Y_TAIL + 16, hp_power); XW(Y_TAIL + 17, lp_power); XW(Y_TAIL + 18, (double)trip_flags);
     XW(Y_TAIL + 19, actual_feedwater_temp); XW(Y_TAIL + 20, (double)fw_available);
     NPD4_FLAG_SET(FL_TAIL, 1);
+    __builtin_amdgcn_s_setprio(0);
     NPD4_STAMP(11);
     {   /* the turbine section but for the lubrication's members, behind the tail (nobody waits for it) and behind wave 2's load of
          * the PREVIOUS step's rotor state for the lubrication pre-step (update_with_lubrication reads it before the rotor moves) */
@@ -564,6 +572,7 @@ __device__ __forceinline__ void npd_step4_body(
         stage_eff[k] = (actual_efficiency * blade_condition_factor * fouling_factor * blade_wear_factor * 1.0);
       }
       NPD4_STAMP(7);
+      __builtin_amdgcn_s_setprio(3);               /* the chain is the group's critical path from here to its last stage */
       NPD4_FLAG_WAIT(FL_PASSA, 1);
       const double sg_avg_pressure = XR(Y_PIN), sg_avg_temperature = XR(Y_TIN), sg_total_steam = XR(Y_STEAM), load_demand = XR(Y_PRIM + 1);
       npd2_chain_t ch;
@@ -622,6 +631,7 @@ __device__ __forceinline__ void npd_step4_body(
       XW(Y_CHRES + 3, ch.hp_power); XW(Y_CHRES + 4, ch.lp_power); XW(Y_CHRES + 5, turbine_efficiency);
       XW(Y_CHRES + 6, sg_total_steam - ch.total_extraction);     /* the effective steam flow the condenser sees */
       NPD4_FLAG_SET(FL_CHAINDONE, 1);
+      __builtin_amdgcn_s_setprio(0);
       NPD4_STAMP(8);
     } else if (wave == 0) {
       npd4_stage_preload<0>(st, old); NPD4_STAMP(7); npd4_pass_b_units<0, 2, 6, 0>(xch, lane); NPD4_STAMP(8); npd4_stage_post<0>(st, old, xch, lane, tdt);
@@ -650,6 +660,7 @@ __device__ __forceinline__ void npd_step4_body(
       obs[11] = (double)(scram_bits & 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       NPD4_FLAG_WAIT(FL_TAIL, 1);
+      __builtin_amdgcn_s_setprio(2);
       NPD4_STAMP(10);
       const double ld = XR(Y_PRIM + 1), sg_total_steam_t = XR(Y_TAIL + 3), fw_flow_t = XR(Y_TAIL + 4);
       obs[10] = ld / 100;                          /* load_demand IS state.power_level (sim.py:161) */
@@ -717,6 +728,7 @@ __device__ __forceinline__ void npd_step4_body(
       NPD4_STAMP(13);
     } else {
       NPD4_FLAG_WAIT(FL_CHAINDONE, 1);
+      __builtin_amdgcn_s_setprio(2);               /* condenser -> info is what ends the step */
       /* ---- condenser (secondary/__init__.py:591-621) */
       const double effective_steam_flow = XR(Y_CHRES + 6), lp6_outlet_enthalpy = XR(Y_CHRES + 2), cwt = XR(Y_CWT);
       double lp_exhaust_quality = 0.90;
