@@ -21,8 +21,7 @@
  *   wave 1  chemistry sidecar -> [level control] pump 1 -> [primary] SG 1 -> stage efficiencies -> the stage chain, each stage as
  *           soon as its pass B unit is there (i.e. while pass A still runs) -> [verdict] -> turbine lubrication pre-step ->
  *           [tail, condenser] reward, write-back
- *   wave 2  [level control] pump 2 -> [primary] SG 2 -> units 1,3,..,11 -> [verdict] stage post 1,4,7,.. -> [chain] condenser ->
- *           [tail] info
+ *   wave 2  [level control] pump 2 -> [primary] SG 2 -> units 1,3,..,11 -> [verdict] stage post 1,4,7,.. -> [chain] condenser
  *
  * ([..] = what the wave waits for.)  Exactness: every device function is the one the other kernels call, sums over pumps / steam
  * generators / stages are taken in the reference's order by one wave from the values the others publish, and the one sequential
@@ -449,6 +448,26 @@ __device__ __forceinline__ void npd_step4_body(
       *NPD_NP(int32_t, NPD_SEC_COL(TURB, 0) + NC + 4 / NPD_NPC, 4 % NPD_NPC) = t.trip_active;
       *NPD_NP(int32_t, NPD_SEC_COL(TURB, 0) + NC + 5 / NPD_NPC, 5 % NPD_NPC) = t.trip_latched_mask;
     }
+    NPD4_FLAG_WAIT(FL_CONDP, 1);                   /* wave 2's condenser */
+    NPD4_STAMP(12);
+    if (info_out) {   /* info (sim.py:199-250) */
+      const double condenser_pressure = XR(Y_CONDP), electrical_power = XR(Y_TAIL + 0), thermal_efficiency = XR(Y_TAIL + 1);
+      const double sg_avg_pressure_t = XR(Y_TAIL + 2), sg_total_steam_t = XR(Y_TAIL + 3), heat_rejection = XR(Y_TAIL + 5);
+      double info[NPB_INFO_DIM];
+      info[NPB_INFO_THERMAL_POWER] = XR(Y_PRIM + 2); info[NPB_INFO_REACTIVITY_PCM] = XR(Y_PRIM + 3); info[NPB_INFO_TIME] = XR(Y_TIME);
+      info[NPB_INFO_ELECTRICAL_POWER] = isfinite(electrical_power) ? electrical_power : 0.0;
+      info[NPB_INFO_THERMAL_EFFICIENCY] = npd_pymax(0.0, npd_pymin(isfinite(thermal_efficiency) ? thermal_efficiency : 0.0, 0.35));
+      info[NPB_INFO_STEAM_FLOW] = isfinite(sg_total_steam_t) ? sg_total_steam_t : 1665.0;
+      info[NPB_INFO_STEAM_PRESSURE] = isfinite(sg_avg_pressure_t) ? sg_avg_pressure_t : 6.895;
+      info[NPB_INFO_CONDENSER_PRESSURE] = isfinite(condenser_pressure) ? condenser_pressure : 0.007;
+      info[NPB_INFO_CONDENSER_HEAT_REJECTION] = isfinite(heat_rejection) ? heat_rejection : 0.0;
+      info[NPB_INFO_FEEDWATER_FLOW] = XR(Y_TAIL + 4);
+      info[NPB_INFO_SG_HEAT_TRANSFER] = XR(Y_TAIL + 6); info[NPB_INFO_TURBINE_POWER] = XR(Y_TAIL + 13);
+      info[NPB_INFO_FEEDWATER_POWER] = XR(Y_TAIL + 14); info[NPB_INFO_PRIMARY_THERMAL_POWER] = XR(Y_PRIM + 4);
+      info[NPB_INFO_TURBINE_EFFICIENCY] = XR(Y_TAIL + 15); info[NPB_INFO_TURBINE_HP_POWER] = XR(Y_TAIL + 16); info[NPB_INFO_TURBINE_LP_POWER] = XR(Y_TAIL + 17);
+      npd2_store_rows<NPB_INFO_DIM>(info, info_out, xch + Y_INFO * NPB_WAVE, lane, block_base, (size_t)n_plants);
+    }
+    NPD4_STAMP(13);
   } else {
     /* ================================ waves 0 .. 2 ================================ */
     int scram_bits = 0;                               /* wave 0: scram_status | scram_fired << 1 | nan_reset << 2 */
@@ -747,25 +766,6 @@ __device__ __forceinline__ void npd_step4_body(
       NPD4_ST_STORE(COND, npb_cond_t, cd, cd_old, 0);
       NPD4_ST_STORE(CHEM, npb_chem_t, chc, chc_old, 1);
       NPD4_STAMP(10);
-      NPD4_FLAG_WAIT(FL_TAIL, 1); NPD4_FLAG_WAIT(FL_CONDP, 1);
-      NPD4_STAMP(11);
-      if (info_out) {   /* info (sim.py:199-250) */
-        const double condenser_pressure = XR(Y_CONDP), electrical_power = XR(Y_TAIL + 0), thermal_efficiency = XR(Y_TAIL + 1);
-        const double sg_avg_pressure_t = XR(Y_TAIL + 2), sg_total_steam_t = XR(Y_TAIL + 3), heat_rejection = XR(Y_TAIL + 5);
-        double info[NPB_INFO_DIM];
-        info[NPB_INFO_THERMAL_POWER] = XR(Y_PRIM + 2); info[NPB_INFO_REACTIVITY_PCM] = XR(Y_PRIM + 3); info[NPB_INFO_TIME] = XR(Y_TIME);
-        info[NPB_INFO_ELECTRICAL_POWER] = isfinite(electrical_power) ? electrical_power : 0.0;
-        info[NPB_INFO_THERMAL_EFFICIENCY] = npd_pymax(0.0, npd_pymin(isfinite(thermal_efficiency) ? thermal_efficiency : 0.0, 0.35));
-        info[NPB_INFO_STEAM_FLOW] = isfinite(sg_total_steam_t) ? sg_total_steam_t : 1665.0;
-        info[NPB_INFO_STEAM_PRESSURE] = isfinite(sg_avg_pressure_t) ? sg_avg_pressure_t : 6.895;
-        info[NPB_INFO_CONDENSER_PRESSURE] = isfinite(condenser_pressure) ? condenser_pressure : 0.007;
-        info[NPB_INFO_CONDENSER_HEAT_REJECTION] = isfinite(heat_rejection) ? heat_rejection : 0.0;
-        info[NPB_INFO_FEEDWATER_FLOW] = XR(Y_TAIL + 4);
-        info[NPB_INFO_SG_HEAT_TRANSFER] = XR(Y_TAIL + 6); info[NPB_INFO_TURBINE_POWER] = XR(Y_TAIL + 13);
-        info[NPB_INFO_FEEDWATER_POWER] = XR(Y_TAIL + 14); info[NPB_INFO_PRIMARY_THERMAL_POWER] = XR(Y_PRIM + 4);
-        info[NPB_INFO_TURBINE_EFFICIENCY] = XR(Y_TAIL + 15); info[NPB_INFO_TURBINE_HP_POWER] = XR(Y_TAIL + 16); info[NPB_INFO_TURBINE_LP_POWER] = XR(Y_TAIL + 17);
-        npd2_store_rows<NPB_INFO_DIM>(info, info_out, xch + Y_INFO * NPB_WAVE, lane, block_base, (size_t)n_plants);
-      }
       NPD4_STAMP(12);
     }
   }

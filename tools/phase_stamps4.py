@@ -20,10 +20,10 @@ LABELS = {
     1: ["chemistry sidecar", "wait: level control; pump 1", "wait: primary", "SG 1 part 1", "wait: feedwater flow", "SG 1 part 2", "stage efficiencies",
         "stage chain (behind pass B), wait: verdict", "-", "turbine lubrication pre-step", "-", "wait: tail, condenser", "reward, write-back"],
     2: ["-", "wait: level control; pump 2", "wait: primary", "SG 2 part 1", "wait: feedwater flow", "SG 2 part 2", "stage arrays preload", "pass B units 1,3,..",
-        "load condenser; wait: verdict; stage post (behind the chain)", "wait: chain; condenser", "wait: tail", "info"],
+        "load condenser; wait: verdict; stage post (behind the chain)", "wait: chain; condenser"],
     3: ["prelude, level control", "pump 0", "wait: pumps 1-3", "pump tails, system level", "fw store, turbine load, stage arrays preload",
         "wait: steam generators", "SG sums, stage pass A, verdict", "pass B units 12-14, stage post 2,5,8,11 (behind the chain)", "wait: chain; rotor", "wait: stage post",
-        "protection, gates, tail"],
+        "protection, gates, tail", "turbine section to the arena; wait: condenser", "info"],
 }
 
 
