@@ -475,17 +475,19 @@ __device__ __attribute__((noinline)) void npd_maint_rule_for_wave(const npd_main
                                                                  unsigned hit_bits, unsigned due_with_orders) {
   const npb_params_t &P = RC->P; const npb_maint_table_t &T = RC->T; const npd_maint_screen_t &S = RC->S;
   const double t = NPD_F64_COL(PRIM, npb_prim_t, sim_time, 0);
-  if (!due_with_orders) {   /* flagged by the screen alone: look properly before anything else is fetched */
-    bool work = false;
+  /* look properly, pump by pump, before anything heavy is fetched: the screen's bit k says "something may be new at pump k for some
+   * plant of the wave"; the second look says whether the scan below would record a violation there (npd_maint_scan_pump returns
+   * without touching anything when no threshold is crossed outside its cooldown), so a pump without one is not scanned at all --
+   * the pump and mpump sections are ~140 columns per pump, the second look 15 */
+  unsigned scan_bits = 0;
 #pragma unroll 1
-    for (int k = 0; k < NPB_NUM_PUMPS; k++) {
-      if ((hit_bits >> k) & 1u) work |= npd_maint_second_look(S, f64, N, p, k, t);
-    }
-    if (!__any(work)) { npd_maint_refresh_cache(S, MC.entry, f64, N, p, t); return; }
+  for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+    if (((hit_bits >> k) & 1u) && __any(npd_maint_second_look(S, f64, N, p, k, t))) scan_bits |= 1u << k;
   }
+  if (!due_with_orders && !scan_bits) { npd_maint_refresh_cache(S, MC.entry, f64, N, p, t); return; }
   npb_maint_t m;
   NPD_LOAD(MAINT, npb_maint_t, m, 0);
-  int dirty = 0;
+  int dirty = 0, executed = -1;      /* executed: the pump this lane's plant has just maintained (its readings have moved: scanned in any case) */
   /* ---- AutoMaintenanceSystem.update: one due order, the earliest created, is carried out */
   if (npd_maint_check_due(&m, &P, t)) {
     dirty = 1;
@@ -509,6 +511,7 @@ __device__ __attribute__((noinline)) void npd_maint_rule_for_wave(const npd_main
         NPD_LOAD(PUMP, npb_pump_t, pm, pick);
         npd_maint_execute(&pm, &P, pick_action, bearing);
         NPD_STORE(PUMP, npb_pump_t, pm, pick);
+        executed = pick;
         if (MC.diag && ((NPD_MA_HANDLER_MASK >> pick_action) & 1u)) {    /* pump_lubrication.py:642-643, 1636-1637: the flags of this step's state-log row (action types the dispatcher knows) */
           MC.diag[(size_t)(NPB_DIAG_PUMP_MAINTENANCE_OCCURRED + pick) * MC.diag_pitch + p] = 1.0;
           if (pick_action == NPB_MA_OIL_TOP_OFF) MC.diag[(size_t)(NPB_DIAG_PUMP_OIL_TOP_OFF_OCCURRED + pick) * MC.diag_pitch + p] = 1.0;
@@ -520,6 +523,7 @@ __device__ __attribute__((noinline)) void npd_maint_rule_for_wave(const npd_main
    * reference orders it) */
 #pragma unroll 1
   for (int k = 0; k < NPB_NUM_PUMPS; k++) {
+    if (!((scan_bits >> k) & 1u) && !__any(executed == k)) continue;
     npb_pump_t pm;
     NPD_LOAD(PUMP, npb_pump_t, pm, k);
     npb_mpump_t mp;
