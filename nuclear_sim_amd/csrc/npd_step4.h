@@ -23,7 +23,10 @@
  *           [tail, condenser] reward, write-back
  *   wave 2  [level control] pump 2 -> [primary] SG 2 -> units 1,3,..,11 -> [verdict] stage post 1,4,7,.. -> [chain] condenser
  *
- * ([..] = what the wave waits for.)  Exactness: every device function is the one the other kernels call, sums over pumps / steam
+ * ([..] = what the wave waits for.)  While a wave is on the group's critical path -- the level control, the pump tails, pass A, the
+ * chain, rotor to tail, the condenser, the observation -- it raises its priority (s_setprio).  The same kernel serves batches of
+ * 45 057 .. 114 688 plants, whose groups no longer fit at once, on the segmented arena such handles have (npb_kernels.hip).
+ * Exactness: every device function is the one the other kernels call, sums over pumps / steam
  * generators / stages are taken in the reference's order by one wave from the values the others publish, and the one sequential
  * dependence between pumps (the demand gate of FeedwaterPumpSystem.update_system, npd_step2.h) makes each pump wait for the one
  * before it and take the real count.
