@@ -55,7 +55,10 @@ enum { FL_CHAIN = 0, FL_FWFLOW = 1, FL_PRIM = 2, FL_FWCTL = 3, FL_PUMP = 4 /* +p
 #define NPD4_FLAGP(n) ((volatile int *)&xch[Y_FLAGS * NPB_WAVE + 2 * (n)])
 /* (a wave's LDS operations execute in issue order, so the word needs no wait behind the data, only the compiler's respect) */
 #define NPD4_FLAG_SET(n, v) do { asm volatile("" ::: "memory"); *NPD4_FLAGP(n) = (v); asm volatile("" ::: "memory"); } while (0)
-#define NPD4_FLAG_WAIT(n, v) do { while (__builtin_amdgcn_readfirstlane(*NPD4_FLAGP(n)) < (v)) __builtin_amdgcn_s_sleep(1); asm volatile("" ::: "memory"); } while (0)
+#ifndef NPD4_POLL_SLEEP
+#define NPD4_POLL_SLEEP 1                     /* s_sleep argument between two polls of a progress word (x 64 clocks) */
+#endif
+#define NPD4_FLAG_WAIT(n, v) do { while (__builtin_amdgcn_readfirstlane(*NPD4_FLAGP(n)) < (v)) __builtin_amdgcn_s_sleep(NPD4_POLL_SLEEP); asm volatile("" ::: "memory"); } while (0)
 /* pass B unit u (0 = the turbine inlet, k + 1 = stage k): up to 11 the even units are wave 0's and the odd ones wave 2's, the last
  * three wave 3's own once its pass A is through; each wave works through its units in rising order and counts them */
 #define NPD4_UNIT_WAIT(u) do { if ((u) < 12) NPD4_FLAG_WAIT(FL_UNIT + (u) % 2, (u) / 2 + 1); else NPD4_FLAG_WAIT(FL_UNIT + 2, (u) - 11); } while (0)
