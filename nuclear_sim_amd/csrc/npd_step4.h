@@ -162,7 +162,7 @@ __device__ __forceinline__ void npd4_pass_b_units(double *xch, int lane) {
 }
 
 /* pump i of FeedwaterPumpSystem.update_system, by whichever wave has it: waits for the level control's hand-out (and, with the
- * automatic maintenance, for the plants' clock from the primary side); if the demand gate could close (npd_step2.h), for the pump
+ * automatic maintenance, the plants' clock is the caller's maint_clock); if the demand gate could close (npd_step2.h), for the pump
  * before it and its count */
 #define NPD4_PUMP(i_, BEFORE_THE_STORE) \
   { \
@@ -170,12 +170,11 @@ __device__ __forceinline__ void npd4_pass_b_units(double *xch, int lane) {
     npb_pump_t pm; \
     NPD_ST_LOAD(PUMP, npb_pump_t, pm, i);      /* on its way while this wave polls */ \
     NPD4_FLAG_WAIT(FL_FWCTL, 1); \
-    if (maint) NPD4_FLAG_WAIT(FL_PRIM, 1); \
     const int n_prev_running = (int)XR(Y_NPREV); \
     const double flow_per_pump = XR(Y_FPP); \
     npd_pump_sysconds_t sc; \
     sc.feedwater_temperature = 40.0; sc.suction_pressure = 0.5; sc.discharge_pressure = 7.4; sc.max_sg_level = XR(Y_MAXLVL); \
-    const double maint_time = maint ? XR(Y_TIME) : 0.0; \
+    const double maint_time = maint_clock; \
     if (maint) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); npd_maint_cache_landed(maint_cache); } \
     const uint32_t cooling_mask = (i & 1) ? maint_cache.z : maint_cache.x; \
     const float cooling_until = __uint_as_float((i & 1) ? maint_cache.w : maint_cache.y); \
@@ -240,6 +239,11 @@ __device__ __forceinline__ void npd_step4_body(
   if (maint) maint_cache = npd_maint_cache_fetch(MC, p, my_pump >> 1);
   /* could the demand gate close for a later pump?  (every wave evaluates this on the same data, npd_step2.h, read before the
    * barrier below, i.e. before any wave stores a pump or the feedwater section) */
+  /* the plants' clock after this step, for the maintenance screen of this wave's pump: the primary side only adds dt to it
+   * (npd_primary_update never writes sim_time), so every wave can form it from the column as the previous step left it -- loaded
+   * here, ahead of the barrier below, i.e. before wave 0 stores the primary section -- instead of waiting for wave 0 */
+  double maint_clock = 0.0;
+  if (maint) maint_clock = (double)NPD_ST_F64(PRIM, npb_prim_t, sim_time, 0, 0);
   bool serial_pumps;
   {
     const int fw_mask = *NPD_NP(const int32_t, NPD_SEC_COL(FW, 0) + NPB_FW_NCARRY + (NPB_FW_NOUT + NPB_I32_SLOT(npb_fw_t, FW, running_mask)) / NPD_NPC,
@@ -254,6 +258,7 @@ __device__ __forceinline__ void npd_step4_body(
     }
     if (wave == 3 && lane < FL_COUNT) *NPD4_FLAGP(lane) = 0;
     serial_pumps = __builtin_amdgcn_ballot_w64(n_prev > 0 && may_run > n_prev) != 0;
+    if (maint) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); maint_clock += dt; }
   }
   NPD2_SYNC_();                                                                       /* the only barrier before the end: the progress words are down */
 
