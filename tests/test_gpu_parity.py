@@ -359,6 +359,61 @@ def test_config4_randomized_oil_top_off_scenario(oracle_lib):
     assert created.max() >= 1 and created.min() == 0, "the scenario mix has plants that trigger within 2 h and plants that do not"
 
 
+@pytest.mark.parametrize("n,T", [(32768, 36), (65536, 24)])
+def test_config4_at_its_size_with_maintenance_against_the_oracle_on_a_sample(oracle_lib, n, T):
+    """BASELINE config 4 at its real per-GPU shape (maintenance_scenario_runner.py:349-411, sim.py:208-223): 32 768 plants with
+    per-seed randomised oil_top_off initial conditions, dt = 5 min, the automatic maintenance ON -- npb_step4_maint_kernel at
+    full occupancy: two groups of four waves per CU polling their LDS progress words beside each other, the rule called with its
+    2 KB/lane scratch frame by the waves whose screen fires -- and once more at 65 536 plants (two rounds of groups on the segmented
+    arena).  Against the CPU oracle on ~200 sampled plants (first, last, wave and segment boundaries) started from the same
+    columns: observations, flags and the event count after every step, every column incl. maint.* / mpump.* at the end; and the
+    job-wide histogram of executions (sharding.event_histogram) against the counts column."""
+    import torch
+    from nuclear_sim_amd.env import BatchedPlantEnv
+    from nuclear_sim_amd import scenarios, sharding
+    seeds = np.arange(n)
+    env = BatchedPlantEnv.action_test("oil_top_off", seeds)
+    rng = np.random.default_rng(404)
+    edges = [0, 1, 63, 64, 65, 127, 255, 256, 16383, 16384, 16385, n // 2 - 1, n // 2, n - 65, n - 64, n - 1]
+    sample = np.unique(np.concatenate([edges, rng.choice(n, 184, replace=False)]))
+    P = oracle_lib.Params(); P.dt = 5.0; P.hs_noise_enabled = 1; P.maint_enabled = 1
+    ora = oracle_lib.OraclePlants(len(sample), P)
+    eff = float(ora.get("pump.lubrication_effectiveness"))
+    for key, v in scenarios.action_test_fields("oil_top_off", seeds, eff).items():
+        name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
+        v = np.asarray(v)
+        ora.set(name, v[sample] if v.shape[0] == n else v, instance=inst, k=k)
+    z = np.random.RandomState(42).standard_normal(T)          # every plant's heat source is seeded 42, as the runner's
+    idx = torch.as_tensor(sample, device=env.device)
+    gid = np.arange(n)
+    for t in range(T):
+        sp = 90.0 + 8.0 * np.sin(2.0 * np.pi * t / (20.0 + gid % 7))      # the runner's profile moves the load; per plant here
+        obs, rew, done, info = env.step(power_setpoint=sp)
+        assert env.last_step_kernel() == "npb_step4_maint_kernel"
+        o_obs, o_rew, o_done, o_flags, _ = ora.step(setpoint=sp[sample], noise_z=np.full(len(sample), z[t]))
+        np.testing.assert_allclose(obs[idx].cpu().numpy(), o_obs, rtol=RTOL, atol=1e-12, err_msg="obs step %d" % t)
+        assert np.array_equal(done[idx].cpu().numpy(), o_done), t
+        assert np.array_equal(info["trip_flags"][idx].cpu().numpy().astype(np.uint32), o_flags), t
+        o_count = np.array([ora.get("maint.maintenance_actions_performed", plant=p) for p in range(len(sample))], dtype=np.int64)
+        assert np.array_equal(info["maintenance_event_count"][idx].cpu().numpy().astype(np.int64), o_count), t
+    f, i = env.state_arrays()
+    f = f[:, idx].cpu().numpy(); i = i[:, idx].cpu().numpy()
+    of, oi = ora.state_all()
+    for kind, slot, label, _p in env_cols():
+        if kind == "i32":
+            assert np.array_equal(i[slot], oi[:, slot]), label
+        else:
+            np.testing.assert_allclose(f[slot], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)
+    performed = env.get_field("maint.maintenance_actions_performed")
+    assert torch.equal(info["maintenance_event_count"].to(torch.int64), performed.to(torch.int64))
+    hist = sharding.event_histogram(performed).cpu().numpy()
+    assert hist.sum() == n and np.array_equal(hist, np.bincount(performed.cpu().numpy().astype(np.int64), minlength=16)[:16])
+    assert hist[0] > 0 and hist[1:].sum() > n // 4, "the catalog's three scenarios: plants that top off within the run and plants that never do (%s)" % hist[:6]
+    from nuclear_sim_amd import _lib
+    executed_top_off = env.get_field("maint.executed", k=_lib.MAINT_ACTIONS.index("oil_top_off")).cpu().numpy()
+    assert np.array_equal(executed_top_off.astype(np.int64), performed.cpu().numpy().astype(np.int64)), "every execution in this scenario is an oil top-off"
+
+
 def test_facade_without_a_maintenance_configuration_is_the_references_default():
     """NuclearPlantSimulator(enable_state_management=True) with NO maintenance configuration (the constructor's default): the
     reference gives a feedwater pump one threshold, oil_level < 30 -> oil_top_off, and delays HIGH-priority work by an hour
