@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define NPB_VERSION 141 /* 0.1.4.1: npb_state_arena_segment (segmented arenas), step-kernel variant 5, NPB_DIAG_DIM 136; 0.1.4: npb_debug_last_step_kernel, npb_info_dim / npb_obs_dim / npb_diag_dim, maintenance catalogs by index; 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
+#define NPB_VERSION 142 /* 0.1.4.2: NPB_DIAG_DIM 170 (state-log rows of round 4), npb_state_arena_layout, NPB_EINVAL for NPB_HEAT_EXTERNAL without its input column; 0.1.4.1: npb_state_arena_segment (segmented arenas), step-kernel variant 5, NPB_DIAG_DIM 136; 0.1.4: npb_debug_last_step_kernel, npb_info_dim / npb_obs_dim / npb_diag_dim, maintenance catalogs by index; 0.1.3.1: params.kinetics_rk4_substeps; 0.1.3: NPB_MODE_PRIMARY, reactivity components behind the info block (params.info_reactivity_components); 0.1.2: npb_reset_reference, maintenance table (npb_maint.h, mpump.* columns); 0.1.1: one arena of equally wide columns, npb_locate_field, npb_gather_fields, npb_create_storage */
 #ifndef NPB_API
 #define NPB_API __attribute__((visibility("default")))
 #endif
@@ -88,7 +88,26 @@ enum {
   NPB_DIAG_STAGE_SYSTEM_EFFICIENCY = 133, NPB_DIAG_TURBINE_PERFORMANCE_FACTOR = 134,
   /* number of alarms the feedwater protection system holds after the step (protection_system.py:399-445) */
   NPB_DIAG_FW_ACTIVE_ALARMS = 135,
-  NPB_DIAG_DIM = 136
+  /* round 4: what the state log's remaining columns need from inside the step.
+   * per feedwater pump, FWP-1..4: the maintenance action carried out on the pump in this step as catalog index + 1 (0 = none;
+   * include/npb_maint.h), from which the thirteen <action>_occurred flags of the pump's state dict follow
+   * (pump_lubrication.py:642-643, 1636-1641); written by the maintenance rule like NPB_DIAG_PUMP_MAINTENANCE_OCCURRED */
+  NPB_DIAG_PUMP_MAINTENANCE_ACTION = 136,
+  /* the feedwater protection system's bookkeeping (protection_system.py:447-476, 680-716): trips standing after the step;
+   * carried in the caller's buffer from the step diagnostics were switched on: steps on which a trip came up
+   * (valid_trip_count), emergency feedwater / steam dump set by such a step's trips and never cleared by the step */
+  NPB_DIAG_FW_ACTIVE_TRIPS = 140, NPB_DIAG_FW_VALID_TRIP_COUNT = 141, NPB_DIAG_FW_EMERGENCY_FEEDWATER = 142, NPB_DIAG_FW_STEAM_DUMP = 143,
+  /* per turbine stage: the extraction flow the stage took [kg/s] (stage_system.py:186-203) */
+  NPB_DIAG_STAGE_EXTRACTION_FLOW = 144,
+  /* per steam-jet ejector, SJE-001..002 (vacuum_pump.py:470-536): air-removal capacity, motive steam flow, steam consumption
+   * rate of the step; and carried in the caller's buffer: the compression ratio (kept from the ejector's last operating step;
+   * the row starts at 1.0) and the hours it has operated; then the vacuum system's total air removal (vacuum_system.py:499) */
+  NPB_DIAG_COND_SJE_CAPACITY = 158, NPB_DIAG_COND_SJE_STEAM_FLOW = 160, NPB_DIAG_COND_SJE_STEAM_CONSUMPTION = 162,
+  NPB_DIAG_COND_SJE_COMPRESSION_RATIO = 164, NPB_DIAG_COND_SJE_OPERATING_HOURS = 166, NPB_DIAG_COND_AIR_REMOVAL = 168,
+  /* the stage system's total power [MW] as its state dict holds it (stage_system.py:976): stability-adjusted, before the turbine's
+   * protection and availability factors */
+  NPB_DIAG_STAGE_SYSTEM_TOTAL_POWER = 169,
+  NPB_DIAG_DIM = 170
 };
 /* info["reactivity_components"] (sim.py:205; reactivity_model.py:77-125, pcm, the dict's insertion order).  Only the
  * reactor heat source has them, and only a caller that sets params.info_reactivity_components gets them: the info

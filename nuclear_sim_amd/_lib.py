@@ -44,7 +44,21 @@ DIAG_TAIL_COLUMNS = (("secondary.condenser_SECONDARY-COMP-001-COND.condenser_ove
                      # NPB_DIAG_TURBINE_PERFORMANCE_FACTOR, NPB_DIAG_FW_ACTIVE_ALARMS
                      ("secondary.turbine_SECONDARY-COMP-001-TURB.enhanced_turbine_performance", 19),
                      ("secondary.feedwater_SECONDARY-COMP-001-FW.protection_active_alarms_count", 20))
-DIAG_DIM = 14 * len(DIAG_STAGE_VALUES) + 3 * len(DIAG_SG_VALUES) + 4 * len(DIAG_PUMP_VALUES) + len(DIAG_FW_VALUES) + len(DIAG_ROTOR_VALUES) + len(DIAG_TAIL_COLUMNS) + 1
+# round 4 (include/npb.h NPB_DIAG_PUMP_MAINTENANCE_ACTION ...): rows by number
+DIAG_PUMP_MAINTENANCE_ACTION = 136          # x4: catalog index + 1 of the action carried out on the pump in this step, 0 = none
+DIAG_FW_ACTIVE_TRIPS, DIAG_FW_VALID_TRIP_COUNT, DIAG_FW_EMERGENCY_FEEDWATER, DIAG_FW_STEAM_DUMP = 140, 141, 142, 143
+DIAG_STAGE_EXTRACTION_FLOW = 144            # x14
+DIAG_COND_SJE_CAPACITY, DIAG_COND_SJE_STEAM_FLOW, DIAG_COND_SJE_STEAM_CONSUMPTION = 158, 160, 162    # x2 each
+DIAG_COND_SJE_COMPRESSION_RATIO, DIAG_COND_SJE_OPERATING_HOURS, DIAG_COND_AIR_REMOVAL = 164, 166, 168
+DIAG_STAGE_SYSTEM_TOTAL_POWER = 169
+DIAG_STAGE_POWER_OUTPUT = 56                # x14 (NPB_DIAG_STAGE_POWER_OUTPUT)
+# rows the step CARRIES in the caller's buffer from one step to the next (accumulators, latches, values kept while equipment
+# rests): row -> value of a freshly constructed plant.  BatchedPlantEnv.enable_diagnostics / reset put them there.
+DIAG_CARRIED_ROWS = {**{124 + q: 0.0 for q in range(5)}, 133: 0.0, DIAG_FW_VALID_TRIP_COUNT: 0.0, DIAG_FW_EMERGENCY_FEEDWATER: 0.0,
+                     DIAG_FW_STEAM_DUMP: 0.0, DIAG_COND_SJE_COMPRESSION_RATIO: 1.0, DIAG_COND_SJE_COMPRESSION_RATIO + 1: 1.0,
+                     DIAG_COND_SJE_OPERATING_HOURS: 0.0, DIAG_COND_SJE_OPERATING_HOURS + 1: 0.0}
+DIAG_DIM = 170
+assert 14 * len(DIAG_STAGE_VALUES) + 3 * len(DIAG_SG_VALUES) + 4 * len(DIAG_PUMP_VALUES) + len(DIAG_FW_VALUES) + len(DIAG_ROTOR_VALUES) + len(DIAG_TAIL_COLUMNS) + 1 == DIAG_PUMP_MAINTENANCE_ACTION
 REACTIVITY_COMPONENTS = ("control_rods", "boron", "doppler", "moderator_temp", "moderator_void", "pressure", "xenon", "samarium",
                          "fuel_depletion", "burnable_poisons")   # reactivity_model.py:87-121, NPB_RHO_*
 

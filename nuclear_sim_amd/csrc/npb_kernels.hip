@@ -53,6 +53,9 @@ extern "C" __attribute__((visibility("default"))) int npb_debug_set_stamp_buffer
 #include "npd_reset.h"
 #include "npb_kernels.h"
 
+#ifndef NPD_OUT_STORE
+#define NPD_OUT_STORE 1   /* how a narrow column of output members only is stored (npd_st_store_elide): 1 = plain store, never fetched (round 4: 65 536 plants 0.0884 -> 0.0838 ms, calibrated reads 269.8 -> 255.7 MB per launch, profiles/r4_out_store.txt) */
+#endif
 #define NPB_OBS_PAD 23 /* LDS row stride in doubles: 22 + 1 keeps the transpose at <= 2-way bank conflicts */
 
 /* ---- segmented arena.  A handle of more than 45 056 plants keeps its arena in SEGMENTS of 16 384 plants: segment s
@@ -224,13 +227,20 @@ __device__ __forceinline__ void npd_st_store_elide(const S &s, const S &old, con
       NPD_STORE_REAL(col0 + k, d[k]);
     }
   }
-  /* narrow columns (outputs as float, flags, status codes, counters): always compared */
+  /* narrow columns (outputs as float, flags, status codes, counters): compared -- except the columns that hold nothing but
+   * OUTPUT members (the first NO / NPD_NPC of them): the step never reads an output, so comparing its old bits is the only
+   * reason the column would be fetched at all (round 3's counters: reads 1.16x algorithmic, 284 B per plant of it these).
+   * NPD_OUT_STORE: 0 = compare like the rest (round 3), 1 = plain store, no compare, no load, 2 = the same, non-temporal */
 #pragma unroll
   for (int c = 0; c < NNC; c++) {
     const uint32_t w0 = npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC), w1 = npd_narrow_bits<NF, NO, NI>(s, c * NPD_NPC + 1);
 #ifdef NPB_PROBE
     npd_st_store_narrow<SM>(st, col0 + NC + c, w0, w1);
 #else
+    if (NPD_OUT_STORE != 0 && (c + 1) * NPD_NPC <= NO) {
+      npd_st_store_narrow<(NPD_OUT_STORE == 2 ? 2 : SM)>(st, col0 + NC + c, w0, w1);
+      continue;
+    }
     const uint32_t o0 = npd_narrow_bits<NF, NO, NI>(old, c * NPD_NPC), o1 = npd_narrow_bits<NF, NO, NI>(old, c * NPD_NPC + 1);
     if (__builtin_amdgcn_ballot_w64(NPD_NPC == 2 ? ((w0 != o0) | (w1 != o1)) : (w0 != o0)) != 0) npd_st_store_narrow<SM>(st, col0 + NC + c, w0, w1);
 #endif
@@ -515,6 +525,7 @@ __device__ __attribute__((noinline)) void npd_maint_rule_for_wave(const npd_main
         if (MC.diag && ((NPD_MA_HANDLER_MASK >> pick_action) & 1u)) {    /* pump_lubrication.py:642-643, 1636-1637: the flags of this step's state-log row (action types the dispatcher knows) */
           MC.diag[(size_t)(NPB_DIAG_PUMP_MAINTENANCE_OCCURRED + pick) * MC.diag_pitch + p] = 1.0;
           if (pick_action == NPB_MA_OIL_TOP_OFF) MC.diag[(size_t)(NPB_DIAG_PUMP_OIL_TOP_OFF_OCCURRED + pick) * MC.diag_pitch + p] = 1.0;
+          MC.diag[(size_t)(NPB_DIAG_PUMP_MAINTENANCE_ACTION + pick) * MC.diag_pitch + p] = (double)(pick_action + 1);
         }
       }
     }

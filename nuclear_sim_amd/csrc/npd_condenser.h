@@ -144,7 +144,12 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
   }
   int n_running = ((cd->ej_operating_mask >> 0) & 1) + ((cd->ej_operating_mask >> 1) & 1);
   double total_capacity = 0.0;
-  if (diag) { diag[2] = 0.0; diag[3] = 0.0; diag[4] = 0.0; }
+  if (diag) { diag[2] = 0.0; diag[3] = 0.0; diag[4] = 0.0;
+#pragma unroll
+              for (int q = 5; q < 16; q++) diag[q] = 0.0;
+              diag[11] = diag[12] = -1.0; }    /* [5 + e] capacity, [7 + e] motive steam flow, [9 + e] steam consumption rate of ejector e; [11 + e] its
+                                                * compression ratio of this step (-1 = it did not run: the old one stands), [13 + e] hours it ran
+                                                * this step; [15] total air removal  (vacuum_pump.py:470-536, vacuum_system.py:499) */
   for (int e = 0; e < 2; e++) { /* SteamJetEjector.update_state vacuum_pump.py:470-536 */
     int operating = (cd->ej_operating_mask >> e) & 1;
     double capacity = 0.0;
@@ -152,6 +157,7 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
       double request = required_capacity / ((n_running > 1) ? n_running : 1);
       double suction = cd->condenser_pressure;
       double overall = cd->ej_nozzle_fouling[e] * cd->ej_diffuser_fouling[e] * cd->ej_nozzle_erosion[e];
+      if (diag) { diag[11 + e] = 1.0; diag[13 + e] = dt; }            /* out of its limits: performance.get('compression_ratio', 1.0) */
       if (suction < 0.003 || suction > 0.015) capacity = 0.0;         /* calculate_steam_jet_performance :96-190 */
       else if (motive_p < 0.8) capacity = 0.0;
       else {
@@ -167,7 +173,9 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
           double rate = (2.5 * npd_exp(0.8 * npd_log(capacity_factor))) * (suction_pressure_ratio * npd_sqrt(suction_pressure_ratio)) * (1.0 / npd_pymax(0.5, overall));
           if (e == 0) { diag[2] = capacity * rate; diag[3] = rate; }
           diag[4] += capacity * rate;
+          diag[7 + e] = capacity * rate; diag[9 + e] = rate;
         }
+        if (diag) { diag[5 + e] = capacity; diag[11 + e] = 0.101 / suction; }   /* discharge pressure 0.101 MPa, vacuum_pump.py:69, :172 */
       }
       /* update_degradation :246-275 */
       cd->ej_nozzle_fouling[e] = npd_pymax(0.5, cd->ej_nozzle_fouling[e] - 1e-05 * dt);
@@ -176,6 +184,7 @@ NPD_FN void npd_condenser_update(npb_cond_t *cd, npb_chem_t *chem, double steam_
     }
     total_capacity += capacity;
   }
+  if (diag) diag[15] = total_capacity;
   { /* calculate_air_mass_balance :308-356 */
     double dt_seconds = dt * 3600.0;
     double new_air_mass = cd->air_mass_in_condenser + (cd->current_air_leakage - total_capacity) * dt_seconds;

@@ -363,6 +363,8 @@ typedef struct npd_fw_acc_t {
   double total_cavitation_risk, total_wear_level, total_vibration;
   int running_count, running_mask, trips;
   uint32_t trip_mask;
+  int trip_kinds;   /* state-log diagnostics only: bit 0 = a trip that starts emergency feedwater, bit 1 = one that opens the steam dump
+                     * (protection_system.py:680-692); dead code in every build that does not write diagnostics */
 } npd_fw_acc_t;
 
 /* ThreeElementControl.calculate_flow_demands  level_control.py:157-363
@@ -467,8 +469,9 @@ NPD_FN void npd_fw_pump_step(npb_pump_t *p, npb_fw_t *fw, npd_fw_acc_t *acc, int
     }
     if (npsh < 0.1) critical_active = 1;
     if (critical_active || fw->npsh_low_low_trip_active) acc->trips++;
+    if (critical_active) acc->trip_kinds |= 1;                       /* '<pump>_npsh_critical' */
   }
-  if (p->suction_pressure < 0.1) acc->trips++;
+  if (p->suction_pressure < 0.1) { acc->trips++; acc->trip_kinds |= 1; }   /* '<pump>_suction_pressure_low' */
   if (p->discharge_pressure > 10.0) acc->trips++;
   if (p->vibration_level > 10.0) { fw->timer_vibration += dt_seconds; if (fw->timer_vibration >= 10.0) acc->trips++; }
   else fw->timer_vibration = 0.0;
@@ -513,6 +516,7 @@ typedef struct npd_fw_result_t {
   double total_flow_rate, total_power_consumption;
   int system_availability, num_running_pumps;
   uint32_t pump_trip_mask;
+  int active_trips, trip_kinds;   /* state-log diagnostics: len(active_trips) and the kinds of npd_fw_acc_t.trip_kinds */
 } npd_fw_result_t;
 
 /* system-level tail: _calculate_health_score performance_monitoring.py:544, flow / SG-level /
@@ -532,13 +536,13 @@ NPD_FN void npd_fw_finish(npb_fw_t *fw, npd_fw_acc_t *acc, const double *sg_leve
   int trips = acc->trips;
   {
     double low_flow_trip = 0.05 * 1500.0, high_flow_trip = 1.3 * 1500.0;
-    if (acc->flow_sum < low_flow_trip) { fw->timer_low_flow += dt_seconds; if (fw->timer_low_flow >= 10.0) trips++; }
+    if (acc->flow_sum < low_flow_trip) { fw->timer_low_flow += dt_seconds; if (fw->timer_low_flow >= 10.0) { trips++; acc->trip_kinds |= 1; } }
     else fw->timer_low_flow = 0.0;
-    if (acc->flow_sum > high_flow_trip) { fw->timer_high_flow += dt_seconds; if (fw->timer_high_flow >= 2.0) trips++; }
+    if (acc->flow_sum > high_flow_trip) { fw->timer_high_flow += dt_seconds; if (fw->timer_high_flow >= 2.0) { trips++; acc->trip_kinds |= 2; } }
     else fw->timer_high_flow = 0.0;
   }
 #pragma unroll
-  for (int i = 0; i < NPB_NUM_SG; i++) if (sg_levels[i] > 16.5) trips++;
+  for (int i = 0; i < NPB_NUM_SG; i++) if (sg_levels[i] > 16.5) { trips++; acc->trip_kinds |= 2; }
   if (fw->overall_health_score < 0.3) trips++;
   if (avg_cavitation_risk > 0.8) trips++;
   if (avg_wear_level > 85.0) trips++;
@@ -549,6 +553,7 @@ NPD_FN void npd_fw_finish(npb_fw_t *fw, npd_fw_acc_t *acc, const double *sg_leve
   res->total_flow_rate = acc->total_flow; res->total_power_consumption = acc->total_power;
   res->system_availability = fw->system_availability; res->num_running_pumps = acc->running_count;
   res->pump_trip_mask = acc->trip_mask;
+  res->active_trips = trips; res->trip_kinds = acc->trip_kinds;
 }
 
 #endif

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     npd_fw_acc_t acc;
     acc.total_flow = acc.total_power = acc.flow_sum = 0.0;
     acc.total_cavitation_risk = acc.total_wear_level = acc.total_vibration = 0.0;
-    acc.running_count = acc.running_mask = acc.trips = 0; acc.trip_mask = 0;
+    acc.running_count = acc.running_mask = acc.trips = 0; acc.trip_mask = 0; acc.trip_kinds = 0;
 #pragma unroll 1
     for (int i = 0; i < NPB_NUM_PUMPS; i++) {
       NPD_STAMP(2 + i);
@@ -208,6 +208,7 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
         }
         diag_alarms += npd_fw_pump_alarms(&pm);
         NPD_DIAG(st, NPB_DIAG_PUMP_MAINTENANCE_OCCURRED + i, 0.0); NPD_DIAG(st, NPB_DIAG_PUMP_OIL_TOP_OFF_OCCURRED + i, 0.0);   /* the rule sets them */
+        NPD_DIAG(st, NPB_DIAG_PUMP_MAINTENANCE_ACTION + i, 0.0);
       }
 #endif
       if (maint) {   /* anything new at this pump -- a threshold crossed outside its cooldown, a cooldown run out -- for any plant of the wave?  (npd_maintenance.h) */
@@ -224,8 +225,20 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     }
     NPD_STAMP(6);
     npd_fw_result_t fwr;
+#ifdef NPD_STEP1_DIAG
+    const int diag_trip_before = fw.system_trip_active;
+#endif
     npd_fw_finish(&fw, &acc, prev_levels, dt, &fwr);
 #ifdef NPD_STEP1_DIAG
+    /* FeedwaterProtectionSystem's bookkeeping beside system_trip_active (protection_system.py:447-476, 680-716): the number of
+     * trips standing, and -- on the step a trip comes up -- the count of such steps and the two emergency actions that stay set
+     * until someone resets the protection system: carried in the caller's buffer from the step diagnostics were switched on */
+    NPD_DIAG(st, NPB_DIAG_FW_ACTIVE_TRIPS, (double)fwr.active_trips);
+    if (st.diag && fw.system_trip_active && !diag_trip_before) {
+      st.diag[(size_t)NPB_DIAG_FW_VALID_TRIP_COUNT * st.diag_pitch] += 1.0;
+      if (fwr.trip_kinds & 1) st.diag[(size_t)NPB_DIAG_FW_EMERGENCY_FEEDWATER * st.diag_pitch] = 1.0;
+      if (fwr.trip_kinds & 2) st.diag[(size_t)NPB_DIAG_FW_STEAM_DUMP * st.diag_pitch] = 1.0;
+    }
     diag_health = fw.overall_health_score;
     NPD_DIAG(st, NPB_DIAG_FW_ACTIVE_ALARMS, (double)(diag_alarms + npd_fw_system_alarms(&fw, &acc, prev_levels)));
 #endif
@@ -363,11 +376,21 @@ __global__ __launch_bounds__(NPB_WAVE) void NPD_STEP1_KERNEL(
     {
       NPD_ST_STORE_ELIDE(TURB, npb_turb_t, t, t_old, 0);
 #ifdef NPD_STEP1_DIAG
-      double cond_diag[5];
+      double cond_diag[16];
       npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
                            cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr, cond_diag);
 #pragma unroll
       for (int q = 0; q < 5; q++) NPD_DIAG(st, NPB_DIAG_COND_OVERALL_HTC + q, cond_diag[q]);
+      if (st.diag) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          NPD_DIAG(st, NPB_DIAG_COND_SJE_CAPACITY + e, cond_diag[5 + e]); NPD_DIAG(st, NPB_DIAG_COND_SJE_STEAM_FLOW + e, cond_diag[7 + e]);
+          NPD_DIAG(st, NPB_DIAG_COND_SJE_STEAM_CONSUMPTION + e, cond_diag[9 + e]);
+          if (cond_diag[11 + e] >= 0.0) NPD_DIAG(st, NPB_DIAG_COND_SJE_COMPRESSION_RATIO + e, cond_diag[11 + e]);   /* carried while the ejector rests */
+          st.diag[(size_t)(NPB_DIAG_COND_SJE_OPERATING_HOURS + e) * st.diag_pitch] += cond_diag[13 + e];              /* vacuum_pump.py:269-270 */
+        }
+        NPD_DIAG(st, NPB_DIAG_COND_AIR_REMOVAL, cond_diag[15]);
+      }
 #else
       npd_condenser_update(&cd, &ch, tr.condenser_pressure, tr.effective_steam_flow, lp_exhaust_quality, 45000.0,
                            cooling_water_temperature, 1.2, 185.0, dt / 60.0, &cr);

@@ -477,7 +477,7 @@ __device__ __forceinline__ void npd_step2_body(
     npd_fw_acc_t acc;
     acc.total_flow = acc.total_power = acc.flow_sum = 0.0;
     acc.total_cavitation_risk = acc.total_wear_level = acc.total_vibration = 0.0;
-    acc.running_count = acc.running_mask = acc.trips = 0; acc.trip_mask = 0;
+    acc.running_count = acc.running_mask = acc.trips = 0; acc.trip_mask = 0; acc.trip_kinds = 0;
 #pragma unroll
     for (int i = 0; i < NPB_NUM_PUMPS; i++) npd2_pump_tail(xch, lane, i, &fw, &acc, dt);
     npd_fw_result_t fwr;

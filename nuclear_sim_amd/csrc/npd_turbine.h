@@ -266,6 +266,7 @@ NPD_FN void npd_stage_system_update_seq(const npd_stage_t &st, const double *stg
     NPD_DIAG(st, NPB_DIAG_STAGE_INLET_PRESSURE + k, current_pressure); NPD_DIAG(st, NPB_DIAG_STAGE_INLET_TEMPERATURE + k, current_temperature);
     NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_PRESSURE + k, so.outlet_pressure); NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_TEMPERATURE + k, so.outlet_temperature);
     NPD_DIAG(st, NPB_DIAG_STAGE_POWER_OUTPUT + k, so.power_output); NPD_DIAG(st, NPB_DIAG_STAGE_LOADING_FACTOR + k, so.loading_factor);
+    NPD_DIAG(st, NPB_DIAG_STAGE_EXTRACTION_FLOW + k, so.extraction_flow);
     npd_stage_post<SM>(st, stg, k, so.loading_factor, so.outlet_temperature, dt, out);
     current_pressure = so.outlet_pressure; current_temperature = so.outlet_temperature; current_flow = so.outlet_flow;
   }
@@ -392,6 +393,7 @@ NPD_FN void npd_stage_system_update(const npd_stage_t &st, const double *stg, do
     NPD_DIAG(st, NPB_DIAG_STAGE_INLET_PRESSURE + k, p_in); NPD_DIAG(st, NPB_DIAG_STAGE_INLET_TEMPERATURE + k, T_in);
     NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_PRESSURE + k, p_self[k]); NPD_DIAG(st, NPB_DIAG_STAGE_OUTLET_TEMPERATURE + k, T_out);
     NPD_DIAG(st, NPB_DIAG_STAGE_POWER_OUTPUT + k, main_power + extraction_power); NPD_DIAG(st, NPB_DIAG_STAGE_LOADING_FACTOR + k, loading_factor);
+    NPD_DIAG(st, NPB_DIAG_STAGE_EXTRACTION_FLOW + k, ef);
     npd_stage_post<SM>(st, stg, k, loading_factor, T_out, dt, out);
     T_in = T_out; sat_in = sat_self[k]; hg_in = hg_self[k];
   }
@@ -661,6 +663,7 @@ NPD_FN void npd_turbine_update(npb_turb_t *t, const npd_stage_t &st, double stea
   npd_turbine_rotor(t, stage_power_mw, steam_temperature, load_demand, dt, &max_bearing_metal, &total_displacement, st.diag ? torques : nullptr);
   if (st.diag) {
     NPD_DIAG(st, NPB_DIAG_ROTOR_FRICTION_TORQUE, torques[0]); NPD_DIAG(st, NPB_DIAG_ROTOR_NET_TORQUE, torques[1]); NPD_DIAG(st, NPB_DIAG_ROTOR_ACCELERATION, torques[2]);
+    NPD_DIAG(st, NPB_DIAG_STAGE_SYSTEM_TOTAL_POWER, stage_power_mw);     /* stage_system.py:976: the stability-adjusted stage power, before the protection gates it */
     /* accumulators the reference carries and nothing in the physics reads: summed in the caller's buffer, i.e. since the
      * diagnostics were switched on (from a zeroed buffer at construction they are the reference's) */
 #pragma unroll

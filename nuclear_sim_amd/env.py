@@ -172,6 +172,10 @@ class BatchedPlantEnv:
             self._info = self._info_buf[: self.n * len(INFO_COLUMNS)].view(self.n, len(INFO_COLUMNS))
             self._rho = self._info_buf[self.n * len(INFO_COLUMNS):].view(self.n, -1) if self._with_rho else None
         self._event_counts = None
+        # for nuclear_sim_amd/statelog.py: how the reference names this plant's providers in its state log, and the log values its
+        # constructor fixed from the initial conditions (action_test() replaces both with the data-gen composer's)
+        self.log_naming = "default"
+        self.log_side_columns = {"secondary.feedwater_SECONDARY-COMP-001-FW.diagnostics_total_wear": np.full(1, 60.0)}   # scenarios.log_side_columns(None)
         if p.maint_enabled and hasattr(self.L, "npb_set_maintenance_count_buffer"):
             with torch.cuda.device(self.device):
                 self._event_counts = torch.zeros(self.n, dtype=torch.int32, device=self.device)
@@ -194,6 +198,10 @@ class BatchedPlantEnv:
                   noise_seeds=[42] * len(seeds), device=device, maintenance=True, params=params)
         eff = float(env.get_field("pump.lubrication_effectiveness")[0].item())
         env.set_fields(scenarios.action_test_fields(action, seeds, eff, randomize=randomize))
+        # what a state log of these plants needs beside their state: the composer's provider names and the values the constructor
+        # fixed from the initial conditions (nuclear_sim_amd/statelog.py)
+        env.log_naming = "composed"
+        env.log_side_columns = scenarios.log_side_columns(action, seeds, randomize=randomize)
         return env
 
     # ------------------------------------------------------------------ helpers
@@ -216,12 +224,26 @@ class BatchedPlantEnv:
         if on:
             pitch = (self.n + 63) // 64 * 64
             self._diag_buf = torch.zeros((_lib.DIAG_DIM, pitch), dtype=torch.float64, device=self.device)
+            self._reset_carried_diagnostics(None)
             _lib.check(self.L.npb_set_diagnostics(self._h, ctypes.c_void_p(self._diag_buf.data_ptr()), pitch), self._h)
             self.diagnostics = self._diag_buf[:, : self.n]
         else:
             _lib.check(self.L.npb_set_diagnostics(self._h, None, 0), self._h)
             self._diag_buf = None; self.diagnostics = None
         return self.diagnostics
+
+    def _reset_carried_diagnostics(self, mask) -> None:
+        """The diagnostics rows the step carries from one step to the next (accumulators, latches, values kept while equipment
+        rests: _lib.DIAG_CARRIED_ROWS) back to a freshly constructed plant's, for the masked plants: they are plant state that lives
+        in this buffer instead of the arena, so every reset must take them along."""
+        buf = getattr(self, "_diag_buf", None)
+        if buf is None:
+            return
+        for row, value in _lib.DIAG_CARRIED_ROWS.items():
+            if mask is None:
+                buf[row].fill_(value)
+            else:
+                buf[row, : self.n].masked_fill_(mask.to(torch.bool), value)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -324,6 +346,7 @@ class BatchedPlantEnv:
         is force-set to the reference's "steady state" (include/npb.h, npb_reset_reference).  Initial conditions set
         through ``set_fields`` are the caller's to re-apply.  Returns the observation, as the reference does."""
         m = self._col(mask, torch.uint8)
+        self._reset_carried_diagnostics(m)
         if reference:
             _lib.check(self.L.npb_reset_reference(self._h, self._p(m), int(bool(start_at_steady_state)), self._stream()), self._h)
         else:

@@ -627,6 +627,30 @@ def _sg_randomized_fields(action: str, seeds: Sequence[int]) -> Dict[object, np.
     return f
 
 
+def log_side_columns(action: Optional[str] = None, seeds: Optional[Sequence[int]] = None, randomize: bool = True) -> Dict[str, np.ndarray]:
+    """Per-plant values of the reference's state log that the CONSTRUCTOR fixes from the configured initial conditions and no step
+    moves: the feedwater diagnostics' wear tracker takes 100 x the mean configured impeller / bearing / seal-face wear
+    (feedwater/physics.py:400-412) and is never updated again (its update is the legacy branch of performance_monitoring.py:493-503,
+    not taken by pumps that own a lubrication system).  ``action`` None: NuclearPlantSimulator's default configuration
+    (FeedwaterInitialConditions: impeller_wear and seal_face_wear 0.3 each, no bearing_wear attribute, feedwater/config.py:270-276)."""
+    name = "secondary.feedwater_SECONDARY-COMP-001-FW.diagnostics_total_wear"
+    if action is None:
+        return {name: np.full(1, 0.3 * 100.0 + 0.3 * 100.0)}
+    tpl = _CATALOG["template_ic"]["feedwater"]
+    keys = [k for k in ("impeller_wear", "bearing_wear", "seal_face_wear") if tpl.get(k) is not None]
+    info = _DELTAS["actions"].get(action, {})
+    if info.get("subsystem") == "feedwater":
+        cond = randomized_conditions_columns(action, seeds, keys=keys) if randomize else catalog_conditions(action)
+    else:
+        cond = {}
+    n = len(seeds)
+    total = np.zeros(n)
+    for k in keys:
+        v = np.asarray(cond[k] if k in cond else tpl[k], dtype=np.float64)
+        total = total + (np.broadcast_to(v, (n, v.shape[-1])).sum(axis=1) / v.shape[-1]) * 100.0
+    return {name: total}
+
+
 def action_test_fields(action: str, seeds: Sequence[int], lubrication_effectiveness: float, randomize: bool = True) -> Dict[object, np.ndarray]:
     """Columns that turn freshly constructed plants (default configuration) into the plants
     ``MaintenanceScenarioRunner`` would build for ``compose_action_test_scenario(action, randomize=True,

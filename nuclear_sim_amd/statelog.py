@@ -6,20 +6,26 @@ provider's `get_state_dict()` and `pd.concat`s the row (simulator/state/state_ma
 Here a sample is one gather kernel (`npb_gather_fields`): the chosen members of every plant, widened to double, land
 in a device buffer `[sample, field, plant]`; nothing touches the host until `table()` / `write_parquet()`.
 
-Columns carry the reference's own log names, all 784 of its numeric log columns (checked at every step against the reference's
-own log of a quiet and of an eventful run, tests/test_gpu_parity.py):
-  * `state_names.json` (made by running the reference through three eventful runs and matching whole series value for value; the
-    generator script is named in DESIGN.md section 6) maps 276 log columns onto state members -- several log columns can show one
-    member (the reference logs the total feedwater flow three times), a few through a unit factor, the idle spare pump by analogy;
-  * `derived_log_columns()`: 99 columns that are plain functions of the end-of-step state (pump performance factors, wear sums,
-    steam-generator system averages, TSP deposit aggregates, level-control errors ...);
-  * `result_log_columns()`: 15 keys of the step's secondary result; `clock_log_columns()`: 4 step counters;
-  * `_all_diagnostic_columns()`: 137 step-internal values from the diagnostics build of the step kernel (`StateLog(env,
-    diagnostics=True)`: per-stage turbine conditions, SG capacities and heat fluxes, pump health, alarm counts, bearing oil
-    temperatures ...);
-  * `history_log_columns()`: 1 column that is a window over another logged column's history (emitted when the log holds every
+Columns carry the reference's own log names, all 784 of its numeric log columns, each by ONE rule (checked at every step against
+the reference's own logs of five runs -- a quiet one, an eventful one, a ReactorHeatSource run with operator actions and a scram, a
+feedwater run with four kinds of maintenance, a pump trip cascade and the pH controller switching chemicals, a turbine / steam
+generator run with TSP shutdown, a vibration trip and an ejector rotation -- tests/test_gpu_parity.py, tests/test_statelog_cpu.py):
+  * `reference_log_columns()`: columns that SHOW a state member, established by intervention on the live reference
+    (the harness script named in DESIGN.md section 6 pokes every member and reads the providers back; `state_names.json` "poked"), plus the
+    members an attribute of the reference is assigned together with, by construction (`_ALIASES`, each with its line);
+  * `derived_log_columns()`: plain functions of the end-of-step state (pump factors, wear sums, SG system statistics, TSP stage and
+    recommendation, vibration components, ejector performance, alarms ...), each restating the provider's get_state_dict;
+  * `result_log_columns()`: 15 keys of the step's secondary result; `clock_log_columns()`: hour counters that advance by a fixed
+    amount per step; `output_log_columns()`: the step's own outputs (the scram pulse);
+  * `_all_diagnostic_columns()`: values from inside the step, from the diagnostics build of the step kernel (`StateLog(env,
+    diagnostics=True)`; include/npb.h NPB_DIAG_*): per-stage turbine conditions and extraction flows, SG heat transfer, pump health,
+    which maintenance action a pump received, the protection system's trip bookkeeping, per-ejector performance ...;
+  * `history_log_columns()`: columns that are a window over another logged column's history (emitted when the log holds every
     step since the reset);
-  * `constant_log_columns()`: 252 columns that hold one value in every row of both reference logs, with that value.
+  * `parameter_log_columns()`: configuration values and attributes that the reference sets at construction and no code on the
+    stepped path ever writes -- each with the reference line that sets it (and, where include/npb_params.h carries it, read from
+    the handle's parameters).  Round 3 had 252 columns here by harvest ("held one value in two logs"); what is left is what
+    the reference itself never moves.
 `StateLog(env)` without a field list records the members all of these need and `table()` emits every such column; members
 selected by name that the reference does not log come out as `npb.<section>.<member>`.
 
@@ -45,36 +51,131 @@ from .schema import SCHEMA
 _NAMES_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "state_names.json")
 
 
-def reference_names() -> Dict[str, str]:
-    """schema label -> ONE of the reference's state-log column names, for the members that are logged there."""
-    with open(_NAMES_PATH) as fh:
-        return json.load(fh)["names"]
+_F = "secondary.feedwater_SECONDARY-COMP-001-FW."
+_T = "secondary.turbine_SECONDARY-COMP-001-TURB."
+_C = "secondary.condenser_SECONDARY-COMP-001-COND."
+_G = "secondary.steam_generator_SECONDARY-COMP-001-SG."
+_R = "secondary.reactor_SECONDARY-COMP-001."
 
 
-def reference_log_columns() -> Dict[str, tuple]:
-    """the reference's log column -> (schema label, factor): every column of its log that is a state member (times a unit factor).
-    The name map is made from runs in which the spare pump FWP-4 never moves, so its columns cannot be matched by their series;
-    they are taken by analogy -- a column FWP-4.x is the member of pump 3 that FWP-1.x is of pump 0 -- and checked like the rest
-    against the reference's own logs (where they hold their resting values)."""
+def _names_json() -> dict:
     with open(_NAMES_PATH) as fh:
-        d = json.load(fh)
-    out = {k: (v[0], float(v[1])) for k, v in d["log_columns"].items()}
-    for name in d.get("constants", {}):
-        if "FWP-4" in name and name not in out:
-            twin = out.get(name.replace("FWP-4", "FWP-1"))
-            if twin is not None and twin[0].startswith(("pump[0].", "mpump[0].")):
-                out[name] = (twin[0].replace("pump[0].", "pump[3].", 1), twin[1])
+        return json.load(fh)
+
+
+# Log columns whose attribute the reference ASSIGNS TOGETHER WITH a schema member (same statement or the same value two lines apart),
+# so that after a step the two are one number by construction -- the poke of make_log_map.py cannot see these (it moves the member,
+# not the twin).  log column -> (member, reference line that ties them)
+def _aliases() -> Dict[str, tuple]:
+    out = {
+        "secondary.feedwater.pump_system_total_flow": ("fw.total_flow_rate", "feedwater/pump_system.py:1292 -> feedwater/physics.py:775-776"),
+        "secondary.feedwater.pump_system_total_power": ("fw.total_power_consumption", "feedwater/pump_system.py:1293 -> feedwater/physics.py:775-776"),
+        _F + "diagnostics_reliability": ("fw.overall_health_score", "feedwater/performance_monitoring.py:562"),
+        _F + "protection_npsh_current": ("pump[3].npsh_available", "feedwater/protection_system.py:75, visited once per pump in dict order (:404-410): FWP-4's stands"),
+        _C + "cooling_water_inlet_temp": ("sec.cooling_water_temperature", "condenser/physics.py:767"),
+        _G + "system_total_steam_flow": ("sec.total_steam_flow", "steam_generator/enhanced_physics.py:515 = secondary/__init__.py:559"),
+        _T + "stage_system_steam_flow": ("sec.total_steam_flow", "turbine/stage_system.py:977: the inlet flow the secondary side hands the turbine, secondary/__init__.py:559-568"),
+        "secondary.ph_control.ph_control_ammonia_dose_rate": ("ph.pending_ammonia_dose", "ph_control_system.py:474-480 -> water_chemistry.py:675 (the controller's outputs, stored as they are)"),
+        "secondary.ph_control.ph_control_morpholine_dose_rate": ("ph.pending_morpholine_dose", "ph_control_system.py:474-480 -> water_chemistry.py:675"),
+    }
+    for k in range(3):
+        out[_F + "level_control_sg_%d_error" % (k + 1)] = ("fw.previous_level_errors[%d]" % k, "feedwater/level_control.py: level_errors[i] and previous_level_errors[i] take the same level_error in one pass (:205-330)")
+        out["secondary.steam_generator_SG-%d.feedwater_temperature" % k] = ("sec.previous_feedwater_temp", "steam_generator.py:762 <- the smoothed temperature of secondary/__init__.py:395-398")
+        out["secondary.steam_generator_SG-%d.tsp_years_since_cleaning" % k] = ("sg[%d].tsp_operating_years" % k, "fouling_model_base.py:104-108: both += dt_years; apart only after a cleaning, which is steam-generator maintenance (outside the path)")
     return out
 
 
-def constant_log_columns() -> Dict[str, float]:
-    """The reference's log columns that hold one and the same value in every row of every reference log under tests/golden/
-    (a quiet run and an eventful one): configuration values, flags at rest, readings of equipment that never runs -- name ->
-    value.  Columns that some other rule here produces (a state member, a derived value, a diagnostic) are left to that rule."""
-    with open(_NAMES_PATH) as fh:
-        const = json.load(fh).get("constants", {})
-    taken = set(reference_log_columns()) | set(derived_log_columns()) | set(result_log_columns()) | set(_all_diagnostic_columns()) | set(history_log_columns())
-    return {k: float(v) for k, v in const.items() if k not in taken}
+def reference_log_columns() -> Dict[str, tuple]:
+    """the reference's log column -> (schema label, factor): every column of its log that SHOWS a state member.  Established by
+    intervention (the generator script is named in DESIGN.md section 6: each member poked on the live reference to two values, the providers read
+    back; a column that equals factor x the poked value both times shows that member), plus the by-construction twins above."""
+    d = _names_json()
+    out = {k: (v[0][0], float(v[0][1])) for k, v in d["poked"]["log_columns"].items()}
+    for name, (label, _why) in _aliases().items():
+        assert name not in out, name
+        out[name] = (label, 1.0)
+    return out
+
+
+def reference_names() -> Dict[str, str]:
+    """schema label -> ONE of the reference's state-log column names, for the members that are logged there (several columns can
+    show one member: the closest name, as state_names.json "names" chose it, where the intervention map agrees)"""
+    lc = reference_log_columns()
+    names = {label: name for label, name in _names_json()["names"].items() if lc.get(name) == (label, 1.0)}
+    for name, (label, factor) in sorted(lc.items()):
+        if factor == 1.0 and label not in names:
+            names[label] = name
+    return names
+
+
+def parameter_log_columns(params=None) -> Dict[str, tuple]:
+    """Log columns the stepped path never moves: configuration values, and attributes the reference sets when it constructs a
+    component and that no code reachable from NuclearPlantSimulator.step() writes again.  name -> (value, where the reference
+    sets it).  ``params``: the handle's npb_params_t (BatchedPlantEnv.params); the few values it carries are read from it."""
+    g = lambda name, default: float(getattr(params, name, default)) if params is not None else float(default)
+    out = {
+        "primary.reactor.rated_power_mw": (g("rated_power_mw", 3000.0), "primary/__init__.py:174 (params.rated_power_mw)"),
+        _C + "cooling_water_flow": (45000.0, "secondary/__init__.py:375 control_inputs.get('cooling_water_flow', 45000.0); sim.py passes none -> condenser/physics.py:766"),
+        _C + "steam_inlet_pressure": (0.007, "turbine/enhanced_physics.py hands back the condenser_pressure=0.007 it was given (secondary/__init__.py:567, :610) -> condenser/physics.py:762"),
+        _F + "feedwater_load_demand": (1.0, "feedwater/physics.py:183; only set_load_demand (:896) writes it and the step never calls it"),
+        _F + "level_control_auto_mode": (1.0, "feedwater/level_control.py:150"),
+        _F + "level_control_manual_setpoint": (3 * g("sg_design_feedwater_flow_per_sg", 500.0), "feedwater/level_control.py:151: design_flow_per_sg * num_steam_generators"),
+        _F + "diagnostics_time_since_maintenance": (0.0, "feedwater/performance_monitoring.py:259; += only in the legacy wear-tracking branch (:493-503), not taken by pumps that own a lubrication system"),
+        _F + "protection_system_available": (1.0, "feedwater/protection_system.py:184"),
+        _F + "protection_false_trip_count": (0.0, "feedwater/protection_system.py:188; incremented by perform_protection_test only"),
+        "secondary.ph_control.ph_control_setpoint": (9.2, "ph_control_system.py:204 config.target_ph"),
+        "secondary.ph_control.ph_control_alarm_equipment": (0.0, "ph_control_system.py:396-414: set by the random equipment failures, which the deterministic limit of include/npb_fields.h (NPB_PH_FIELDS) leaves out"),
+        _R + "system_feedwater_temperature": (227.0, "secondary/__init__.py:373 control_inputs.get('feedwater_temp', 227.0); sim.py passes none"),
+        _R + "system_num_steam_generators": (3.0, "secondary/__init__.py:256"),
+        _G + "system_efficiency": (0.98, "steam_generator/enhanced_physics.py:139 / config.py:274 design_efficiency"),
+        _G + "system_performance_factor": (1.0, "steam_generator/enhanced_physics.py:143; moved by steam-generator maintenance only (:664, :988 ...), outside the path"),
+        _G + "system_load_balance_factor": (1.0, "steam_generator/enhanced_physics.py:145; moved by steam-generator maintenance only"),
+        _G + "system_num_steam_generators": (3.0, "steam_generator/enhanced_physics.py:685 config.num_steam_generators"),
+        _T + "vibration_trend_slope": (0.0, "turbine/rotor_dynamics.py:616; nothing on the path computes a trend"),
+        _T + "stage_system_extraction_flow": None,   # produced from the diagnostics (placeholder removed below)
+    }
+    del out[_T + "stage_system_extraction_flow"]
+    for pre in ("secondary.water_chemistry.", _F):     # the shared WaterChemistry, logged under its own name and in the feedwater system's dict
+        out[pre + "water_chemistry_iron_concentration"] = (0.1, "water_chemistry.py:234 config.design_iron_concentration")
+        out[pre + "water_chemistry_copper_concentration"] = (0.05, "water_chemistry.py:235")
+        out[pre + "water_chemistry_silica_concentration"] = (20.0, "water_chemistry.py:236")
+        out[pre + "water_chemistry_alkalinity"] = (120.0, "water_chemistry.py:243")
+        out[pre + "water_chemistry_concentration_factor"] = (5.0, "water_chemistry.py:373-374: 1 / (blowdown 0.02 + evaporation) capped at config.concentration_factor_max, the cap at every update")
+        out[pre + "water_chemistry_blowdown_rate"] = (0.02, "water_chemistry.py:263, re-set from the literal 'blowdown_rate': 0.02 of every caller (condenser/physics.py:773, feedwater/physics.py:705-712)")
+    for k in range(3):
+        out[_F + "level_control_sg_%d_target" % (k + 1)] = (12.5, "feedwater/level_control.py:136 config.level_setpoint")
+        N = "secondary.steam_generator_SG-%d." % k
+        out[N + "steam_void_fraction"] = (0.8, "steam_generator.py:483-489: x rho_f / (x rho_f + (1 - x) rho_g) clipped to [0, 0.8]; the quality is itself clipped to >= 0.90 (:478), "
+                                               "where the ratio exceeds 0.8 for any rho_f / rho_g > 0.45 -- the upper clip, always")
+        out[N + "base_pump_power_mw"] = (5.0, "steam_generator/steam_generator.py:649")
+        out[N + "tsp_cleaning_cycles"] = (0.0, "tsp_fouling_model.py total_cleaning_cycles: counted by perform_cleaning, i.e. steam-generator maintenance (outside the path)")
+        out[N + "tube_primary_boric_acid_ppm"] = (1000.0, "steam_generator/tube_interior_fouling.py:82")
+        out[N + "tube_primary_lithium_ppm"] = (2.0, "steam_generator/tube_interior_fouling.py:83")
+        out[N + "tube_primary_ph"] = (7.2, "steam_generator/tube_interior_fouling.py:84")
+        out[N + "tube_primary_dissolved_oxygen_ppm"] = (0.005, "steam_generator/tube_interior_fouling.py:86")
+    for k in range(4):
+        N = "secondary.feedwater_FWP-%d." % (k + 1)
+        out[N + "motor_voltage"] = (6.6, "feedwater/pump_system.py:77, :709 ('kV constant')")
+        out[N + "seal_water_pressure"] = (0.8, "feedwater/pump_lubrication.py:58, :207 config.seal_water_system_pressure")
+        out[N + "npsh_margin_degradation"] = (0.0, "feedwater/pump_lubrication.py:1472 cavitation_damage * 0.5 with the argument the closure never passes (:1659-1852: 'cavitation_damage' is not in pump_conditions -> 0.0)")
+        out[N + "maintenance_due"] = (0.0, "lubrication_base.py:159; set by check_maintenance_requirements (:402-432), which only the never-stepped governor calls (turbine/governor_system.py:1014)")
+        out[_T + "TB-00%d_vibration_disp" % (k + 1)] = (5.0, "turbine/enhanced_physics.py:572-573 initial_conditions.bearing_vibrations; the bearing model never writes it (rotor_dynamics.py:62)")
+        out[_T + "TB-00%d_vibration_vel" % (k + 1)] = (0.0, "turbine/rotor_dynamics.py:63; never written")
+    L = "secondary.turbine_TB-LUB-001."          # the turbine lubrication system's performance effects: computed by update_turbine_lubrication_effects
+    for name, value, why in (("oil_level", 100.0, "turbine/turbine_bearing_lubrication.py:201 <- turbine/config.py:349 oil_reservoir_level; no consumption model"),   # (:346-382), which only the module's __main__ demo calls (:1260)
+                             ("efficiency_degradation_factor", 1.0, "turbine_bearing_lubrication.py:689: 1 - turbine_efficiency_degradation, computed by _calculate_turbine_performance_degradation (:384-421), reached from update_turbine_lubrication_effects only -- which nothing on the path calls"),
+                             ("bearing_housing_temperature", 80.0, "turbine_bearing_lubrication.py:181 config.bearing_housing_temperature (:58); rewritten at :421 only"),
+                             ("oil_cooling_effectiveness", 1.0, "turbine_bearing_lubrication.py:187; rewritten at :372 only"),
+                             ("vibration_increase", 0.0, "turbine_bearing_lubrication.py:186; rewritten at :417 only"),
+                             ("steam_contamination_rate", 0.0, "turbine_bearing_lubrication.py:180; rewritten at :367 only"),
+                             ("maintenance_due", 0.0, "lubrication_base.py:159; check_maintenance_requirements is never called on the path")):
+        out[L + name] = (value, why)
+    return out
+
+
+def constant_log_columns(params=None) -> Dict[str, float]:
+    """name -> value of parameter_log_columns (kept under its round-3 name for callers that emit them)"""
+    return {k: v[0] for k, v in parameter_log_columns(params).items()}
 
 
 def _max(a, b):
@@ -178,7 +279,6 @@ def derived_log_columns() -> Dict[str, tuple]:
             tot = tot + _max(0.1, 1.0 - (w * a + (1.0 - eff) * b))
         return tot / 5 * eff
     out["secondary.turbine_TB-LUB-001.system_health_factor"] = (("turb.lub_effectiveness",) + tuple("turb.lub_wear[%d]" % k for k in range(5)), tb_health)
-    out["secondary.condenser_SECONDARY-COMP-001-COND.condensate_flow"] = (("sec.total_steam_flow",), lambda q: q - 250.0)   # the main steam less the extraction flows
     # enhanced_physics.py:815-821 with the property fits :1285-1310: steam enthalpy at the header's conditions x steam rate
     def header_enthalpy(p_mpa, temp_c):
         pb = np.clip(p_mpa * 10.0, 0.01, 100.0)
@@ -204,32 +304,129 @@ def derived_log_columns() -> Dict[str, tuple]:
                                                            lambda tds, hard, ph: 2 * ph_saturation(tds, hard) - ph)
         out[pre + "water_chemistry_stability_factor"] = (("chem[0].ph", "chem[0].treatment_efficiency"),
                                                          lambda ph, te: np.clip(((1.0 - np.abs(ph - 9.2) / 2.0) + te + (1.0 - abs(5.0 - 2.0) / 3.0)) / 3.0, 0.1, 1.0))
+    # ---- round 4: the columns round 3 emitted as literals
+    for k in range(4):
+        P, N = "pump[%d]." % k, "secondary.feedwater_FWP-%d." % (k + 1)
+        out[N + "head_factor"] = ((P + "head_degradation",), lambda d: _max(0.5, 1 - d / 100))                      # pump_lubrication.py:236-238
+    # FeedwaterPumpSystem.system_available: enough pumps running, whatever the protection system says (pump_system.py:1297; 3 = minimum_pumps_required)
+    out["secondary.feedwater.pump_system_available"] = (("fw.running_mask",), lambda m: (sum(((np.asarray(m).astype(np.int64) >> i) & 1) for i in range(4)) >= 3).astype(np.float64))
+    out[F + "protection_npsh_margin"] = (("pump[3].npsh_available",), lambda v: v - 0.1)   # protection_system.py:131: current_npsh - npsh_critical_trip, which resolves to low_suction_pressure_trip = 0.1 (getattr fall-back)
+    # steam generators: maxima over the three (enhanced_physics.py:712, :718), the maintenance hint (:722), the TSP stage (tsp_fouling_model.py:394-411,
+    # FoulingStage order :53-58) and the replacement recommendation (:700-703: fouling >= 0.8 or older than the 40-year design life)
+    max3 = lambda a, b, c: _max(_max(a, b), c)
+    out[S + "system_max_tsp_fouling_fraction"] = (three("tsp_fouling_fraction"), max3)
+    out[S + "system_max_scale_thickness_mm"] = (three("scale_thickness"), max3)
+    out[S + "system_fouling_maintenance_needed"] = (three("tsp_fouling_fraction") + three("scale_thickness"),
+                                                    lambda a, b, c, x, y, z: ((mean3(a, b, c) > 0.15) | (mean3(x, y, z) > 0.5)).astype(np.float64))
+    for i in range(3):
+        G, N = "sg[%d]." % i, "secondary.steam_generator_SG-%d." % i
+        out[N + "tsp_fouling_stage_numeric"] = ((G + "tsp_fouling_fraction",), lambda f: np.where(f < 0.4, 0.0, np.where(f < 0.7, 1.0, np.where(f < 0.85, 2.0, 3.0))))
+        out[N + "tsp_replacement_recommended"] = ((G + "tsp_fouling_fraction", G + "tsp_operating_years"), lambda f, y: ((f >= 0.8) | (y > 40.0)).astype(np.float64))
+    # turbine: availability is "not tripped" (enhanced_physics.py:829); the vibration monitor's other readings are fixed multiples of
+    # the displacement it stores (rotor_dynamics.py:660-693: 1X : 2X : 3X = 1 : 0.1 : 0.05, y = 0.8 x, velocity = displacement x omega / 1000,
+    # acceleration = velocity x omega / 9.81, omega from the rotor speed of the same update)
+    out[_T + "enhanced_turbine_availability"] = (("turb.trip_active",), lambda t: 1.0 - (np.asarray(t) != 0).astype(np.float64))
+    rss = np.sqrt(1.0 + 0.1 ** 2 + 0.05 ** 2)
+    vib = ("turb.vibration_displacement", "turb.rotor_speed")
+    omega = lambda rpm: 2 * np.pi * (rpm / 60.0)
+    out[_T + "vibration_displacement_y"] = (vib, lambda d, rpm: d * 0.8)
+    out[_T + "vibration_1x_amplitude"] = (vib, lambda d, rpm: d / rss)
+    out[_T + "vibration_2x_amplitude"] = (vib, lambda d, rpm: d / rss * 0.1)
+    out[_T + "vibration_velocity_x"] = (vib, lambda d, rpm: d * omega(rpm) / 1000.0)
+    out[_T + "vibration_velocity_y"] = (vib, lambda d, rpm: d * omega(rpm) / 1000.0 * 0.8)
+    out[_T + "vibration_acceleration_x"] = (vib, lambda d, rpm: d * omega(rpm) / 1000.0 * omega(rpm) / 9.81)
+    out[_T + "vibration_acceleration_y"] = (vib, lambda d, rpm: d * omega(rpm) / 1000.0 * omega(rpm) / 9.81 * 0.8)
+    # condenser: the ejectors' flags and performance factor (vacuum_pump.py:541, :272-275), the condensate at the saturation temperature of
+    # the condenser pressure the vacuum system ends the step with (condenser/physics.py:841 with the fit :1824-1838)
+    for e in range(2):
+        N = "secondary.condenser.SJE-00%d_" % (e + 1)
+        out[N + "operating"] = (("cond.ej_operating_mask",), lambda m, e=e: ((np.asarray(m).astype(np.int64) >> e) & 1).astype(np.float64))
+        out[N + "performance"] = (("cond.ej_nozzle_fouling[%d]" % e, "cond.ej_diffuser_fouling[%d]" % e, "cond.ej_nozzle_erosion[%d]" % e), lambda a, b, c: a * b * c)
+
+    def cond_tsat(p_mpa):
+        t = 1730.63 / (8.07131 - np.log10(np.clip(p_mpa * 10.0, 0.01, 100.0))) - 233.426
+        t = np.where((p_mpa >= 0.005) & (p_mpa <= 0.01), np.clip(t, 35.0, 45.0), t)
+        return np.where(p_mpa <= 0.001, 10.0, np.clip(t, 10.0, 374.0))
+    out[_C + "condensate_temperature"] = (("cond.condenser_pressure",), cond_tsat)
+    # pH controller (ph_control_system.py:243, :416-424, :345-347, :659): the error it stores is setpoint - measured of the same update; the
+    # pH alarms compare that measurement with config.ph_alarm_low / _high (8.8 / 9.6); the consumption is the two dose rates together
+    out["secondary.ph_control.ph_control_error"] = (("ph.measured_ph",), lambda m: 9.2 - m)
+    out["secondary.ph_control.ph_control_alarm_low"] = (("ph.measured_ph",), lambda m: (m < 8.8).astype(np.float64))
+    out["secondary.ph_control.ph_control_alarm_high"] = (("ph.measured_ph",), lambda m: (m > 9.6).astype(np.float64))
+    out["secondary.ph_control.ph_control_total_consumption"] = (("ph.pending_ammonia_dose", "ph.pending_morpholine_dose"), lambda a, b: a + b)
+    out["secondary.ph_control.ph_control_mode_auto"] = (("ph.controller_enabled",), lambda e: (np.asarray(e) != 0).astype(np.float64))   # :426-432: AUTO -> FAILED and enabled -> False in one statement pair
     mapped = set(reference_log_columns())
     return {k: v for k, v in out.items() if k not in mapped}
 
 
 def clock_log_columns(dt: float) -> Dict[str, tuple]:
-    """Log columns that count the steps taken: name -> (member labels, function), for a plant stepped with ``dt``.  The shared
-    WaterChemistry is updated twice a step (feedwater/physics.py:708, secondary/__init__.py:644), each time adding its guess of
-    dt in hours (water_chemistry.py:335-348) to operating_hours and last_treatment_time; the number of steps is read off the
-    secondary side's own hour counter (operating_hours += dt / 3600, secondary/__init__.py:632)."""
+    """Log columns that count the steps taken: name -> (member labels, function), for a plant stepped with ``dt``.  The number of
+    steps n is read off the secondary side's own hour counter (operating_hours += dt / 3600, secondary/__init__.py:632).
+    The shared WaterChemistry is updated twice a step (feedwater/physics.py:708, secondary/__init__.py:644), each time adding its
+    guess of dt in hours (water_chemistry.py:335-348) to operating_hours and last_treatment_time.  Every other counter adds the
+    same dt / 60 per step: the turbine, its stage system, each of the 14 stages and 4 bearings, the vacuum system and the condenser
+    are handed dt / 60 "hours" (secondary/__init__.py:568, :620; enhanced_physics.py:832, stage_system.py:329, :996,
+    rotor_dynamics.py:306, vacuum_system.py:502, condenser/physics.py:849), the feedwater system adds dt / 60 itself
+    (feedwater/physics.py:809) and the steam-generator system (60 dt) / 3600 (steam_generator/enhanced_physics.py:525) --
+    unconditionally, tripped or not."""
     dth = dt / 3600.0 if dt > 100 else (dt / 60.0 if dt > 1 else dt)
-    hours = (("sec.operating_hours",), lambda h: 2 * dth * np.round(h * 3600.0 / dt))
-    F = "secondary.feedwater_SECONDARY-COMP-001-FW."
-    return {pre + k: hours for pre in ("secondary.water_chemistry.", F) for k in ("water_chemistry_operating_hours", "water_chemistry_time_since_treatment")}
+    steps = lambda h: np.round(h * 3600.0 / dt)
+    chem = (("sec.operating_hours",), lambda h: 2 * dth * steps(h))
+    hours = (("sec.operating_hours",), lambda h: (dt / 60.0) * steps(h))
+    out = {pre + k: chem for pre in ("secondary.water_chemistry.", _F) for k in ("water_chemistry_operating_hours", "water_chemistry_time_since_treatment")}
+    stage_names = ["HP-%d" % (k + 1) for k in range(8)] + ["LP-%d" % (k + 1) for k in range(6)]
+    for name in ["secondary.turbine_%s.operating_hours" % sn for sn in stage_names] + \
+                [_T + k for k in ("operating_hours", "enhanced_turbine_operating_hours", "stage_system_operating_hours")] + \
+                [_T + "TB-00%d_operating_hours" % (k + 1) for k in range(4)] + \
+                ["secondary.condenser.vacuum_system_operating_hours", _C + "condenser_operating_hours", _F + "feedwater_operating_hours",
+                 _G + "system_operating_hours"]:
+        out[name] = hours
+    # the pH controller's chemical alarm looks at the tank levels BEFORE this update's consumption (ph_control_system.py:246 runs
+    # _update_alarms_and_trips, :262 _update_chemical_supplies): the levels the step ends with, plus what it dosed -- dose [kg/h] x dt
+    # "hours" (the controller is handed the simulator's dt as hours, secondary/__init__.py:647-650) over the 1 000 / 2 000 kg tanks
+    out["secondary.ph_control.ph_control_alarm_chemical"] = (
+        ("ph.ammonia_tank_level", "ph.morpholine_tank_level", "ph.pending_ammonia_dose", "ph.pending_morpholine_dose"),
+        lambda la, lm, da, dm: (((la + np.where(da > 0, da * dt / 1000.0 * 100.0, 0.0)) < 20.0) | ((lm + np.where(dm > 0, dm * dt / 2000.0 * 100.0, 0.0)) < 20.0)).astype(np.float64))
+    return out
+
+
+def output_log_columns() -> Dict[str, str]:
+    """Log columns that are an OUTPUT of the step just taken, not state: PrimaryReactorPhysics.scram_activated is the result of this
+    step's safety check (primary/__init__.py:255-262: True on the step the scram fires, False again on the next) -- the step's
+    ``done`` column (sim.py:256).  name -> output"""
+    return {"primary.reactor.scram_activated": "done", "primary.reactor.safety_scram_activated": "done"}
 
 
 def history_log_columns() -> Dict[str, tuple]:
-    """Log columns that are a function of another log column's recent history: name -> (source log column, function of the
-    [samples, plants] series).  The pH controller's RMS deviation is the root mean square of the last 100 steps' |pH error|
-    (ph_control_system.py:441-455), a list the reference keeps on the controller; a log that holds every step since the reset
-    holds the same list, so ``table()`` emits the column exactly then (steps 1, 2, 3 ... recorded with every=1)."""
+    """Log columns that are a function of other log columns' recent history: name -> (source log columns, function of their
+    [samples, plants] series).  ``table()`` emits them when the log holds every step since the reset (steps 1, 2, 3 ... recorded
+    with every=1): then it holds the lists the reference keeps.
+      * the pH controller's RMS deviation: root mean square of the last 100 steps' |pH error| (ph_control_system.py:441-455), and its
+        time in control: the share of the steps so far whose |error| was within the 0.05 deadband (:457-467; the steps are equally long);
+      * the NPSH trend of the feedwater protection: its one NPSHProtection object is visited once per pump per step and keeps the last
+        ten readings whoever they belong to (protection_system.py:77-85): (latest - oldest kept) / number kept."""
     def rms_of_last_100(series):
         ns = series.shape[0]
         csum = np.concatenate([np.zeros((1,) + series.shape[1:]), np.cumsum(np.square(series), axis=0)], axis=0)
         hi = np.arange(1, ns + 1); lo = np.maximum(0, hi - 100)
         return np.sqrt((csum[hi] - csum[lo]) / (hi - lo).reshape((-1,) + (1,) * (series.ndim - 1)))
-    return {"secondary.ph_control.ph_control_deviation_rms": ("secondary.ph_control.ph_control_error", rms_of_last_100)}
+
+    def time_in_control(series):
+        inside = (np.abs(series) <= 0.05).astype(np.float64)
+        n = np.arange(1, series.shape[0] + 1).reshape((-1,) + (1,) * (series.ndim - 1))
+        return np.cumsum(inside, axis=0) / n * 100.0
+
+    def npsh_trend(a, b, c, d):
+        seq = np.stack([a, b, c, d], axis=1).reshape((4 * a.shape[0],) + a.shape[1:])     # reading 4 (t - 1) + k = pump k at step t
+        out = np.empty_like(a)
+        for t in range(a.shape[0]):
+            n = 4 * (t + 1); kept = min(10, n)
+            out[t] = (seq[n - 1] - seq[n - kept]) / kept
+        return out
+    E = "secondary.ph_control.ph_control_error"
+    return {"secondary.ph_control.ph_control_deviation_rms": ((E,), rms_of_last_100),
+            "secondary.ph_control.ph_control_time_in_control": ((E,), time_in_control),
+            _F + "protection_npsh_trend": (tuple("secondary.feedwater_FWP-%d.npsh_available" % (k + 1) for k in range(4)), npsh_trend)}
 
 
 def result_log_columns() -> Dict[str, tuple]:
@@ -271,6 +468,8 @@ def log_columns(fields: Optional[Sequence[str]] = None) -> List[tuple]:
             wanted.update(need)
         for need, _fn in clock_log_columns(1.0).values():
             wanted.update(need)
+        for rows, _fn in diagnostic_function_columns().values():
+            wanted.update(r for r in rows if isinstance(r, str))
         for kind, slot, label, _path in cols:
             if label in wanted:
                 out.append((kind, slot, label, names.get(label, "npb." + label)))
@@ -300,8 +499,8 @@ def diagnostic_log_columns() -> Dict[str, int]:
     for v, value in enumerate(_lib.DIAG_SG_VALUES):       # SteamGenerator.get_state_dict (steam_generator.py:943-985)
         for i in range(3):
             out["secondary.steam_generator_SG-%d.%s" % (i, value)] = 14 * len(_lib.DIAG_STAGE_VALUES) + v * 3 + i
-    known = set(json.load(open(_NAMES_PATH))["unmatched"])
-    return {name: row for name, row in out.items() if name in known}
+    shown = set(reference_log_columns())     # e.g. LP-6's outlet is no member, HP-1's inlet is none either: all of them come from here
+    return {name: row for name, row in out.items() if name not in shown}
 
 
 def _all_diagnostic_columns() -> Dict[str, int]:
@@ -321,6 +520,64 @@ def _all_diagnostic_columns() -> Dict[str, int]:
     for name, off in _lib.DIAG_TAIL_COLUMNS:
         out[name] = base + off
     return out
+
+
+MAINTENANCE_FLAG_ACTIONS = ("oil_change", "oil_top_off", "bearing_replacement", "seal_replacement", "component_overhaul", "system_cleaning",
+                            "bearing_inspection", "impeller_inspection", "impeller_replacement", "lubrication_system_check", "motor_inspection",
+                            "oil_analysis", "vibration_analysis")    # FeedwaterPumpLubricationSystem.maintenance_action_flags, pump_lubrication.py:90-104
+
+
+def diagnostic_function_columns() -> Dict[str, tuple]:
+    """Log columns that are a function of diagnostics rows (include/npb.h NPB_DIAG_*, round 4): name -> (rows, function).
+      * per pump the thirteen <action>_occurred flags of its state dict (pump_lubrication.py:642-643 sets the flag of the action the
+        dispatcher is handed, :1636-1641 logs and clears them): from the row that names the action the maintenance rule carried out on
+        the pump in this step (oil_top_off_occurred keeps its own row, NPB_DIAG_PUMP_OIL_TOP_OFF_OCCURRED);
+      * the stage system's total extraction (stage_system.py:978): the fourteen stages' extraction flows, summed in stage order;
+      * its total power (stage_system.py:976); the protection system's trip bookkeeping; the ejectors."""
+    out = {}
+    actions = list(_lib.MAINT_ACTIONS)
+    for k in range(4):
+        for a in MAINTENANCE_FLAG_ACTIONS:
+            if a == "oil_top_off":
+                continue
+            out["secondary.feedwater_FWP-%d.%s_occurred" % (k + 1, a)] = ((_lib.DIAG_PUMP_MAINTENANCE_ACTION + k,), lambda v, code=actions.index(a) + 1: (v == code).astype(np.float64))
+
+    def total(*flows):
+        acc = 0.0 * flows[0]
+        for f in flows:
+            acc = acc + f
+        return acc
+    out[_T + "stage_system_extraction_flow"] = (tuple(_lib.DIAG_STAGE_EXTRACTION_FLOW + k for k in range(14)), total)
+    ident = lambda v: v
+    out[_T + "stage_system_total_power"] = ((_lib.DIAG_STAGE_SYSTEM_TOTAL_POWER,), ident)
+    stage_names = ["HP-%d" % (k + 1) for k in range(8)] + ["LP-%d" % (k + 1) for k in range(6)]
+    for k, sn in enumerate(stage_names):
+        out["secondary.turbine_%s.extraction_flow" % sn] = ((_lib.DIAG_STAGE_EXTRACTION_FLOW + k,), ident)
+    out[_T + "extraction_flow"] = ((_lib.DIAG_STAGE_EXTRACTION_FLOW + 13,), ident)     # the stage system's dict keeps the last stage's un-prefixed keys
+    out[_F + "protection_active_trips_count"] = ((_lib.DIAG_FW_ACTIVE_TRIPS,), ident)
+    out[_F + "protection_valid_trip_count"] = ((_lib.DIAG_FW_VALID_TRIP_COUNT,), ident)
+    out[_F + "protection_emergency_feedwater"] = ((_lib.DIAG_FW_EMERGENCY_FEEDWATER,), ident)
+    out[_F + "protection_steam_dump"] = ((_lib.DIAG_FW_STEAM_DUMP,), ident)
+    for e in range(2):
+        N = "secondary.condenser.SJE-00%d_" % (e + 1)
+        out[N + "capacity"] = ((_lib.DIAG_COND_SJE_CAPACITY + e,), ident)
+        out[N + "steam_flow"] = ((_lib.DIAG_COND_SJE_STEAM_FLOW + e,), ident)
+        out[N + "steam_consumption"] = ((_lib.DIAG_COND_SJE_STEAM_CONSUMPTION + e,), ident)
+        out[N + "compression_ratio"] = ((_lib.DIAG_COND_SJE_COMPRESSION_RATIO + e,), ident)
+        out[N + "operating_hours"] = ((_lib.DIAG_COND_SJE_OPERATING_HOURS + e,), ident)
+    out["secondary.condenser.vacuum_system_air_removal"] = ((_lib.DIAG_COND_AIR_REMOVAL,), ident)
+    # the condenser is handed the main steam less what the stages extracted (enhanced_physics.py effective_steam_flow -> condenser/physics.py:842);
+    # a source that is a string is a state member sampled with the log
+    out[_C + "condensate_flow"] = (("sec.total_steam_flow",) + tuple(_lib.DIAG_STAGE_EXTRACTION_FLOW + k for k in range(14)), lambda q, *flows: q - total(*flows))
+    plain = _all_diagnostic_columns()         # the first ejector's steam flow / consumption have had rows of their own since round 3
+    return {k: v for k, v in out.items() if k not in plain}
+
+
+def log_column_name(name: str, naming: str) -> str:
+    """A rule's column name (written with the data-gen composer's ids) as a plant of the given naming logs it"""
+    if naming == "default":
+        return name.replace("secondary.reactor_SECONDARY-COMP-001.", "secondary.reactor.").replace("_SECONDARY-COMP-001-", "_SECONDARY-001-")
+    return name
 
 
 class StateLog:
@@ -348,6 +605,12 @@ class StateLog:
             if getattr(env, "diagnostics", None) is None:
                 env.enable_diagnostics(True)
             self._diag = torch.empty((self.capacity, _lib.DIAG_DIM, env.n), dtype=torch.float64, device=env.device)
+        # the step's own outputs that the reference logs (the scram pulse = the step's done column)
+        self._done = torch.empty((self.capacity, env.n), dtype=torch.uint8, device=env.device) if self._reference_layout else None
+        # how the reference names the plant's secondary-side providers: NuclearPlantSimulator's default configuration gives
+        # "secondary.<subsystem>_SECONDARY-001-<X>." (and "secondary.reactor." for the secondary side itself), the data-gen composer's
+        # configuration "SECONDARY-COMP-001" (auto_register.py:83-165 with each config's system_id)
+        self.naming = getattr(env, "log_naming", "default")
         self._times: List[float] = []
         self._steps: List[int] = []
 
@@ -368,6 +631,8 @@ class StateLog:
                 self._res[row, j] = res[k]
         if self._diag is not None:
             self._diag[row].copy_(self.env.diagnostics)
+        if self._done is not None:
+            self._done[row].copy_(self.env._done)
         self._times.append(float(time_minutes)); self._steps.append(int(step))
 
     def maybe_record(self, step: int, time_minutes: float) -> bool:
@@ -410,12 +675,22 @@ class StateLog:
                 dg = self._diag[:len(self._times)].cpu().numpy()[:, :, idx]
                 for name, row in sorted(_all_diagnostic_columns().items()):
                     cols[name] = dg[:, row, :].reshape(-1)
+                for name, (rows, fn) in sorted(diagnostic_function_columns().items()):
+                    cols[name] = np.asarray(fn(*[(data[:, index[r], :] if isinstance(r, str) else dg[:, r, :]).reshape(-1) for r in rows]), dtype=np.float64)
+            done = self._done[:len(self._times)].cpu().numpy()[:, idx].reshape(-1).astype(np.float64)
+            for name, what in sorted(output_log_columns().items()):
+                cols[name] = done
             if self._steps == list(range(1, ns + 1)):      # every step since the reset: the windowed columns can be formed
-                for name, (source, fn) in sorted(history_log_columns().items()):
-                    cols[name] = np.asarray(fn(cols[source].reshape(ns, npl)), dtype=np.float64).reshape(-1)
-            for name, value in sorted(constant_log_columns().items()):
+                for name, (sources, fn) in sorted(history_log_columns().items()):
+                    if all(src in cols for src in sources):
+                        cols[name] = np.asarray(fn(*[cols[src].reshape(ns, npl) for src in sources]), dtype=np.float64).reshape(-1)
+            for name, value in sorted(constant_log_columns(self.env.params).items()):
                 if name not in cols:
                     cols[name] = np.full(ns * npl, value)
+            for name, values in sorted(getattr(self.env, "log_side_columns", {}).items()):     # per-plant values the constructor fixed (below)
+                cols[name] = np.tile(np.broadcast_to(np.asarray(values, dtype=np.float64), (self.env.n,))[idx], ns)
+            if self.naming == "default":
+                cols = {log_column_name(k, "default"): v for k, v in cols.items()}
             return pa.table(cols)
         for f, (kind, _slot, _label, name) in enumerate(self.columns):
             v = data[:, f, :].reshape(-1)

@@ -142,6 +142,38 @@ def scenarios():
                              + [(SGP_ % (1, sp, k), v) for sp, v in (("magnetite", 1.2), ("silica", 0.6)) for k in range(7)],
                   pokes={12: [(L % (1, "oil_level"), 9.0)], 24: [(P % 2 + ".state.npsh_available", 11.0)],
                          36: [("=list(root.secondary_physics.turbine.rotor_dynamics.bearings.values())[1].metal_temperature", 105.0)]}))
+    # L1-L3 (round 4): runs whose state LOG moves where the m1 / e1 logs rest (log_<name>.npz is the reference's own log of each;
+    # nuclear_sim_amd/statelog.py must follow every column of them).
+    # L1: NuclearPlantSimulator(enable_state_management=True) on the ReactorHeatSource from the equilibrium state, the s2 action
+    # script (rods, boron, coolant flow, steam valve), a scram by over-power at step 90: the 19 primary.reactor.* columns
+    S.append(dict(name="l1_reactor_log", steps=140, heat_source="reactor", equilibrium=(100.0, 95.0), state_management=True, every=4,
+                  feedwater_thresholds_only=True,
+                  actions=lambda t: (int(acts[t]), float(mags[t])), pokes={90: [("primary_physics.state.neutron_flux", 1.3e13)]}))
+    # L2: the data-gen runner's plant with the m8 pokes (impeller inspection, impeller replacement, component overhaul, an oil
+    # top-off promoted to an oil change: four different <action>_occurred flags), the pH controller's ammonia tank run dry
+    # (morpholine dosing, chemical alarm), an NPSH collapse (cavitation, pump trip, the protection system's trip count and
+    # emergency feedwater), then the SG-level trip of every pump (steam dump; levels fall to their floor)
+    PH_ = "secondary_physics.ph_control_system.controller.state.%s"
+    S.append(dict(name="l2_feedwater_events_log", steps=60, dt=5.0, noise=True, noise_seed=42, every=2, feedwater_thresholds_only=True,
+                  runner=dict(action="oil_top_off", duration_hours=5.0),
+                  setpoints=lambda t: 90.0 + 6.0 * float(np.sin(t / 6.0)),
+                  init_pokes=[(W % (1, "impeller"), 8.5), (P % 2 + ".state.cavitation_damage", 8.5),
+                              (W % (3, "mechanical_seals"), 17.0), (W % (3, "motor_bearings"), 9.0),
+                              (L % (4, "oil_level"), 57.0), (L % (4, "oil_contamination_level"), 15.5)],
+                  pokes={10: [(PH_ % "ammonia_tank_level", 3.0)],
+                         20: [(P % 1 + ".state.npsh_available", 0.05)], 30: [(P % 2 + ".state.npsh_available", 3.0)],
+                         44: [("secondary_physics._previous_sg_conditions['levels'][0]", 16.2)]}))
+    # L3: steam generators and turbine: TSP deposits past the fouling model's stages on SG-0 (shutdown protection, replacement
+    # recommendation) and uneven on SG-1, a rotor overspeed excursion (clamped), a thermal bow (vibration trip: turbine availability,
+    # every vibration column), the ejectors' weekly rotation brought forward (SJE-002 takes over)
+    S.append(dict(name="l3_turbine_sg_events_log", steps=60, dt=5.0, noise=True, noise_seed=42, every=2, feedwater_thresholds_only=True,
+                  runner=dict(action="oil_top_off", duration_hours=5.0),
+                  cooling=lambda t: 25.0 + 5.0 * float(np.sin(t / 7.0)),
+                  init_pokes=[(SGP_ % (0, sp, k), v) for sp, v in (("magnetite", 4.0), ("copper", 2.0), ("silica", 2.5)) for k in range(7)]
+                             + [(SGP_ % (1, "magnetite", k), 3.5) for k in range(3)],
+                  pokes={10: [("secondary_physics.turbine.rotor_dynamics.rotor_speed", 5000.0)],
+                         18: [("secondary_physics.condenser.vacuum_system.control_logic.rotation_timer", 167.95)],
+                         30: [("secondary_physics.turbine.rotor_dynamics.thermal_bow", 2.0)]}))
     # H1: a user-supplied heat source through the reference's plugin interface (heat_source_interface.py:23-112, consumed at
     # primary/__init__.py:203-225): a scripted load swing whose power_percent is NOT its thermal power over rated (the two keys
     # are independent in the interface), with actuator actions and a cooling-water swing on top

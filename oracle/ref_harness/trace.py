@@ -82,6 +82,13 @@ def run_reference(sc, columns):
                           noise_seed=sc.get("noise_seed", 42), secondary=sc.get("secondary"),
                           enable_secondary=sc.get("enable_secondary", True), state_management=sc.get("state_management", False))
     from systems.primary import ControlAction
+    if sc.get("feedwater_thresholds_only") and getattr(sim, "state_manager", None) is not None:
+        # a maintenance configuration that names the feedwater pumps only: the automatic maintenance of steam generators, turbine
+        # and condenser (TSP cleaning, bearing work ...) is outside the path this repository restates, and a run whose log is to
+        # be followed column by column must not have the reference execute it
+        th = sim.state_manager.maintenance_thresholds
+        for cid in [c for c in th if not c.startswith("FWP-")]:
+            del th[cid]
     if sc.get("thresholds_override"):
         # edit the live maintenance thresholds of every feedwater pump (what another maintenance configuration would load)
         for cid, th in sim.state_manager.maintenance_thresholds.items():

@@ -24,7 +24,12 @@ def _env(g=None, n=1, **kw):
         kw.setdefault("reactivity_components", g.rc is not None)
         if m.get("maint_thresholds"):    # the run used a maintenance configuration other than the default one
             kw.setdefault("maintenance_thresholds", dict((nm, c) for nm, c in m["maint_thresholds"]))
-    return BatchedPlantEnv(n, **kw)
+    env = BatchedPlantEnv(n, **kw)
+    if g is not None and g.meta.get("runner"):    # the data-gen runner's plant: the composer's provider names and construction-fixed log values
+        from nuclear_sim_amd import scenarios
+        env.log_naming = "composed"
+        env.log_side_columns = scenarios.log_side_columns(g.meta["runner"]["action"], [0], randomize=False)
+    return env
 
 
 def _host_state(env):
@@ -1212,16 +1217,18 @@ def test_state_log_diagnostics_match_the_references_log():
             assert ok.all(), (name, int(np.argmin(ok)), mine[~ok, lane][:3], want[~ok][:3])
 
 
-@pytest.mark.parametrize("fixture", ["m1_oil_top_off_staggered", "e1_eventful_log"])
+@pytest.mark.parametrize("fixture", ["m1_oil_top_off_staggered", "e1_eventful_log", "l1_reactor_log", "l2_feedwater_events_log", "l3_turbine_sg_events_log"])
 def test_state_log_reproduces_the_references_log_column_by_column(fixture):
     """SURVEY 8f-3 as a whole: the state log with diagnostics on, sampled every step, against the reference's OWN log
-    (sim.state_manager.data) of two runs -- the quiet m1 run and the eventful e1 run (pump trip on low oil, NPSH collapse, load
-    and cooling-water swings, worn components, a fouled steam generator, a hot turbine bearing) -- under the reference's column
-    names: state members (several columns per member, the idle spare pump by analogy), functions of end-of-step state, keys of
-    the step's secondary result, step counters, step-internal diagnostics from the diagnostics build (turbine stages, steam
-    generators, pump health and maintenance flags, the steam-generator conditions the feedwater system was given, bearing oil
-    temperatures, the turbine's performance factor, the protection system's alarm count), the one column that is a window over
-    another column's history, and the columns that never move in either log, with their value.  All 784 columns at every step."""
+    (sim.state_manager.data) of five runs -- the quiet m1 run; the eventful e1 run (pump trip on low oil, NPSH collapse, load
+    and cooling-water swings, worn components, a fouled steam generator, a hot turbine bearing); and the three runs of round 4 that
+    move what those leave at rest: l1, a ReactorHeatSource plant under rod / boron / flow / valve actions into a scram (default
+    configuration: the reference's other provider naming); l2, four kinds of maintenance on four pumps, the pH controller out of
+    ammonia, an NPSH collapse, then every pump tripped on SG level; l3, TSP deposits into the fouling model's shutdown, a rotor
+    overspeed excursion, a vibration trip, the ejectors' rotation -- under the reference's column names: state members,
+    functions of end-of-step state, keys of the step's secondary result, step counters, the step's own outputs, step-internal
+    diagnostics from the diagnostics build, windows over logged history, and the 86 columns the reference itself never moves.
+    All 784 columns at every step."""
     import os
     from golden_util import GOLDEN_DIR
     from nuclear_sim_amd import statelog
