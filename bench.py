@@ -109,6 +109,30 @@ def measured_traffic(n):
     return best
 
 
+def measured_traffic_split(n):
+    """(read bytes, write bytes) per launch from the same committed PMC passes (calibrated FETCH_SIZE, WRITE_SIZE), or None"""
+    src = measured_traffic(n)[1]
+    if not src:
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, src)))
+        return float(d["FETCH_SIZE"]["step_bytes_calibrated"]), float(d["WRITE_SIZE"]["step_bytes_calibrated"])
+    except Exception:
+        return None
+
+
+def algorithmic_read_write_bytes(env, bytes_per_plant):
+    """the algorithmic bytes of one plant-step by direction: a carried member is read and written once each (8 B + 8 B; 4 + 4 for an
+    int32 member), an output member only written (4 B), the per-step inputs only read, obs / reward / done / flags / info only written.
+    The handle reports the sum (npb_handle_step_bytes_per_plant); the write-only part is the schema's."""
+    from nuclear_sim_amd.schema import SCHEMA
+    info_dim = 17
+    write_only = 4 * SCHEMA.n_outputs_step() + 22 * 8 + 8 + 1 + 4 + info_dim * 8
+    read_only = 16                                   # power setpoint + noise (the other inputs are passed as NULL)
+    both = bytes_per_plant - write_only - read_only  # state read + written
+    return both // 2 + read_only, both // 2 + write_only
+
+
 def c3_noise(lo, n, total):
     """BASELINE config 3's heat-source noise exactly as specified: plant i draws from
     np.random.RandomState(42 + i) -- the reference's own generator (constant_heat_source.py:58-62,178), seeded by
@@ -183,10 +207,41 @@ def main():
                     help="also run the automatic oil_top_off maintenance kernel after every step (not the headline workload)")
     ap.add_argument("--storage", choices=["f64", "f32"], default="f64",
                     help="element type of the carried state in HBM (f32 = BASELINE config 5; the headline is f64)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no stepping, no GPU: the ranks rendezvous (NPB_BENCH_BACKEND, e.g. gloo), all-reduce one number and rank 0 prints "
+                         "{n_gpus, launch_check: true} -- a test of the launcher path on a box without GPUs, not a measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Run plainly as `python bench.py --gpus N`: nobody has set up the ranks.  Start them here -- N fresh worker processes
+        # through torch's own launcher, one per GPU, each re-entering this file with RANK / LOCAL_RANK / WORLD_SIZE set -- BEFORE
+        # anything in this process touches the GPU (no torch.cuda call, no HIP call: the parent stays a plain launcher, it is never
+        # re-exec'ed), relay their output (rank 0 prints the JSON line) and exit with the launcher's code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import torch.distributed as dist
+
+    if args.launch_check:
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(os.environ.get("NPB_BENCH_BACKEND", "gloo"))
+            one = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(one)
+            assert int(one.item()) == world
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "requested_gpus": args.gpus}), flush=True)
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -334,6 +389,9 @@ def main():
         bytes_per_plant = env.handle_step_bytes_per_plant() - null_input_bytes
         achieved = bytes_per_plant * n / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(n) if args.storage == "f64" else (None, None)
+        traffic_rw = measured_traffic_split(n) if args.storage == "f64" else None
+        # reads: carried members + int32 members + the inputs passed; writes: the same state + the outputs (floats) + obs / reward / done / flags / info
+        algorithmic_rw = algorithmic_read_write_bytes(env, bytes_per_plant)
         out = {
             "metric": "plant-env-steps/s", "value": n_global * K / elapsed, "unit": "plant-env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
@@ -351,11 +409,15 @@ def main():
                                             "not measured by this run" % traffic_src) if traffic_src else None,
                          "frac_of_peak_by_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "algorithmic_bytes_per_launch": bytes_per_plant * n,
-                         "bytes_not_moved": "the algorithmic figure counts every carried column as read + written; the kernel "
-                                            "skips the store of a column whose bits did not change for any plant of a wave "
-                                            "(measured writes ~200 MB vs 268 MB algorithmic at 65 536 plants, profiles/), and part "
-                                            "of the reads is served by the 256 MB Infinity Cache; NULL inputs (20 B/plant) are "
-                                            "already excluded",
+                         "read_bytes": traffic_rw[0] if traffic_rw else None, "write_bytes": traffic_rw[1] if traffic_rw else None,
+                         "algorithmic_read_bytes": algorithmic_rw[0] * n, "algorithmic_write_bytes": algorithmic_rw[1] * n,
+                         "bytes_not_moved": "the algorithmic figure counts every carried column as read + written; WRITES come out below "
+                                            "it because the kernel skips the store of a column whose bits did not change for any plant of "
+                                            "a wave (unchanged-column elision); READS come out ABOVE it (FETCH_SIZE counts what the L2 "
+                                            "fetches, Infinity-Cache hits included: the cache does not hide reads from this counter): "
+                                            "the narrow columns that mix output and int32 members are fetched whole, the turbine's "
+                                            "lubrication pre-step re-reads part of the turbine section on another wave, every wave reads "
+                                            "the plant's clock; NULL inputs (20 B/plant) are already excluded",
                          "kernel": launched_kernel + (" (the build with the automatic maintenance inside: threshold screen in the pump phase, rule by function call for flagged waves)" if args.maintenance else ""),
                          "kernel_ms": kernel_ms},
             "preconditioning": {"ms": precondition_ms, "what": "a scratch handle of the same size stepped on the same inputs before the %d warm-up "

@@ -225,6 +225,12 @@ NPB_API int npb_gather_fields(NpbHandle *h, int n_fields, const int *kinds, cons
  * of 262 144 plants 10 %.) */
 NPB_API int npb_state_arena(NpbHandle *h, void **arena, size_t *pitch, int *storage);
 NPB_API size_t npb_state_arena_segment(const NpbHandle *h);
+/* The same with the whole layout in one answer: *segment = plants per segment (0 = one block), *columns = arena columns of the
+ * handle's storage type.  npb_state_arena itself REFUSES to hand out the pointer of a segmented arena (NPB_EINVAL, npb_last_error
+ * says why): a caller written before segments existed would compute arena + (column * pitch + plant) * width and touch the wrong
+ * plants without any error.  A raw-arena dump is a checkpoint only together with (pitch, segment, columns, storage): record them.
+ * Asking for the layout alone (arena = NULL) does not invalidate the maintenance cooldown cache; asking for the pointer does. */
+NPB_API int npb_state_arena_layout(NpbHandle *h, void **arena, size_t *pitch, size_t *segment, int *columns, int *storage);
 /* (With params.maint_enabled the step kernels consult a cache of which maintenance thresholds are inside their cooldown; every
  * entry point that can change state, the table or the clock invalidates it, this one included.  A caller that keeps the pointer
  * and writes the arena between later steps calls npb_state_arena again after each such write.) */

@@ -188,6 +188,8 @@ def load():
     L.npb_get_field.argtypes = [vp, ci, ci, vp, ci, vp]
     L.npb_set_field.argtypes = [vp, ci, ci, vp, ci, vp]
     L.npb_state_arena.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ci)]
+    if hasattr(L, "npb_state_arena_layout"):     # ABI 142
+        L.npb_state_arena_layout.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     if hasattr(L, "npb_state_arena_segment"):    # ABI 141
         L.npb_state_arena_segment.argtypes = [vp]
         L.npb_state_arena_segment.restype = ctypes.c_size_t

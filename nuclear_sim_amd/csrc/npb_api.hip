@@ -395,9 +395,22 @@ int npb_gather_fields(NpbHandle *h, int n_fields, const int *kinds, const int *s
 
 int npb_state_arena(NpbHandle *h, void **arena, size_t *pitch, int *storage) {
   if (!h) return NPB_EINVAL;
-  h->maint_cache_stale = true;      /* the caller may write the arena through this pointer (before the next step) */
-  if (arena) *arena = h->f64;
-  if (pitch) *pitch = h->seg ? h->seg : h->pitch;      /* a segmented arena: consecutive [columns][pitch] blocks of `pitch` plants each */
+  if (h->seg && arena) {      /* column * pitch + plant is NOT where a plant's element is on this arena: say so instead of handing out a pointer */
+    return fail(h, NPB_EINVAL, "npb_state_arena: this handle's arena is segmented (npb_state_arena_segment plants per segment): column * pitch + plant is "
+                               "not where a plant's element is; use npb_state_arena_layout, which reports the segment size with the pointer");
+  }
+  if (arena) { *arena = h->f64; h->maint_cache_stale = true; }      /* the caller may write the arena through this pointer (before the next step) */
+  if (pitch) *pitch = h->seg ? h->seg : h->pitch;
+  if (storage) *storage = h->storage;
+  return NPB_OK;
+}
+
+int npb_state_arena_layout(NpbHandle *h, void **arena, size_t *pitch, size_t *segment, int *columns, int *storage) {
+  if (!h) return NPB_EINVAL;
+  if (arena) { *arena = h->f64; h->maint_cache_stale = true; }      /* a query of the layout alone (arena = NULL) leaves the maintenance cache alone */
+  if (pitch) *pitch = h->seg ? h->seg : h->pitch;
+  if (segment) *segment = h->seg;
+  if (columns) *columns = h->storage == NPB_STORAGE_F32 ? (int)NPB_TOTAL_COL32 : (int)NPB_TOTAL_COL64;
   if (storage) *storage = h->storage;
   return NPB_OK;
 }
@@ -418,6 +431,8 @@ int npb_step(NpbHandle *h, const int32_t *action, const double *magnitude, const
              const double *noise_z, const double *cooling_water_temp, double *obs, double *reward, uint8_t *done,
              uint32_t *trip_flags, double *info, void *stream) {
   if (!h) return NPB_EINVAL;
+  if (h->params.heat_source == NPB_HEAT_EXTERNAL && !noise_z)      /* a NULL column would read as 0 MW thermal, silently */
+    return fail(h, NPB_EINVAL, "npb_step: params.heat_source is NPB_HEAT_EXTERNAL, whose thermal power arrives in the noise_z column (include/npb_params.h): it must not be NULL");
   NPB_USE_DEVICE(h);
   const bool narrow = h->storage == NPB_STORAGE_F32;
   npb_maint_table_t table;

@@ -79,31 +79,47 @@ class HeatSourceNoise:
         return out
 
 
-def equilibrium_state(power_level: float = 100.0, control_rod_position: float = 95.0) -> Dict[str, object]:
-    """create_equilibrium_state(auto_balance=True)  reactivity_model.py:443-529, as a field dict
-    for ``BatchedPlantEnv.set_fields``."""
+def equilibrium_state(power_level=100.0, control_rod_position=95.0) -> Dict[str, object]:
+    """create_equilibrium_state(power_level, control_rod_position, auto_balance=True)  reactivity_model.py:443-529, as a field
+    dict for ``BatchedPlantEnv.set_fields``.  Scalars, or arrays [n] for one state per plant (BASELINE config 2: power ~ U[60, 100] %,
+    rods ~ U[80, 100] % per plant): temperatures and precursors follow the asked power level, the boron concentration is the
+    critical one for the asked rod position at those temperatures (calculate_critical_boron_concentration :390-416 on
+    calculate_total_reactivity :77-125 with boron = 0) -- and the last two lines of the reference put flux and power level back to
+    exactly 100 % whatever was asked (:518-520), which is reproduced."""
+    p = np.asarray(power_level, dtype=np.float64); rods = np.asarray(control_rod_position, dtype=np.float64)
+    p, rods = np.broadcast_arrays(p, rods)
     beta = [0.000215, 0.001424, 0.001274, 0.002568, 0.000748, 0.000273]
     lam = [0.077, 0.311, 1.40, 3.87, 1.40, 0.195]
-    flux = 1e13 * (power_level / 100.0)
+    flux = 1e13 * (p / 100.0)
     prec = [(beta[i] / lam[i]) * (flux / 1e-5) for i in range(6)]
-    fuel_t = 575.0 + (power_level - 100.0) * 2.0
-    cool_t = 293.0 + (17.0 * (power_level / 100.0))
-    # total reactivity without boron (ReactivityModel.calculate_total_reactivity, boron = 0)
-    pos = min(max(control_rod_position / 100.0, 0.0), 1.0)
+    fuel_t = 575.0 + (p - 100.0) * 2.0
+    cool_t = 293.0 + (17.0 * (p / 100.0))
+    # total reactivity without boron (ReactivityModel.calculate_total_reactivity, boron = 0), the dict's ten terms in their order
+    pos = np.minimum(np.maximum(rods / 100.0, 0.0), 1.0)
     comps = [3000.0 * (pos - 0.5), -10.0 * 0.0, -2.5e-5 * (fuel_t - 575.0) * 1e5, -3.0e-5 * (cool_t - 280.0) * 1e5,
              -1000.0 * 0.0, 0.5 * (15.5 - 15.5), (1.0e15 / 1.0e15) * -1800.0, (5.0e14 / 5.0e14) * -600.0,
              3340.0 + -0.15 * 15000.0, 0.0 * float(np.exp(-0.0002 * 15000.0))]
     total = 0
     for c in comps:
         total = total + c
-    boron = max(0, (total - 0.0) / -10.0)
-    d = {"prim.neutron_flux": 1e13, "prim.power_level": 100.0, "prim.control_rod_position": control_rod_position,
-         "prim.xenon_concentration": 1.0e15, "prim.iodine_concentration": 1.5e16,
-         "prim.samarium_concentration": 5.0e14, "prim.fuel_temperature": fuel_t,
+    boron = np.maximum(0, (total - 0.0) / -10.0)
+    one = np.ones_like(p)
+    d = {"prim.neutron_flux": 1e13 * one, "prim.power_level": 100.0 * one, "prim.control_rod_position": rods * one,
+         "prim.xenon_concentration": 1.0e15 * one, "prim.iodine_concentration": 1.5e16 * one,
+         "prim.samarium_concentration": 5.0e14 * one, "prim.fuel_temperature": fuel_t,
          "prim.coolant_temperature": cool_t, "prim.boron_concentration": boron}
     for i in range(6):
         d[("prim.precursors", 0, i)] = prec[i]
+    if p.ndim == 0:
+        d = {k: float(v) for k, v in d.items()}
     return d
+
+
+def config2_draws(n: int):
+    """BASELINE config 2's per-plant (power level, rod position) draws: U[60, 100] % and U[80, 100] % from
+    numpy.random.default_rng(1234) -- one generator per quantity (1234, 1235), each indexed by plant, so that plant i's state does not
+    depend on how many plants the batch has"""
+    return np.random.default_rng(1234).uniform(60.0, 100.0, n), np.random.default_rng(1235).uniform(80.0, 100.0, n)
 
 
 class BatchedPlantEnv:
@@ -722,6 +738,30 @@ class NuclearPlantSimulator:
                 out[f.path[len("primary_physics.state."):]] = self._env.get_field("prim." + f.name)[0].item()
         return _Namespace(**out)
 
+    def _state_after_actuators(self, a: int, magnitude: float):
+        """``self.state`` with this step's actuator movement applied: PrimaryReactorPhysics._apply_control_actions
+        (primary/__init__.py:289-359; rates :174-176 and the 50 ppm/s of :333,341; which action moves what: sim.py:260-288) -- what a
+        HeatSource plugin is shown, since the reference moves the actuators before it updates the heat source."""
+        st = self.state
+        p, dt = self._env.params, self.dt
+        if a == ControlAction.CONTROL_ROD_INSERT.value:
+            st.control_rod_position = max(0, st.control_rod_position - p.max_control_rod_speed * dt * magnitude)
+        elif a == ControlAction.CONTROL_ROD_WITHDRAW.value:
+            st.control_rod_position = min(100, st.control_rod_position + p.max_control_rod_speed * dt * magnitude)
+        elif a == ControlAction.INCREASE_COOLANT_FLOW.value:
+            st.coolant_flow_rate = min(50000, st.coolant_flow_rate + p.max_flow_change_rate * dt * magnitude)
+        elif a == ControlAction.DECREASE_COOLANT_FLOW.value:
+            st.coolant_flow_rate = max(5000, st.coolant_flow_rate - p.max_flow_change_rate * dt * magnitude)
+        elif a == ControlAction.DILUTE_BORON.value:
+            st.boron_concentration = max(0, st.boron_concentration - 50.0 * dt * magnitude)
+        elif a == ControlAction.BORATE_COOLANT.value:
+            st.boron_concentration = min(3000, st.boron_concentration + 50.0 * dt * magnitude)
+        elif a == ControlAction.OPEN_STEAM_VALVE.value:
+            st.steam_valve_position = min(100, st.steam_valve_position + p.max_valve_speed * dt * magnitude)
+        elif a == ControlAction.CLOSE_STEAM_VALVE.value:
+            st.steam_valve_position = max(0, st.steam_valve_position - p.max_valve_speed * dt * magnitude)
+        return st
+
     def set_power_setpoint(self, power_percent: float) -> None:
         """heat_source.set_power_setpoint  constant_heat_source.py:93-102 (applied at the next step)."""
         if self._plugin is not None:
@@ -734,10 +774,16 @@ class NuclearPlantSimulator:
         a = ControlAction.NO_ACTION.value if action is None else (action.value if isinstance(action, ControlAction) else int(action))
         hs = self.primary_physics.heat_source
         if self._plugin is not None:
-            # primary/__init__.py:203-225: actuators first, then heat_source.update(dt, reactor_state, control_action); the plugin
-            # sees the state as it is before this step's actuator movement (its result is an input column of the launch)
-            res = self._plugin.update(dt=self.dt, reactor_state=self.state, control_action=ControlAction(a))
-            unsupported = [k for k in ("neutron_flux", "reactivity_pcm", "reactivity_components") if k in res and res[k] not in (None, {}, 0, 0.0)]
+            # primary/__init__.py:200-207: _apply_control_actions FIRST, then heat_source.update(dt, reactor_state, control_action) -- the
+            # plugin sees the rods, flow, boron and valve where this step's action has moved them.  The launch moves them too (its
+            # result is an input column of the launch), so the view handed to the plugin is moved here, on the host, by the same rule
+            res = self._plugin.update(dt=self.dt, reactor_state=self._state_after_actuators(a, float(magnitude)), control_action=ControlAction(a))
+
+            def given(v):           # a key the plugin filled in (None, an empty dict, a zero -- of any numeric type -- count as absent)
+                if v is None or (isinstance(v, dict) and not v):
+                    return False
+                return not (np.isscalar(v) and float(v) == 0.0) if not isinstance(v, dict) else True
+            unsupported = [k for k in ("neutron_flux", "reactivity_pcm", "reactivity_components") if k in res and given(res[k])]
             if unsupported:
                 raise NotImplementedError("a HeatSource plugin's result may carry thermal_power_mw and power_percent; %s are not supported" % unsupported)
             obs, rew, done, info = self._env.step(action=[a], magnitude=[magnitude], thermal_power_mw=[float(res["thermal_power_mw"])],

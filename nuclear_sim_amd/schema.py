@@ -123,6 +123,10 @@ class Schema:
         width = 8 if storage == "f64" else 4
         return sum(sec.count * sec.ncol(storage) for sec in self.sections) * width
 
+    def n_outputs_step(self) -> int:
+        """output members (written by the step, never read by it) of the sections the step kernels own"""
+        return sum(sec.count * sec.nout for sec in self.sections if sec.member not in ("mpump", "maint"))
+
     def is_output(self, name: str) -> bool:
         """True for an fp64 member that the step only writes (stored as float)."""
         sec, f = self.by_name[name]

@@ -181,6 +181,12 @@ def scenarios():
                   heat_script=lambda k: (3000.0 * (0.82 + 0.15 * float(np.sin(k / 17.0))), 100.0 * (0.80 + 0.17 * float(np.sin(k / 17.0 + 0.2)))),
                   actions=lambda t: (int(acts[t]), float(mags[t])) if t % 3 == 0 else None,
                   cooling=lambda t: 24.0 + 3.0 * float(np.cos(t / 25.0))))
+    # H2: the same interface with a plugin that READS the reactor state it is handed: its power follows the control-rod position,
+    # which the reference moves BEFORE it updates the heat source (primary/__init__.py:200-207) -- a facade that shows the plugin the
+    # state of the step before runs one step behind this fixture
+    S.append(dict(name="h2_heat_source_plugin_reads_state", steps=80, heat_source="external", every=2,
+                  heat_script=lambda k, st: (3000.0 * (0.5 + 0.005 * st.control_rod_position), 100.0 * (0.5 + 0.005 * st.control_rod_position) - 0.001 * st.steam_valve_position),
+                  actions=lambda t: (int([0, 1, 0, 0, 1, 4, 5, 8][t % 8]), float(mags[t]))))
     # C1-C5: branches no other fixture visits (tests/test_fixture_coverage.py lists what varies where)
     FP = "secondary_physics.feedwater_system.pump_system.pumps['FWP-%d']"
     SGP = "secondary_physics.steam_generator_system.steam_generators[%d].tsp_fouling.deposits.%s_thickness[%d]"
@@ -525,6 +531,28 @@ def make_c4_counts(seeds=tuple(range(64)), steps=48, procs=8):
     print("c4_counts: %d seeds x %d steps; executions per plant: %s" % (len(results), steps, np.bincount(perf.astype(int)).tolist()))
 
 
+def make_config2_equilibrium(n=8):
+    """tests/golden/ic_config2_equilibrium.npz -- BASELINE config 2's per-plant initial states held by the reference: SURVEY 8(d) C2
+    draws power ~ U[60, 100] % and rods ~ U[80, 100] % per plant from numpy.random.default_rng(1234) and starts each plant from
+    create_equilibrium_state(power, rods) (reactivity_model.py:443-529).  The first `n` plants' draws and every ReactorState member
+    the constructor returns for them; pins nuclear_sim_amd.env.equilibrium_state on arrays."""
+    from . import refsim
+    refsim.setup()
+    from systems.primary.reactor.reactivity_model import create_equilibrium_state
+    rng = np.random.default_rng(1234)
+    power = rng.uniform(60.0, 100.0, 4096)[:n]
+    rods = np.random.default_rng(1234 + 1).uniform(80.0, 100.0, 4096)[:n]
+    cols = [c for c in SCHEMA.columns() if c[2].startswith("prim.") and c[3].startswith("primary_physics.state.")]
+    rows = []
+    for p, r in zip(power, rods):
+        with refsim.quiet():
+            st = create_equilibrium_state(power_level=float(p), control_rod_position=float(r), auto_balance=True)
+        rows.append([float(eval("st." + c[3][len("primary_physics.state."):], {"st": st})) for c in cols])
+    np.savez_compressed(os.path.join(OUT, "ic_config2_equilibrium.npz"), power=power, rods=rods, state=np.array(rows),
+                        labels=np.array([c[2] for c in cols]), kinds=np.array([c[0] for c in cols]))
+    print("ic_config2_equilibrium: %d states, boron %s" % (n, np.array(rows)[:, [c[2] for c in cols].index("prim.boron_concentration")].round(1)))
+
+
 def make_maint_table():
     """tests/golden/maint_table.json: StateManager.maintenance_thresholds['FWP-1'] of the data-gen action-test simulator, in
     its dict order, with the state-log key each threshold name resolves to (None = never resolves, never fires), plus the
@@ -559,6 +587,8 @@ def make_maint_table():
 if __name__ == "__main__":
     if sys.argv[1:] == ["maint_table"]:
         make_maint_table()
+    elif sys.argv[1:] == ["config2_ic"]:
+        make_config2_equilibrium()
     elif sys.argv[1:] == ["ic_check"]:
         make_ic_check()
     elif sys.argv[1:] == ["c4_counts"]:

@@ -156,7 +156,8 @@ def scripted_heat_source(script, rated_power_mw=3000.0):
             self.power_setpoint_percent = power_percent
 
         def update(self, dt, **kwargs):
-            tp, pp = script(self.k)
+            # a script of two arguments is shown the reactor state the reference hands its heat source (primary/__init__.py:203-207)
+            tp, pp = script(self.k, kwargs["reactor_state"]) if script.__code__.co_argcount == 2 else script(self.k)
             self.k += 1
             self.current_power_mw = tp
             self.results.append((tp, pp))

@@ -265,6 +265,51 @@ def test_config2_reactor_and_sg_only_at_4096(oracle_lib, integrator):
             np.testing.assert_allclose(f[slot, :n], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)
 
 
+def test_config2_as_specified_per_plant_equilibria_2000_steps(oracle_lib):
+    """BASELINE config 2 as SURVEY 8(d) C2 writes it: 4 096 plants, ReactorHeatSource, primary + steam generators only, every
+    plant started from its own create_equilibrium_state(power ~ U[60, 100] %, rods ~ U[80, 100] %) (default_rng(1234);
+    equilibrium_state on arrays, pinned to the reference's constructor by tests/golden/ic_config2_equilibrium.npz), i.i.d. actions
+    over {0, 1, 2, 3, 8, 9, 10} with magnitude U[0, 1] (seed 1235), 2 000 steps of the reference's integrator at dt = 1.0 -- the
+    parity-gated mode.  The oracle steps 128 sampled plants through all 2 000 steps with the same per-plant inputs; observations,
+    done and flags compared every 50th step and at the end every state member."""
+    import torch
+    from nuclear_sim_amd.env import equilibrium_state, config2_draws
+    n, T = 4096, 2000
+    env = _env(n=n, dt=1.0, heat_source="reactor", mode="primary_sg")
+    power, rods = config2_draws(n)
+    ic = equilibrium_state(power, rods)
+    env.set_fields(ic)
+    rng = np.random.default_rng(77)
+    sample = np.unique(np.concatenate([[0, 63, 64, n - 1], rng.choice(n, 124, replace=False)]))
+    P = oracle_lib.Params(); P.dt = 1.0; P.heat_source = 1; P.mode = 1
+    ora = oracle_lib.OraclePlants(len(sample), P)
+    for key, v in ic.items():
+        name, inst, k = (key, 0, 0) if not isinstance(key, tuple) else (key[0], key[1], key[2] if len(key) > 2 else 0)
+        ora.set(name, np.asarray(v)[sample], instance=inst, k=k)
+    arng = np.random.default_rng(1235)
+    idx = torch.as_tensor(sample, device=env.device)
+    scrams = 0
+    for t in range(T):
+        acts = arng.choice([0, 1, 2, 3, 8, 9, 10], size=n).astype(np.int32); mags = arng.uniform(0, 1, n)
+        obs, rew, done, info = env.step(action=acts, magnitude=mags)
+        o_obs, o_rew, o_done, o_flags, _ = ora.step(action=acts[sample], magnitude=mags[sample])
+        scrams += int(o_done.sum())
+        if t % 50 == 0 or t == T - 1:
+            np.testing.assert_allclose(obs[idx].cpu().numpy(), o_obs, rtol=RTOL, atol=1e-12, err_msg="obs step %d" % t)
+            assert np.array_equal(done[idx].cpu().numpy(), o_done), t
+            assert np.array_equal(info["trip_flags"][idx].cpu().numpy().astype(np.uint32), o_flags), t
+    f, i = env.state_arrays()
+    f = f[:, idx].cpu().numpy(); i = i[:, idx].cpu().numpy()
+    of, oi = ora.state_all()
+    for kind, slot, label, _p in env_cols():
+        if kind == "i32":
+            assert np.array_equal(i[slot], oi[:, slot]), label
+        else:
+            np.testing.assert_allclose(f[slot], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)
+    flux = env.get_field("prim.neutron_flux").cpu().numpy()
+    assert np.ptp(flux) > 0 and np.isfinite(flux).all()
+
+
 def test_long_run_stays_on_the_oracle(oracle_lib):
     """1500 steps of one wave of heterogeneous plants: the last-bit differences of the device arithmetic
     (reciprocal multiplication, lean exp/log) must not grow past the parity budget."""
@@ -471,6 +516,25 @@ def test_heat_source_plugin_through_the_facade():
         np.testing.assert_allclose(r["observation"], g.obs[t], rtol=RTOL, atol=1e-12, err_msg="obs step %d" % t)
         np.testing.assert_allclose(r["reward"], g.reward[t], rtol=RTOL, atol=1e-9)
         assert r["info"]["reactivity"] == 0.0 and r["info"]["reactivity_components"] == {}      # primary/__init__.py:218-225
+    # fixture h2: a plugin that READS the state it is handed -- its power follows the rod position, which the reference moves before
+    # it updates the heat source (primary/__init__.py:200-207); numpy scalars in the result's optional keys are "absent" too
+    g2 = Golden("h2_heat_source_plugin_reads_state")
+
+    class FollowsRods(HeatSource):
+        def __init__(self):
+            super().__init__(3000.0)
+
+        def update(self, dt, **kwargs):
+            st = kwargs["reactor_state"]
+            return {"thermal_power_mw": 3000.0 * (0.5 + 0.005 * st.control_rod_position),
+                    "power_percent": 100.0 * (0.5 + 0.005 * st.control_rod_position) - 0.001 * st.steam_valve_position,
+                    "reactivity_pcm": np.float64(0.0), "reactivity_components": {}}
+
+    sim2 = NuclearPlantSimulator(dt=1.0, heat_source=FollowsRods(), secondary_config={"secondary_system": {}}, enable_state_management=False)
+    for t in range(g2.T):
+        r = sim2.step(action=ControlAction(int(g2.action[t])), magnitude=float(g2.magnitude[t]))
+        np.testing.assert_allclose(r["observation"], g2.obs[t], rtol=RTOL, atol=1e-12, err_msg="h2 obs step %d" % t)
+        np.testing.assert_allclose(r["info"]["thermal_power"], g2.noise_z[t], rtol=1e-12)      # what the reference's plugin returned at this step
     with pytest.raises(TypeError):
         NuclearPlantSimulator(heat_source=object())
     with pytest.raises(ValueError):
@@ -1289,6 +1353,13 @@ def test_segmented_arena_is_only_a_layout(variant, monkeypatch):
             monkeypatch.setenv("NPB_ARENA_SEGMENT", segment)
         env = _env(n=n, dt=5.0, noise_enabled=True, maintenance=True)
         assert int(env.L.npb_state_arena_segment(env._h)) == (16384 if segment is None else 0)
+        # the raw-arena entry points: a segmented arena's pointer is only handed out together with its segment size
+        import ctypes
+        ptr = ctypes.c_void_p(); pitch = ctypes.c_size_t(); seg = ctypes.c_size_t(); ncol = ctypes.c_int(); stor = ctypes.c_int()
+        rc_old = env.L.npb_state_arena(env._h, ctypes.byref(ptr), ctypes.byref(pitch), ctypes.byref(stor))
+        assert (rc_old != 0) == (segment is None), "npb_state_arena refuses a segmented arena"
+        assert env.L.npb_state_arena_layout(env._h, ctypes.byref(ptr), ctypes.byref(pitch), ctypes.byref(seg), ctypes.byref(ncol), ctypes.byref(stor)) == 0
+        assert ptr.value and int(seg.value) == (16384 if segment is None else 0) and int(pitch.value) == (16384 if segment is None else (n + 63) // 64 * 64) and ncol.value == 796
         env.set_step_kernel(variant)
         r = np.random.default_rng(3)
         for k in range(4):

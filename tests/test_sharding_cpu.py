@@ -151,3 +151,24 @@ def test_config4_histogram_does_not_depend_on_the_world_size():
             assert p.exitcode == 0
     assert np.array_equal(hists[1], hists[2])
     assert hists[1].sum() == n_global and hists[1][0] > 0 and hists[1][1:].sum() > 0
+
+
+def test_bench_starts_its_own_ranks_when_nobody_has():
+    """`python bench.py --gpus 2` run plainly (no WORLD_SIZE in the environment, no outside launcher): the parent must start the
+    two worker processes itself, before it touches any GPU, and relay rank 0's line with n_gpus = 2.  Here without a GPU, so with
+    --launch-check (rendezvous + one all-reduce over gloo, no stepping); the real path with two ranks sharing one device is
+    rehearsed on the GPU box by tools/bench_rehearsal.sh."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NPB_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["launch_check"] is True
+    text = open(os.path.join(root, "bench.py")).read()
+    launch = text.index('if args.gpus > 1 and "WORLD_SIZE" not in os.environ')
+    assert "import torch" not in text[text.index("def main():"):launch], "main() starts the ranks before it imports torch: the parent never touches the GPU"

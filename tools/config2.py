@@ -5,11 +5,11 @@ and 65 536.  python3 tools/config2.py"""
 import sys, time, torch, numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nuclear_sim_amd.env import BatchedPlantEnv, equilibrium_state
+from nuclear_sim_amd.env import BatchedPlantEnv, equilibrium_state, config2_draws
 for integ in ("reference", "rk4"):
     for n in (4096, 65536):
         env = BatchedPlantEnv(n, dt=0.1, heat_source="reactor", mode="primary_sg", integrator=integ)
-        env.set_fields(equilibrium_state())
+        env.set_fields(equilibrium_state(*config2_draws(n)))      # one equilibrium state per plant
         a = torch.randint(0, 4, (n,), dtype=torch.int32, device=env.device); m = torch.rand(n, dtype=torch.float64, device=env.device)
         for _ in range(20): env.step(action=a, magnitude=m)
         torch.cuda.synchronize(); t = time.perf_counter(); K = 300

@@ -24,8 +24,8 @@ def burst(env, K=300):
 import ctypes
 for rnd in range(2):
     for i, env in enumerate(envs):
-        real = ctypes.c_void_p(); pitch = ctypes.c_size_t(); stor = ctypes.c_int()
-        env.L.npb_state_arena(env._h, ctypes.byref(real), ctypes.byref(pitch), ctypes.byref(stor))
+        real = ctypes.c_void_p(); pitch = ctypes.c_size_t(); seg = ctypes.c_size_t(); ncol = ctypes.c_int(); stor = ctypes.c_int()
+        env.L.npb_state_arena_layout(env._h, ctypes.byref(real), ctypes.byref(pitch), ctypes.byref(seg), ctypes.byref(ncol), ctypes.byref(stor))
         mn, md = burst(env)
         # the calibration kernel (reads and rewrites every column in the step's access shape) on the same arena
         from nuclear_sim_amd import _lib
