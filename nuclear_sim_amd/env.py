@@ -127,6 +127,10 @@ class BatchedPlantEnv:
 
     step() returns ``(obs[N,22], reward[N], done[N], info)`` where ``info`` holds column tensors
     (``electrical_power``, ``trip_flags``, ...) instead of one dict per plant.
+
+    Every tensor step() hands out -- obs, reward, done and each column of info, ``info["maintenance_event_count"]`` included (the
+    column the step kernels keep current, npb_set_maintenance_count_buffer) -- is one of the env's own device buffers, written again
+    by the next step: ``clone()`` what is to be kept (a list that appends them step after step holds N aliases of the latest values).
     """
 
     action_space_size = 15       # NuclearPlantEnv sim.py:916

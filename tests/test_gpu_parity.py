@@ -307,7 +307,7 @@ def test_config2_as_specified_per_plant_equilibria_2000_steps(oracle_lib):
         else:
             np.testing.assert_allclose(f[slot], of[:, slot], rtol=RTOL, atol=ATOL_SMALL, err_msg=label)
     flux = env.get_field("prim.neutron_flux").cpu().numpy()
-    assert np.ptp(flux) > 0 and np.isfinite(flux).all()
+    assert np.isfinite(flux).all() and (flux >= 1e8).all() and (flux <= 1e14).all()      # (after 2 000 steps of random actions every plant sits on a clip: the parity is in the comparisons above)
 
 
 def test_long_run_stays_on_the_oracle(oracle_lib):
