@@ -297,6 +297,77 @@ def scenarios():
     S.append(dict(name="r5_reset_power_levels", steps=75, noise=True, noise_seed=42, every=1,
                   setpoints=lambda t: {0: 100.0, 12: 80.0, 26: 60.0, 40: 30.0, 54: 4.0, 66: 110.0}.get(t),
                   resets={10: True, 24: True, 38: True, 52: True, 64: True, 72: True}))
+    # C12-C15 (round 4, second pass): what the differential fuzz of tools/mutant_fuzz.py could still tell from the restatement after C8-C11
+    # -- values INSIDE the 0.1 % sliver a threshold's mutant opens (computed from the live simulator where they depend on its state),
+    # clips approached from outside, branches that need several components in a corner at once
+    def boron_for(total_pcm):
+        """the boron concentration that puts the reference's own total reactivity at total_pcm for the state as it is (-10 pcm / ppm, reactivity_model.py:144-160)"""
+        def f(sim):
+            st = sim.primary_physics.state
+            return st.boron_concentration + (sim.primary_physics.heat_source.reactivity_model.calculate_total_reactivity(st)[0] - total_pcm) / 10.0
+        return f
+    BORON = PS + "boron_concentration"
+    relatch = [(PS + "scram_status", False), (PS + "control_rod_position", 95.0), (PS + "neutron_flux", 1e13), (PS + "fuel_temperature", 600.0),
+               (PS + "coolant_temperature", 300.0), (PS + "coolant_pressure", 15.5)]
+    # C12: the reactor model's thresholds from inside their slivers: |rho| = 1000.5 pcm either side (point_kinetics.py's 0.01 band), fuel temperature,
+    # pressure and power a hair past their scram limits (scram_logic.py:24-61: 1200 C, 17.2 MPa, 118 %), each in its own life of the latch; fuel and
+    # coolant below their lower clips; a core flow past the heat-transfer coefficient's upper clip; steam flow past 3000 kg/s; 350 % power (the steam
+    # generators' tube velocity past both fouling models' velocity clips); a flux above the 1e14 ceiling
+    S.append(dict(name="c12_primary_thresholds", steps=40, heat_source="reactor", equilibrium=(100.0, 95.0), every=1,
+                  # (the step's own fission-product update moves the total by -0.69 pcm after the poke: the two band pokes aim 0.69 pcm high)
+                  pokes={2: [(BORON, boron_for(1001.19))], 3: [(BORON, boron_for(0.0))], 5: [(BORON, boron_for(-999.81))], 6: relatch + [(BORON, boron_for(0.0))],
+                         # (a poked temperature moves the Doppler / moderator terms: the boron poke AFTER it in the same list cancels that, so the flux rests,
+                         #  the power stays within 5 % of 100 and the temperature rates keep their narrow clips)
+                         8: [(PS + "fuel_temperature", 1201.5), (BORON, boron_for(0.0))],
+                         10: relatch + [(BORON, boron_for(0.0))], 12: [(PS + "coolant_pressure", 17.225)],
+                         14: relatch + [(BORON, boron_for(0.0))], 16: [(PS + "neutron_flux", 1.1805e13), (BORON, boron_for(0.0))],
+                         18: relatch + [(BORON, boron_for(0.0))], 20: [(PS + "fuel_temperature", 185.0), (PS + "coolant_temperature", 190.0), (BORON, boron_for(0.0))],
+                         22: relatch + [(BORON, boron_for(0.0))], 24: [(PS + "coolant_flow_rate", 130000.0)], 26: [(PS + "coolant_flow_rate", 20000.0)],
+                         28: [(PS + "steam_flow_rate", 3005.0)], 30: [(PS + "neutron_flux", 3.5e13)], 34: [(PS + "neutron_flux", 2e14)],
+                         36: [(PS + "fuel_temperature", 2050.0)]}))
+    # C13: a plant whose FIRST step is below 10 % power: the hot leg's floor in sim.py:389-391 shows only before the first heat-removal factor exists
+    S.append(dict(name="c13_first_step_low_power", steps=6, noise=True, noise_seed=3, every=1, setpoints=lambda t: 6.0 if t == 0 else None))
+    # C14: turbine and condenser -- every stage under 2 mm of deposits (almost no expansion: superheated exhaust, the quality handed to the
+    # condenser clipped at 1, so the latent heat no longer cancels out of the condenser's heat balance), dissolved solids past the nutrient cap,
+    # a condenser pressure outside the ejectors' suction band, a diffuser at its fouling floor, air in-leak past its cap, 99 % of the tubes plugged
+    STG = "=list(root.secondary_physics.turbine.stage_system.stages.values())[%d]."
+    EJ = "=list(root.secondary_physics.condenser.vacuum_system.ejectors.values())[%d]."
+    def stage_deposits(mm):
+        """deposits on every stage, with the two factors a stage derives from them at the end of its update and reads at the start of the next
+        (stage_system.py:313, 321): poked alone, the deposits would act one step late in the reference"""
+        f = 1.0 / (1.0 + mm / 0.5)
+        return [(STG % k + "deposit_thickness", mm) for k in range(14)] + [("~" + STG % k + "fouling_factor", f) for k in range(14)] \
+            + [("~" + STG % k + "blade_condition_factor", f) for k in range(14)]
+    S.append(dict(name="c14_turbine_condenser_corners", steps=40, noise=True, noise_seed=9, every=1,
+                  setpoints=lambda t: 100.0 if t < 24 else 35.0,
+                  pokes={3: stage_deposits(2.0),
+                         8: [(CH1 + "total_dissolved_solids", 1200.0), (EJ % 0 + "diffuser_fouling_factor", 0.6000002), (EJ % 0 + "nozzle_fouling_factor", 0.5000001),
+                             (EJ % 0 + "nozzle_erosion_factor", 0.70000001)],
+                         12: [(CD + "vacuum_system.condenser_pressure", 0.02)], 14: [(CD + "vacuum_system.condenser_pressure", 0.002)],
+                         16: [(CD + "vacuum_system.current_air_leakage", 0.16)],
+                         20: [(CD + "tube_degradation.plugged_tube_count", 83500.0), (CD + "tube_degradation.active_tube_count", 500.0)],
+                         30: stage_deposits(0.1)}))
+    # C15: steam generators -- levels a hair inside the level factor's two thresholds (12.5 m, 8 m), every feedwater pump stopped under steam demand
+    # (inventory depletion), a secondary pressure above the primary side's temperatures at low power (negative heat transfer), and the TSP
+    # shutdown criteria one at a time: uneven deposits (maldistribution alone), a 41-year-old plate 52 % blocked (age alone)
+    def tsp_level_thickness(fraction):
+        """deposit thickness [mm] that blocks `fraction` of a 23-mm hole's area (tsp_fouling_model.py:302-340)"""
+        return 23.0 * (1.0 - (1.0 - fraction) ** 0.5) / 2.0
+    S.append(dict(name="c15_sg_corners", steps=64, noise=True, noise_seed=9, every=1,
+                  setpoints=lambda t: 100.0 if t < 13 else (30.0 if t < 20 else (100.0 if t < 30 else (3.0 if t < 45 else (115.0 if t < 54 else 100.0)))),
+                  pokes={3: [(SG_ % 0 + "water_level", 12.505), (SG_ % 1 + "water_level", 8.004), (SG_ % 2 + "water_level", 12.52),
+                             # (2.5 mm of scale: the generator is limited by its own surface, not by what the primary side brings, so the level factor shows)
+                             (SG_ % 0 + "tube_interior_fouling.scale_thickness", 2.5), (SG_ % 0 + "tube_interior_fouling.scale_composition['crud_deposits']", 1.0),
+                             (SG_ % 2 + "tube_interior_fouling.scale_thickness", 2.5), (SG_ % 2 + "tube_interior_fouling.scale_composition['crud_deposits']", 1.0)],
+                         6: [(SG_ % 0 + "water_level", 8.01)],
+                         10: [(FP % j + ".state.status", "=PumpStatus.STOPPED") for j in (1, 2, 3, 4)] + [(FP % j + ".state.speed_percent", 0.0) for j in (1, 2, 3, 4)]
+                             + [(FP % j + ".state.flow_rate", 0.0) for j in (1, 2, 3, 4)],
+                         20: [(SGP % (0, "magnetite", k), tsp_level_thickness(0.45)) for k in range(3)]                        # maldistribution: three plates 45 % blocked, four clean
+                             + [(SGP % (1, "magnetite", k), tsp_level_thickness(0.52)) for k in range(7)] + [(SG_ % 1 + "tsp_fouling.operating_years", 40.02)]
+                             + [(SGP % (2, "magnetite", k), tsp_level_thickness(0.52)) for k in range(7)] + [(SG_ % 2 + "tsp_fouling.operating_years", 39.99)],
+                         # (this saturation fit gives 262 C at the 8-MPa clip, below any cold leg: only a pressure no step can leave behind puts it above the hot leg)
+                         36: [(SG_ % 0 + "secondary_pressure", 18.0)],
+                         58: [(SGP % (2, "magnetite", k), tsp_level_thickness(0.58)) for k in range(7)]}))                      # pressure-drop ratio 5.7 alone
     # R1-R3: NuclearPlantSimulator.reset() (sim.py:546-581) in the middle of a run -- the reference's reset is not a
     # re-construction (parts of the history survive, start_at_steady_state force-sets the secondary side and advances the
     # steam generators once), so the state it leaves and the trajectory after it are pinned here
@@ -466,7 +537,7 @@ def main(only=None):
         meta["init_pokes"] = [[p, trace.poke_number(v)] for p, v in sc.get("init_pokes", [])]
         # pokes expressed in schema labels so tests can replay them without the reference
         path_to_label = {c[3]: (c[0], c[1], c[2]) for c in cols}
-        meta["pokes_schema"] = {str(k): [[p, trace.poke_number(v)] for p, v in lst] for k, lst in sc.get("pokes", {}).items()}
+        meta["pokes_schema"] = {str(k): [[p, trace.poke_number(v)] for p, v in lst if not p.startswith("~")] for k, lst in sc.get("pokes", {}).items()}
         np.savez_compressed(os.path.join(OUT, sc["name"] + ".npz"),
                             action=ref["action"], magnitude=ref["magnitude"], setpoint=ref["setpoint"],
                             cooling=ref["cooling"], noise_z=ref["noise_z"], obs=ref["obs"], reward=ref["reward"],

@@ -11,7 +11,8 @@ Scenario dict keys:
   actions: {step: (action_id, magnitude)} or callable(step)->(action, magnitude),
   setpoints: callable(step)->percent or None,
   cooling: callable(step)->degC or None,
-  pokes: {step: [(python_path, value), ...]} applied to the sim before that step.
+  pokes: {step: [(python_path, value), ...]} applied to the sim before that step; value may be callable(sim) -> number; a path written
+         "~path" is applied to the reference only (a cached copy of a poked member that no schema column holds) and not recorded for replay.
   resets: {step: start_at_steady_state} -> sim.reset(start_at_steady_state) is called before that step (after the
           step's pokes); the observation it returns and the state it leaves are recorded (reset_obs / reset_state).
   runner: {"action": name, "duration_hours": h, "feedwater_ic": {...}} -> build the simulator the
@@ -131,8 +132,12 @@ def run_reference(sc, columns):
     resets = sc.get("resets", {})
     reset_steps, reset_modes, reset_obs, reset_state = [], [], [], []
     for t in range(T):
-        for path, v in sc.get("pokes", {}).get(t, []):
-            _poke(sim, path, poke_value(v))
+        lst = sc.get("pokes", {}).get(t, [])
+        for j, (path, v) in enumerate(lst):
+            if callable(v):          # a value computed from the live simulator (e.g. the boron that puts the reactivity on a threshold):
+                v = float(v(sim))    # resolved here and written back, so the fixture records the number that was poked
+                lst[j] = (path, v)
+            _poke(sim, path.lstrip("~"), poke_value(v))     # "~path": a derived copy the reference caches (not a schema member), kept consistent with the poke beside it
         if t in resets:
             with refsim.quiet():
                 ob = sim.reset(start_at_steady_state=bool(resets[t]))

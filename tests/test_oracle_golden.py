@@ -117,3 +117,15 @@ def test_known_answers_from_reference_tests(oracle_lib):
     obs, rew, done, flags, info = o2.step()
     assert done[0] == 0  # one-shot: True only on the firing step
 
+
+
+def test_external_heat_source_without_a_power_percent_column(oracle_lib):
+    """NPB_HEAT_EXTERNAL with a NaN set-point column (include/npb.h: the caller gave no power_percent): the percent is the thermal
+    power over the rated power.  A convenience of the boundary with no reference counterpart -- a reference plugin's update() always
+    carries 'power_percent' (primary/__init__.py:211) -- so this is the only place that holds it."""
+    P = oracle_lib.Params(); P.heat_source = 2
+    o = oracle_lib.OraclePlants(1, P)
+    o.step(noise_z=np.array([1234.5]), setpoint=np.array([np.nan]))
+    assert o.get("prim.power_level") == 1234.5 / P.rated_power_mw * 100.0
+    o.step(noise_z=np.array([1234.5]), setpoint=np.array([77.0]))
+    assert o.get("prim.power_level") == 77.0

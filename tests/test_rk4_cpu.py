@@ -150,3 +150,16 @@ def test_zero_substeps_is_the_reference_update(oracle_lib):
     assert a.get("prim.neutron_flux") == b.get("prim.neutron_flux")
     c = _plant(oracle_lib, 30, 1.0); c.step()                       # (dt = 1 s with 30 sub-steps is past RK4's stability bound: not asserted on)
     assert np.isfinite(a.get("prim.neutron_flux"))
+
+
+def test_the_flux_floor_and_the_power_it_reports(oracle_lib):
+    """a scrammed plant left alone decays to the reference's flux floor (1e8, point_kinetics.py:100) and stays ON it; the power the
+    step reports is that flux over 1e13, in percent and in MW (reactor_heat_source.py:95-99)"""
+    o = _plant(oracle_lib, 50, 5.0, rods=95.0)
+    o.step()
+    o.set("prim.scram_status", 1)
+    for _ in range(400):
+        _obs, _rew, _done, _flags, info = o.step()
+    assert o.get("prim.neutron_flux") == 1e8
+    assert o.get("prim.power_level") == 1e8 / 1e13 * 100.0
+    assert info[0, 0] == (1e8 / 1e13) * o.params.rated_power_mw

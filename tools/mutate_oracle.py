@@ -105,7 +105,7 @@ def run_mutant(job):
         cc = subprocess.run(["gcc", "-O2", "-fPIC", "-std=gnu11", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden", "-fopenmp", "-w",
                              "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), "-shared", "-o", so, os.path.join(work, "npo_api.c"), "-lm"],
                             capture_output=True, text=True, cwd=work)
-        rec = {"file": fname, "line": ln + 1, "op": kind, "was": before[col:col + length], "now": rep, "text": before.strip()[:140]}
+        rec = {"file": fname, "line": ln + 1, "col": col, "op": kind, "was": before[col:col + length], "now": rep, "text": before.strip()[:140]}
         if cc.returncode != 0:
             rec["result"] = "stillborn"
             return rec
@@ -127,6 +127,41 @@ def run_mutant(job):
         shutil.rmtree(work, ignore_errors=True)
 
 
+
+EQUALITY = {("<", "<="), ("<=", "<"), (">", ">="), (">=", ">")}
+
+
+def annotate(record):
+    """Give every survivor of the record a class and, where it has one, the guard that keeps it from showing (tools/mutation_guards.py)."""
+    import re
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from mutation_guards import GUARDS
+    surv = record["survivors"]
+    # a threshold's x 1.001 mutant counts as a sliver only if the comparison it belongs to is pinned from both sides: no dropped / forced
+    # branch and no reversed comparison of the same line survives
+    loose = {(r["file"], r["line"]) for r in surv if r["op"] == "branch" or (r["op"] == "cmp" and (r["was"], r["now"]) not in EQUALITY)}
+    counts = {}
+    for r in surv:
+        why = None
+        for g in GUARDS:
+            f, sub, ops, text = g[:4]
+            toks = g[4] if len(g) > 4 else None
+            if r["file"] == f and sub in r["text"] and (ops is None or r["op"] in ops) and (toks is None or r["was"] in toks):
+                why = ("guarded", text); break
+        if why is None and r["op"] == "cmp" and (r["was"], r["now"]) in EQUALITY:
+            why = ("equality", "differs only when the two operands are equal to the last bit")
+        if why is None and r["op"] == "const" and (r["file"], r["line"]) not in loose:
+            t = re.escape(r["was"])
+            if re.search(r"(<=|>=|<|>)\s*\(?\s*" + t + r"(?![\w.])", r["text"]) or re.search(r"(?<![\w.])" + t + r"\s*\)?\s*(<=|>=|<|>)", r["text"]):
+                why = ("sliver", "a threshold moved by 0.1 % while both of its sides are pinned (the dropped / forced branch and the reversed comparison of this line are killed): only a value inside the 0.1 % tells")
+        if why is None:
+            why = ("unexplained", "")
+        r["class"], r["guard"] = why
+        counts[why[0]] = counts.get(why[0], 0) + 1
+    record["survivor_classes"] = counts
+    return counts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--files", default=",".join(DEFAULT_FILES))
@@ -135,17 +170,32 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r4_mutation_score.json"))
     ap.add_argument("--retest-survivors", action="store_true",
                     help="run only the mutants the record at --out lists as survivors (after fixtures were added or tolerances tightened) and move the ones now killed")
+    ap.add_argument("--distinguishable-only", action="store_true",
+                    help="with --retest-survivors: only the survivors tools/mutant_fuzz.py could tell from the original (the others stay listed)")
+    ap.add_argument("--annotate", action="store_true", help="classify the survivors of the record at --out (equality / sliver / guarded / unexplained) and list the unexplained ones")
     args = ap.parse_args()
+    if args.annotate:
+        rec = json.load(open(args.out))
+        print(json.dumps(annotate(rec), indent=1))
+        json.dump(rec, open(args.out, "w"), indent=1)
+        for r in rec["survivors"]:
+            if r["class"] == "unexplained":
+                print("UNEXPLAINED %s:%d %s  %r -> %r   | %s   [%s]" % (r["file"], r["line"], r["op"], r["was"], r["now"], r["text"][:110], r.get("fuzz", "")[:40]))
+        return
     jobs = []
     rng = random.Random(4)
     if args.retest_survivors:
         old = json.load(open(args.out))
-        want = {(r["file"], r["line"], r["op"], r["was"], r["now"]) for r in old["survivors"]}
+        # (records written before the column was kept match by line and token: two sites on a line with the same token are then both run)
+        keep_listed = [r for r in old["survivors"] if args.distinguishable_only and not r.get("fuzz", "").startswith("distinguishable")]
+        fuzz_of = {(r["file"], r["line"], r["op"], r["was"], r["now"]): r.get("fuzz") for r in old["survivors"]}
+        want = {(r["file"], r["line"], r.get("col"), r["op"], r["was"], r["now"]) for r in old["survivors"] if r not in keep_listed}
+        had = {f: c for f, c in __import__("collections").Counter(r["file"] for r in old["survivors"]).items()}
         for fname in sorted({r["file"] for r in old["survivors"]}):
             lines = open(os.path.join(ORACLE, fname)).read().split("\n")
             for i, st in enumerate(sites(os.path.join(ORACLE, fname))):
                 ln, col, length, rep, kind = st
-                if (fname, ln + 1, kind, lines[ln][col:col + length], rep) in want:
+                if (fname, ln + 1, col, kind, lines[ln][col:col + length], rep) in want or (fname, ln + 1, None, kind, lines[ln][col:col + length], rep) in want:
                     jobs.append((fname, st, i))
         print("%d of %d recorded survivors found again in the present text" % (len(jobs), len(want)), flush=True)
         results = []
@@ -154,10 +204,13 @@ def main():
                 results.append(rec)
                 if (k + 1) % 25 == 0:
                     print("%d / %d   now killed %d" % (k + 1, len(jobs), sum(r["result"] == "killed" for r in results)), flush=True)
-        now_killed = [r for r in results if r["result"] == "killed"]
-        for r in now_killed:
-            old["by_file"][r["file"]]["killed"] += 1; old["by_file"][r["file"]]["survived"] -= 1
-        old["survivors"] = [r for r in results if r["result"] == "survived"]
+        for r in results:
+            if fuzz_of.get((r["file"], r["line"], r["op"], r["was"], r["now"])):
+                r["fuzz"] = fuzz_of[(r["file"], r["line"], r["op"], r["was"], r["now"])]
+        old["survivors"] = keep_listed + [r for r in results if r["result"] == "survived"]
+        left = __import__("collections").Counter(r["file"] for r in old["survivors"])
+        for f, c in had.items():   # a survivor can only stay one or be killed: count by what is left
+            old["by_file"][f]["killed"] += c - left.get(f, 0); old["by_file"][f]["survived"] = left.get(f, 0)
         tot = {k: sum(s_[k] for s_ in old["by_file"].values()) for k in ("killed", "survived", "stillborn")}
         old.update(checks=CHECKS, mutants=sum(tot.values()), viable=tot["killed"] + tot["survived"], killed=tot["killed"], score=tot["killed"] / max(1, tot["killed"] + tot["survived"]))
         json.dump(old, open(args.out, "w"), indent=1)
