@@ -322,7 +322,9 @@ def scenarios():
                          10: relatch + [(BORON, boron_for(0.0))], 12: [(PS + "coolant_pressure", 17.225)],
                          14: relatch + [(BORON, boron_for(0.0))], 16: [(PS + "neutron_flux", 1.1805e13), (BORON, boron_for(0.0))],
                          18: relatch + [(BORON, boron_for(0.0))], 20: [(PS + "fuel_temperature", 185.0), (PS + "coolant_temperature", 190.0), (BORON, boron_for(0.0))],
-                         22: relatch + [(BORON, boron_for(0.0))], 24: [(PS + "coolant_flow_rate", 130000.0)], 26: [(PS + "coolant_flow_rate", 20000.0)],
+                         22: relatch + [(BORON, boron_for(0.0))],
+                         # (the coefficient's 50e6 bound shows only while the fuel's rate is inside its own +-1 K/s clip: a fuel 60 K above the coolant balances 3000 MW)
+                         24: [(PS + "coolant_flow_rate", 130000.0), (PS + "fuel_temperature", 361.0), (BORON, boron_for(0.0))], 26: [(PS + "coolant_flow_rate", 20000.0)],
                          28: [(PS + "steam_flow_rate", 3005.0)], 30: [(PS + "neutron_flux", 3.5e13)], 34: [(PS + "neutron_flux", 2e14)],
                          36: [(PS + "fuel_temperature", 2050.0)]}))
     # C13: a plant whose FIRST step is below 10 % power: the hot leg's floor in sim.py:389-391 shows only before the first heat-removal factor exists
@@ -355,10 +357,12 @@ def scenarios():
         return 23.0 * (1.0 - (1.0 - fraction) ** 0.5) / 2.0
     S.append(dict(name="c15_sg_corners", steps=64, noise=True, noise_seed=9, every=1,
                   setpoints=lambda t: 100.0 if t < 13 else (30.0 if t < 20 else (100.0 if t < 30 else (3.0 if t < 45 else (115.0 if t < 54 else 100.0)))),
-                  pokes={3: [(SG_ % 0 + "water_level", 12.505), (SG_ % 1 + "water_level", 8.004), (SG_ % 2 + "water_level", 12.52),
-                             # (2.5 mm of scale: the generator is limited by its own surface, not by what the primary side brings, so the level factor shows)
+                  pokes={3: [(SG_ % 1 + "water_level", 8.004),
+                             # (2.5 mm of scale: the generator is limited by its own surface, not by what the primary side brings, so the level factor shows
+                             #  -- from the NEXT step on: the scale's thermal resistance is a member the fouling update refreshes at the end of a step)
                              (SG_ % 0 + "tube_interior_fouling.scale_thickness", 2.5), (SG_ % 0 + "tube_interior_fouling.scale_composition['crud_deposits']", 1.0),
                              (SG_ % 2 + "tube_interior_fouling.scale_thickness", 2.5), (SG_ % 2 + "tube_interior_fouling.scale_composition['crud_deposits']", 1.0)],
+                         4: [(SG_ % 0 + "water_level", 12.505), (SG_ % 2 + "water_level", 12.52)],
                          6: [(SG_ % 0 + "water_level", 8.01)],
                          10: [(FP % j + ".state.status", "=PumpStatus.STOPPED") for j in (1, 2, 3, 4)] + [(FP % j + ".state.speed_percent", 0.0) for j in (1, 2, 3, 4)]
                              + [(FP % j + ".state.flow_rate", 0.0) for j in (1, 2, 3, 4)],
@@ -390,6 +394,15 @@ def scenarios():
                   actions=lambda t: (int(acts[t]), float(mags[t])), resets={70: True}))
     S.append(dict(name="p2_primary_only_constant", steps=80, noise=True, noise_seed=21, every=2, enable_secondary=False,
                   setpoints=lambda t: 100.0 - 0.5 * t if t < 40 else None))
+    # P3: the primary side alone with its steam and feedwater flows poked past 3000 kg/s: with the secondary side on, the simulator overwrites the
+    # primary's own steam flow with the steam generators' every step (sim.py:262-266) and that clip is never seen
+    S.append(dict(name="p3_primary_only_flow_clips", steps=12, noise=True, noise_seed=21, every=1, enable_secondary=False,
+                  pokes={3: [(PS + "steam_flow_rate", 3005.0), (PS + "feedwater_flow_rate", 3004.0), (PS + "steam_valve_position", 80.0)]}))
+    # C16: dt = 0.1 with every feedwater pump stopped at 25 % load: a steam generator's inventory-depletion correction (steam_generator.py:455-462)
+    # inside its +-0.2 MPa clip -- at dt = 1 the generators' 60-s step drives it into the clip whatever the load
+    S.append(dict(name="c16_sg_inventory_depletion", steps=30, dt=0.1, noise=True, noise_seed=9, every=1, setpoints=lambda t: 25.0,
+                  pokes={5: [(FP % j + ".state.status", "=PumpStatus.STOPPED") for j in (1, 2, 3, 4)] + [(FP % j + ".state.speed_percent", 0.0) for j in (1, 2, 3, 4)]
+                            + [(FP % j + ".state.flow_rate", 0.0) for j in (1, 2, 3, 4)]}))
     S.extend(fuzz_scenarios())
     return S
 

@@ -153,7 +153,7 @@ def annotate(record):
         if why is None and r["op"] == "const" and (r["file"], r["line"]) not in loose:
             t = re.escape(r["was"])
             if re.search(r"(<=|>=|<|>)\s*\(?\s*" + t + r"(?![\w.])", r["text"]) or re.search(r"(?<![\w.])" + t + r"\s*\)?\s*(<=|>=|<|>)", r["text"]):
-                why = ("sliver", "a threshold moved by 0.1 % while both of its sides are pinned (the dropped / forced branch and the reversed comparison of this line are killed): only a value inside the 0.1 % tells")
+                why = ("sliver", "a threshold moved by 0.1 % (no dropped / forced branch and no reversed comparison of this line survives): only a value inside the 0.1 % tells")
         if why is None:
             why = ("unexplained", "")
         r["class"], r["guard"] = why
@@ -172,6 +172,7 @@ def main():
                     help="run only the mutants the record at --out lists as survivors (after fixtures were added or tolerances tightened) and move the ones now killed")
     ap.add_argument("--distinguishable-only", action="store_true",
                     help="with --retest-survivors: only the survivors tools/mutant_fuzz.py could tell from the original (the others stay listed)")
+    ap.add_argument("--only-class", default=None, help="with --retest-survivors: only the survivors --annotate put in this class (e.g. unexplained)")
     ap.add_argument("--annotate", action="store_true", help="classify the survivors of the record at --out (equality / sliver / guarded / unexplained) and list the unexplained ones")
     args = ap.parse_args()
     if args.annotate:
@@ -187,7 +188,8 @@ def main():
     if args.retest_survivors:
         old = json.load(open(args.out))
         # (records written before the column was kept match by line and token: two sites on a line with the same token are then both run)
-        keep_listed = [r for r in old["survivors"] if args.distinguishable_only and not r.get("fuzz", "").startswith("distinguishable")]
+        keep_listed = [r for r in old["survivors"] if (args.distinguishable_only and not r.get("fuzz", "").startswith("distinguishable"))
+                       or (args.only_class and r.get("class") != args.only_class)]
         fuzz_of = {(r["file"], r["line"], r["op"], r["was"], r["now"]): r.get("fuzz") for r in old["survivors"]}
         want = {(r["file"], r["line"], r.get("col"), r["op"], r["was"], r["now"]) for r in old["survivors"] if r not in keep_listed}
         had = {f: c for f, c in __import__("collections").Counter(r["file"] for r in old["survivors"]).items()}

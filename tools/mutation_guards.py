@@ -3,9 +3,10 @@
 A survivor is either a hole in the fixtures or a change no state of the reference can observe.  Three classes are recognised
 mechanically (mutate_oracle.annotate):
     equality   `<` <-> `<=`, `>` <-> `>=`: the two programs differ only when both operands are equal to the last bit;
-    sliver     the threshold of a comparison scaled by 1.001 WHILE the same comparison's dropped / forced branch and its reversed
-               direction are killed: both sides of the threshold are pinned by fixtures, the mutant only moves it by 0.1 %, and it takes a
-               value inside that 0.1 % to tell (tools/mutant_fuzz.py found such values for some: those have fixtures c12 ... c15);
+    sliver     the threshold of a comparison scaled by 1.001 while no dropped / forced branch and no reversed comparison of the same line
+               survives (the comparison is exercised: where its branch was never taken, the mutants INSIDE the branch survive and show up as
+               unexplained): the mutant moves the threshold by 0.1 % and it takes a value inside that 0.1 % to tell (tools/mutant_fuzz.py found
+               such values for some: those have fixtures c12 ... c15 with pokes computed to land there);
     guarded    the entries below: (file, text the mutated line contains, operators or None for all, the guard[, mutated tokens or all]).
 A guard names the line of the restatement (or of the reference) that keeps the mutated token from mattering at the reference's constants.
 Everything listed here was also stepped against the original on 27 000 random plant-steps with every member scaled by 0.3 ... 3
@@ -35,6 +36,7 @@ GUARDS = [
     ("npo_primary.h", "hot_leg_temp = npo_clip(hot_leg_temp, cold_leg_temp + 5.0, 350.0);", ["const", "sign"], "the first of the two identical lines (npo_primary.h:331): its lower bound binds only below 4.45 % power (delta_t_core < 5 K), where the next line assigns the same cold_leg + 5 on a plant's first step and line 338 recomputes the clip on every later one", ["5.0", "+"]),
     ("npo_primary.h", "hot_leg_temp = npo_clip(hot_leg_temp, cold_leg_temp + 5.0, 350.0);", ["const"], "the 350 C bound: delta_t_core = 3e6 pf / (17100 max(0.3, pf) 5.2) <= 33.74 K over a cold leg <= 300 C", ['350.0']),
     ("npo_primary.h", "loop_hot = npo_clip(loop_hot, loop_cold + 5.0, 350.0);", ["const"], "the 350 C bound: see the hot leg", ['350.0']),
+    ("npo_primary.h", "double pressure_dot = npo_clip(-0.01 * pressure_error, -0.05, 0.05);", ["const"], "the bound that survives is the lower one (the upper is reached from 10.05 MPa in fixture c11): -0.05 needs a pressure more than 5 MPa above its set-point, and the pressure is clipped to 20 against a set-point of at least 15.3", ["0.05"]),
     # ---- npo_chem.h
     ("npo_chem.h", "c->water_aggressiveness = npo_clip(1.0 + iron_effect", ["const"], "the lower bound: 1.0 + 0.05 + three non-negative terms >= 1.05", ['0.5']),
     ("npo_chem.h", "double blend_factor = npo_pymin(0.05 * dt_hours * 0.1, 0.5);", ["const"], "dt_hours <= 100 / 60 by the unit guess above it (a dt above 100 is divided by 3600): the blend is at most 0.0083, the 0.5 cap never binds", ['0.5']),
@@ -110,7 +112,7 @@ GUARDS = [
     ("npo_sg.h", "double steam_supply_factor = (P->sg_secondary_design_flow > 0)", None, "a positive parameter"),
     ("npo_sg.h", "equilibrium_pressure = npo_clip(equilibrium_pressure, 3.0, 8.5);", None, "6.9 x (0.7 + 0.3 x heat input / design) - 0.5 x steam demand / design: 4.1 ... 7.9 MPa for heat inputs 0 ... 1.5 x design and demands 0 ... 1.5 x design; neither bound binds"),
     ("npo_sg.h", "double new_pressure = npo_clip(base_new_pressure + pressure_corrections, 1.0, 8.0);", ["const"], "the lower bound: the pressure relaxes towards >= 4.1 MPa and a step's corrections are clipped to +-0.2", ['1.0']),
-    ("npo_sg.h", "if (q_flow_factor > 1.1) quality_degradation += npo_pymin((q_flow_factor - 1.1) * 0.01, 0.03);", ["const", "minmax"], "the 0.03 cap needs a steam flow of 4.1 x design per generator; the demand is at most 1.5 x (the heat source's set-point limit)", ['0.03', 'npo_pymin']),
+    ("npo_sg.h", "if (q_flow_factor > 1.1) quality_degradation += npo_pymin((q_flow_factor - 1.1) * 0.01, 0.03);", None, "never taken: a generator's steam demand is 1500 x min(1, load) / 3 <= 500 kg/s = its secondary_design_flow (npo_secondary.h:59 caps the load fraction at 1.0, enhanced_physics.py:549-584 splits it evenly), so q_flow_factor <= 1.0; the reversed comparison, which would take it always, is killed"),
     ("npo_sg.h", "if (heat_flux_ratio > 1.2) quality_degradation += npo_pymin((heat_flux_ratio - 1.2) * 0.005, 0.02);", ["const"], "the 0.02 cap needs a heat flux of 5.2 x design", ['0.02']),
     ("npo_sg.h", "double target_quality = npo_clip(0.995 - quality_degradation, 0.90, 1.0);", None, "the degradation terms add up to at most 0.02 + 0.03 + 0.02: the target stays in 0.925 ... 0.995"),
     ("npo_sg.h", "if (total_primary_flow > 0) demands[i]", None, FLOW03),
