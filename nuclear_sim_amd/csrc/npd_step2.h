@@ -264,11 +264,16 @@ __device__ __forceinline__ void npd2_seq_stage(int k, double &cur_p, double &cur
 struct npd2_tstg_old_t { double eff_deg[14], deposit[14], blade_wear[14], rotor_t[8], casing_t[6], blade_t[14]; };
 /* stage k's old values as scalars (rotor_t / casing_t are read only where the stage has such a point); stress_out: rotor point
  * k's thermal stress (k < 8) */
+/* DEG: this caller also advances the stage's efficiency degradation and deposit thickness (the four-wave kernel's chain wave does
+ * that itself, from the copies it has to load anyway: npd_step4.h) */
+template <bool DEG = true>
 __device__ __forceinline__ void npd2_stage_post_vals(const npd_stage_t &st, int k, double eff_deg, double deposit, double blade_wear_old, double rotor_t,
                                                      double casing_t, double blade_t, double loading_factor, double outlet_temperature, double dt,
                                                      double *stress_out) {
-  NPD2_TSTG(stage_efficiency_degradation, k) = (npd_real_t)(eff_deg + 1e-05 * dt);
-  NPD2_TSTG(stage_deposit_thickness, k) = (npd_real_t)(deposit + 5e-05 * dt);
+  if constexpr (DEG) {
+    NPD2_TSTG(stage_efficiency_degradation, k) = (npd_real_t)(eff_deg + 1e-05 * dt);
+    NPD2_TSTG(stage_deposit_thickness, k) = (npd_real_t)(deposit + 5e-05 * dt);
+  }
   double blade_wear = (1e-06 * dt) * npd_sq(loading_factor);
   NPD2_TSTG(stage_blade_wear_factor, k) = (npd_real_t)npd_pymax(0.7, blade_wear_old - blade_wear);
   const double time_constant = 3600.0 / 3600.0, ambient = 25.0;

@@ -100,6 +100,12 @@ __device__ __forceinline__ void npd4_store_turb_range(const npd_stage_t &st, con
 /* the stage arrays of the stages k = R, R + 3, R + 6 ... (at most five) into registers / their post-pass behind the chain's flag.
  * The arrays are indexed by the stage's position j in the wave's list, so that the three waves that share this code path keep them
  * in the same registers */
+/* NPD4_CHAIN_STORES_DEG (round 4): the chain's wave has to load every stage's efficiency degradation and deposit thickness for the stage
+ * efficiencies; it also stores their advanced values (old + rate x dt, nothing the chain computes), so the post-pass waves no longer fetch
+ * those 28 columns a second time -- 224 B per plant-step of the 346 B the kernel read beyond its algorithmic bytes */
+#ifndef NPD4_CHAIN_STORES_DEG
+#define NPD4_CHAIN_STORES_DEG 1
+#endif
 struct npd4_old_t { double eff_deg[5], deposit[5], blade_wear[5], blade_t[5], rotor_t[5], casing_t[5]; };
 template <int R>
 __device__ __forceinline__ void npd4_stage_preload(const npd_stage_t &st, npd4_old_t &old) {
@@ -108,7 +114,8 @@ __device__ __forceinline__ void npd4_stage_preload(const npd_stage_t &st, npd4_o
     const int k = R + 3 * j;
     if (k >= 14) { old.eff_deg[j] = old.deposit[j] = old.blade_wear[j] = old.blade_t[j] = 0.0; }
     else {
-      old.eff_deg[j] = (double)NPD2_TSTG(stage_efficiency_degradation, k < 14 ? k : 0); old.deposit[j] = (double)NPD2_TSTG(stage_deposit_thickness, k < 14 ? k : 0);
+      if (NPD4_CHAIN_STORES_DEG) { old.eff_deg[j] = old.deposit[j] = 0.0; }
+      else { old.eff_deg[j] = (double)NPD2_TSTG(stage_efficiency_degradation, k < 14 ? k : 0); old.deposit[j] = (double)NPD2_TSTG(stage_deposit_thickness, k < 14 ? k : 0); }
       old.blade_wear[j] = (double)NPD2_TSTG(stage_blade_wear_factor, k < 14 ? k : 0); old.blade_t[j] = (double)NPD2_TSTG(blade_temperatures, k < 14 ? k : 0);
     }
     old.rotor_t[j] = (k < 8) ? (double)NPD2_TSTG(rotor_temperatures, k < 8 ? k : 0) : 0.0;
@@ -127,8 +134,8 @@ __device__ __forceinline__ void npd4_stage_post(const npd_stage_t &st, const npd
     if (k >= 14) continue;
     NPD4_FLAG_WAIT(FL_CHAIN, base + k + 1);
     double stress = 0.0;
-    npd2_stage_post_vals(st, k, old.eff_deg[j], old.deposit[j], old.blade_wear[j], old.rotor_t[j], old.casing_t[j], old.blade_t[j],
-                         XR(Y_LOADING + (k < 14 ? k : 0)), XR(Y_TOUT + (k < 14 ? k : 0)), tdt, &stress);
+    npd2_stage_post_vals<!NPD4_CHAIN_STORES_DEG>(st, k, old.eff_deg[j], old.deposit[j], old.blade_wear[j], old.rotor_t[j], old.casing_t[j], old.blade_t[j],
+                                                 XR(Y_LOADING + (k < 14 ? k : 0)), XR(Y_TOUT + (k < 14 ? k : 0)), tdt, &stress);
     if (k < 8) XW(Y_STRESS + (k < 8 ? k : 0), stress);
   }
   NPD4_FLAG_SET(FL_POST + R, 1);
@@ -595,11 +602,16 @@ __device__ __forceinline__ void npd_step4_body(
       double stage_eff[14];
 #pragma unroll
       for (int k = 0; k < 14; k++) {
-        double fouling_factor = 1.0 / (1.0 + (double)NPD2_TSTG(stage_deposit_thickness, k) / 0.5);
+        const double deposit = (double)NPD2_TSTG(stage_deposit_thickness, k), eff_deg = (double)NPD2_TSTG(stage_efficiency_degradation, k);
+        double fouling_factor = 1.0 / (1.0 + deposit / 0.5);
         double blade_wear_factor = (double)NPD2_TSTG(stage_blade_wear_factor, k);
         double blade_condition_factor = npd_pymin(fouling_factor, blade_wear_factor);
-        double actual_efficiency = npd_pymax(0.7, 0.88 - (double)NPD2_TSTG(stage_efficiency_degradation, k));
+        double actual_efficiency = npd_pymax(0.7, 0.88 - eff_deg);
         stage_eff[k] = (actual_efficiency * blade_condition_factor * fouling_factor * blade_wear_factor * 1.0);
+        if (NPD4_CHAIN_STORES_DEG) {   /* the stage post-pass's two rate updates (npd2_stage_post_vals), here where the old values are in registers */
+          NPD2_TSTG(stage_efficiency_degradation, k) = (npd_real_t)(eff_deg + 1e-05 * tdt);
+          NPD2_TSTG(stage_deposit_thickness, k) = (npd_real_t)(deposit + 5e-05 * tdt);
+        }
       }
       NPD4_STAMP(7);
       __builtin_amdgcn_s_setprio(3);               /* the chain is the group's critical path from here to its last stage */
