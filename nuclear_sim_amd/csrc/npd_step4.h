@@ -100,11 +100,13 @@ __device__ __forceinline__ void npd4_store_turb_range(const npd_stage_t &st, con
 /* the stage arrays of the stages k = R, R + 3, R + 6 ... (at most five) into registers / their post-pass behind the chain's flag.
  * The arrays are indexed by the stage's position j in the wave's list, so that the three waves that share this code path keep them
  * in the same registers */
-/* NPD4_CHAIN_STORES_DEG (round 4): the chain's wave has to load every stage's efficiency degradation and deposit thickness for the stage
- * efficiencies; it also stores their advanced values (old + rate x dt, nothing the chain computes), so the post-pass waves no longer fetch
- * those 28 columns a second time -- 224 B per plant-step of the 346 B the kernel read beyond its algorithmic bytes */
+/* NPD4_CHAIN_STORES_DEG = 1 (round 4, measured and NOT kept): the chain's wave, which has to load every stage's efficiency degradation and
+ * deposit thickness for the stage efficiencies anyway, also stores their advanced values (old + rate x dt), so that the post-pass waves do not
+ * read those 28 columns a second time.  65 536 plants 0.0850 -> 0.0887 ms, 32 768 plants 0.0426 -> 0.0450: 28 stores and 28 adds more on the
+ * wave whose chain is the group's critical path cost 4-6 %, and the second reads were hitting the L2 anyway (FETCH_SIZE 255.5 -> 253.1 MB per
+ * launch for 14.7 MB fewer bytes requested): profiles/r4_ab_chain_stores_deg_rejected.txt */
 #ifndef NPD4_CHAIN_STORES_DEG
-#define NPD4_CHAIN_STORES_DEG 1
+#define NPD4_CHAIN_STORES_DEG 0
 #endif
 struct npd4_old_t { double eff_deg[5], deposit[5], blade_wear[5], blade_t[5], rotor_t[5], casing_t[5]; };
 template <int R>
