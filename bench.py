@@ -415,9 +415,12 @@ def main():
                                             "it because the kernel skips the store of a column whose bits did not change for any plant of "
                                             "a wave (unchanged-column elision); READS come out ABOVE it (FETCH_SIZE counts what the L2 "
                                             "fetches, Infinity-Cache hits included: the cache does not hide reads from this counter): "
-                                            "the narrow columns that mix output and int32 members are fetched whole, the turbine's "
-                                            "lubrication pre-step re-reads part of the turbine section on another wave, every wave reads "
-                                            "the plant's clock; NULL inputs (20 B/plant) are already excluded",
+                                            "by the counters these are the kernel's own loads (the vector caches request the same bytes). "
+                                            "Columns two waves of a group both read (stage arrays, part of the turbine section, the plant's "
+                                            "clock) and the narrow columns that mix output and int32 members are candidates, but removing "
+                                            "224 B per plant of such second reads lowered FETCH_SIZE by 35 B per plant (they hit the L2; "
+                                            "DESIGN.md section 3, round 4): the excess is not accounted for column by column; NULL inputs "
+                                            "(20 B/plant) are already excluded",
                          "kernel": launched_kernel + (" (the build with the automatic maintenance inside: threshold screen in the pump phase, rule by function call for flagged waves)" if args.maintenance else ""),
                          "kernel_ms": kernel_ms},
             "preconditioning": {"ms": precondition_ms, "what": "a scratch handle of the same size stepped on the same inputs before the %d warm-up "
