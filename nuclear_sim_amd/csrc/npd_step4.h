@@ -108,6 +108,11 @@ __device__ __forceinline__ void npd4_store_turb_range(const npd_stage_t &st, con
 #ifndef NPD4_CHAIN_STORES_DEG
 #define NPD4_CHAIN_STORES_DEG 0
 #endif
+#ifndef NPD4_UNITS_FIRST
+#define NPD4_UNITS_FIRST 1   /* wave 0: its pass B units before the preload of its stage arrays, which only its post-pass needs -- wave 0's steam generator is
+                              * the last to finish, so its first unit is what the chain's first stage waits for (round 4: 32 768 plants 0.04277 -> 0.04245 ms,
+                              * three alternating runs each, profiles/r4_ab_units_first.txt) */
+#endif
 struct npd4_old_t { double eff_deg[5], deposit[5], blade_wear[5], blade_t[5], rotor_t[5], casing_t[5]; };
 template <int R>
 __device__ __forceinline__ void npd4_stage_preload(const npd_stage_t &st, npd4_old_t &old) {
@@ -678,7 +683,11 @@ __device__ __forceinline__ void npd_step4_body(
       __builtin_amdgcn_s_setprio(0);
       NPD4_STAMP(8);
     } else if (wave == 0) {
+#if NPD4_UNITS_FIRST
+      npd4_pass_b_units<0, 2, 6, 0>(xch, lane); NPD4_STAMP(7); npd4_stage_preload<0>(st, old); NPD4_STAMP(8); npd4_stage_post<0>(st, old, xch, lane, tdt);
+#else
       npd4_stage_preload<0>(st, old); NPD4_STAMP(7); npd4_pass_b_units<0, 2, 6, 0>(xch, lane); NPD4_STAMP(8); npd4_stage_post<0>(st, old, xch, lane, tdt);
+#endif
     } else {
       npd4_stage_preload<1>(st, old); NPD4_STAMP(7); npd4_pass_b_units<1, 2, 6, 1>(xch, lane); NPD4_STAMP(8);
       NPD_ST_LOAD(COND, npb_cond_t, cd, 0);        /* for the condenser, which this wave runs as soon as the chain is through */
