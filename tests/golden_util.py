@@ -23,9 +23,13 @@ try:
     ORACLE_EXACT_COLUMNS = frozenset(json.load(open(os.path.join(GOLDEN_DIR, "oracle_exact_columns.json")))["bit_identical"])
 except OSError:
     ORACLE_EXACT_COLUMNS = frozenset()
-# columns that are differences of nearly equal numbers (1 - area ratio ~ 1e-8..1e-7): their relative error
-# is an amplified 1-ulp effect, so they are checked with an absolute floor instead
-ATOL_SMALL = 1e-12
+# absolute floor under the relative tolerance: far below any column's working magnitude (deposit layers start at 1e-11 mm: with the 1e-12 of
+# rounds 1-3 a 0.1 % error in their growth rate was invisible -- found by tools/mutate_device.py) ...
+ATOL_SMALL = float(os.environ.get("NPB_ATOL_SMALL", "1e-18"))
+# ... except for the two columns that are differences of nearly equal numbers (a steam generator's TSP fouling fraction = 1 - area ratio ~ 1e-8
+# and the heat-transfer degradation computed from it): one ulp of the 1.0 is 1e-8 of them, so the ORACLE's 1e-10 needs a floor there
+CANCELLATION_COLUMNS = ("tsp_fouling_fraction", "tsp_ht_degradation")
+CANCELLATION_FLOOR = 1e-15
 
 
 def fixture_names():
@@ -108,12 +112,13 @@ def compare_state(g, f64, i32, row, where, rtol=None, loose=()):
                 bad.append((label, int(i32[slot]), int(v)))
         else:
             mine = float(f64[slot])
+            floor = CANCELLATION_FLOOR if label.endswith(CANCELLATION_COLUMNS) else ATOL_SMALL
             if loose and label.startswith(loose):
-                tol = RTOL * abs(v) + ATOL_SMALL
+                tol = RTOL * abs(v) + floor
             elif rtol < RTOL and label in ORACLE_EXACT_COLUMNS:
                 tol = 4.5e-16 * abs(v)         # the oracle against the reference on a column it reproduces bit for bit
             else:
-                tol = rtol * abs(v) + ATOL_SMALL
+                tol = rtol * abs(v) + floor
             if not (abs(mine - v) <= tol):
                 bad.append((label, mine, float(v)))
     assert not bad, "%s %s: %d mismatching columns, first: %s" % (g.name, where, len(bad), bad[:5])

@@ -113,6 +113,23 @@ def cmd_build(args):
 def cmd_run(args):
     index = json.load(open(os.path.join(OUT, "index.json")))
     os.makedirs(os.path.join(ROOT, "gpurun_out", "r4"), exist_ok=True)
+    if args.stage2:
+        # the mutants the golden replays let through although the CPU fixtures kill their twin: the whole GPU parity file (the HIP-vs-restatement
+        # comparisons on random batches, the rk4 mode, the long run ...)
+        index = json.load(open(args.stage2))
+        for rec in index:
+            if rec.get("gpu") != "survived" or rec["twin"] != "killed":
+                continue
+            env = dict(os.environ, NPB_LIB=os.path.join(OUT, "libnpb_%d.so" % rec["k"]), PYTHONDONTWRITEBYTECODE="1")
+            t = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                                "-k", "not test_native_library_is_loaded"], cwd=ROOT, env=env, capture_output=True, text=True)
+            import re
+            m = re.search(r"FAILED (\S+)", t.stdout)
+            rec["gpu_stage2"] = "survived" if t.returncode == 0 else "killed"
+            rec["by_stage2"] = (m.group(1) if m else t.stdout[-200:]) if t.returncode != 0 else ""
+            print("%2d %-16s %4d %-6s stage 2: %-8s %s" % (rec["k"], rec["file"], rec["line"], rec["op"], rec["gpu_stage2"], rec["by_stage2"]), flush=True)
+            json.dump(index, open(args.stage2, "w"), indent=1)
+        return
     for rec in index:
         if rec["build"] != "ok":
             continue
@@ -143,5 +160,6 @@ if __name__ == "__main__":
     ap.add_argument("--sample", type=int, default=24)
     ap.add_argument("--jobs", type=int, default=6)
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--stage2", default=None, help="run: a results file of an earlier `run`; its survivors with a CPU-killed twin get the whole GPU parity file")
     a = ap.parse_args()
     (cmd_build if a.cmd == "build" else cmd_run)(a)
