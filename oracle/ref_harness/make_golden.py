@@ -403,6 +403,34 @@ def scenarios():
     S.append(dict(name="c16_sg_inventory_depletion", steps=30, dt=0.1, noise=True, noise_seed=9, every=1, setpoints=lambda t: 25.0,
                   pokes={5: [(FP % j + ".state.status", "=PumpStatus.STOPPED") for j in (1, 2, 3, 4)] + [(FP % j + ".state.speed_percent", 0.0) for j in (1, 2, 3, 4)]
                             + [(FP % j + ".state.flow_rate", 0.0) for j in (1, 2, 3, 4)]}))
+    # C17-C19 (round 4, third pass): values inside the 0.1 % slivers of thresholds the differential fuzz could not reach, where a fixed poke
+    # lands there (tools/mutation_guards.py: class "sliver")
+    h = 1.0 / 60.0                                   # the condenser's chemistry advances by dt / 60 hours per step (condenser/physics.py:769-800)
+    # the three treatment thresholds of WaterChemistry._update_chemical_treatment (water_chemistry.py:416-438), met from 0.05 % above AFTER the
+    # step's own dosing: chlorine 0.2001 (> 0.2), antiscalant 2.001 (> 2.0), inhibitor 5.0025 (> 5.0)
+    chlorine0 = (0.2001 - 0.5 * h) / (np.exp(-0.1 * h) * (1.0 - 0.5 * h))
+    antiscalant0 = (2.001 - 5.0 * 0.5 * h) / (1.0 - 0.5 * h)
+    inhibitor0 = (5.0025 - 10.0 * 0.5 * h) / (1.0 - 0.5 * h)
+    tube_area = np.pi * (0.0254 / 2.0) ** 2
+    active = float(round(45.0 / (3.0015 * tube_area)))      # cooling-water velocity 3.0015 m/s (> 3.0: vibration damage starts)
+    S.append(dict(name="c17_threshold_slivers", steps=30, noise=False, every=1,
+                  # 120.06 % for five steps: a primary-limited generator's heat flux is 1.2006 x design (> 1.2: the quality degradation's second term)
+                  setpoints=lambda t: 120.06 if 20 <= t < 25 else 100.0,
+                  pokes={3: [(CH1 + "chlorine_residual", float(chlorine0)), (CH1 + "antiscalant_concentration", float(antiscalant0)), (CH1 + "corrosion_inhibitor_level", float(inhibitor0))],
+                         6: [(CD + "tube_degradation.active_tube_count", active), (CD + "tube_degradation.plugged_tube_count", 84000.0 - active)],
+                         9: [(CD + "vacuum_system.condenser_pressure", 0.008004)],        # > 0.008: the lag ejector starts
+                         # TSP shutdown criteria from just inside (generator 0 stays clean for the heat-flux steps): maldistribution 0.30015 (three plates
+                         # 9.9 % blocked, four 5 %), pressure-drop ratio 5.0025, then a 41-year-old plate 50.025 % blocked
+                         12: [(SGP % (1, "magnetite", k), tsp_level_thickness(0.09917321809860119 if k < 3 else 0.05)) for k in range(7)]
+                             + [(SGP % (2, "magnetite", k), tsp_level_thickness(1.0 - 1.0 / np.sqrt(5.0025))) for k in range(7)],
+                         16: [(SGP % (1, "magnetite", k), tsp_level_thickness(0.50025)) for k in range(7)] + [(SG_ % 1 + "tsp_fouling.operating_years", 41.0)]}))
+    # C18: a first step at 10.005 % power (the hot leg's floor is for power fractions below 0.1; a primary-limited generator then sits at 0.10005
+    # of its design power: the availability count's > 0.1)
+    S.append(dict(name="c18_first_step_10p005", steps=4, every=1, setpoints=lambda t: 10.005 if t == 0 else None))
+    # C19: the inventory-depletion branch's steam-flow threshold from 0.05 % above: 20.01 % load is 100.05 kg/s per generator (> 100), no feedwater
+    S.append(dict(name="c19_sg_inventory_threshold", steps=16, dt=0.1, every=1, setpoints=lambda t: 20.01,
+                  pokes={5: [(FP % j + ".state.status", "=PumpStatus.STOPPED") for j in (1, 2, 3, 4)] + [(FP % j + ".state.speed_percent", 0.0) for j in (1, 2, 3, 4)]
+                            + [(FP % j + ".state.flow_rate", 0.0) for j in (1, 2, 3, 4)]}))
     S.extend(fuzz_scenarios())
     return S
 
