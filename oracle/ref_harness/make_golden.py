@@ -431,6 +431,13 @@ def scenarios():
     S.append(dict(name="c19_sg_inventory_threshold", steps=16, dt=0.1, every=1, setpoints=lambda t: 20.01,
                   pokes={5: [(FP % j + ".state.status", "=PumpStatus.STOPPED") for j in (1, 2, 3, 4)] + [(FP % j + ".state.speed_percent", 0.0) for j in (1, 2, 3, 4)]
                             + [(FP % j + ".state.flow_rate", 0.0) for j in (1, 2, 3, 4)]}))
+    # C20: the rotor's equation of motion.  At every dt another fixture uses, one step of the rated torque (563 rpm/s over 6 ... 300 s) carries the
+    # rotor into its 3780-rpm clamp, so the speed is 3600 at construction and 3780 ever after and neither the acceleration, the friction term nor
+    # anything behind "rotor_speed <" is seen.  dt = 0.002 (0.12 s: 68 rpm per step) with the speed poked to 3000 and to 5 rpm with a cold rotor (below 100:
+    # thermal bow builds up instead of decaying, rotor_dynamics.py:913-954) and back
+    S.append(dict(name="c20_rotor_dynamics", steps=60, dt=0.002, noise=True, noise_seed=9, every=1,
+                  pokes={3: [("secondary_physics.turbine.rotor_dynamics.rotor_speed", 3000.0)], 25: [("secondary_physics.turbine.rotor_dynamics.rotor_speed", 5.0), ("secondary_physics.turbine.rotor_dynamics.rotor_temperature", 100.0)],
+                         45: [("secondary_physics.turbine.rotor_dynamics.rotor_speed", 3700.0)]}))
     S.extend(fuzz_scenarios())
     return S
 

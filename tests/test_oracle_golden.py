@@ -80,6 +80,15 @@ def test_oracle_replays_golden(oracle_lib, name):
         np.testing.assert_allclose(obs[0], g.obs[t], rtol=RTOL, atol=1e-12, err_msg="%s obs step %d" % (name, t))
         np.testing.assert_allclose(rew[0], g.reward[t], rtol=RTOL, atol=1e-9, err_msg="%s reward step %d" % (name, t))
         assert int(done[0]) == int(g.done[t]), "%s done step %d" % (name, t)
+        # the trip flags (include/npb.h NPB_TRIP_*) have no counterpart of their own in the reference: they are a digest of state members it
+        # does have, so they are held to THOSE members as the reference left them (bit 2, the NaN reset, is an event of the step, not a state)
+        if t + 1 in sampled:
+            ref = dict(zip((c[2] for c in g.cols), g.state[sampled[t + 1]]))
+            if g.meta.get("enable_secondary", True) and not np.isnan(ref.get("turb.trip_active", np.nan)):
+                want = (int(ref["prim.scram_status"]) != 0) | (int(g.done[t]) << 1) | ((int(ref["turb.trip_active"]) != 0) << 3) | ((int(ref["fw.system_trip_active"]) != 0) << 4)
+                for k in range(4):
+                    want |= (int(ref["pump[%d].trip_active" % k]) != 0) << (8 + k)
+                assert (int(flags[0]) & ~4) == want, "%s trip flags step %d: %d, the reference's state says %d" % (name, t, int(flags[0]), want)
         m = ~np.isnan(g.info[t])
         np.testing.assert_allclose(info[0][:g.info.shape[1]][m], g.info[t][m], rtol=RTOL, atol=1e-9, err_msg="%s info step %d" % (name, t))
         # the three turbine keys of info["secondary_system"] that come out of the step itself (include/npb.h NPB_INFO_TURBINE_*)
