@@ -438,6 +438,10 @@ def scenarios():
     S.append(dict(name="c20_rotor_dynamics", steps=60, dt=0.002, noise=True, noise_seed=9, every=1,
                   pokes={3: [("secondary_physics.turbine.rotor_dynamics.rotor_speed", 3000.0)], 25: [("secondary_physics.turbine.rotor_dynamics.rotor_speed", 5.0), ("secondary_physics.turbine.rotor_dynamics.rotor_temperature", 100.0)],
                          45: [("secondary_physics.turbine.rotor_dynamics.rotor_speed", 3700.0)]}))
+    # C21: the feedwater system's equipment protection (pump_system.py:470-490): the bearing temperature it watches is the oil temperature + 5 K,
+    # which a RUNNING pump's own update keeps inside [35, 75] C -- only the stopped spare keeps a poked 130 C long enough for the 120-C timer
+    S.append(dict(name="c21_fw_equipment_protection", steps=20, noise=True, noise_seed=9, every=1,
+                  pokes={3: [(FP % 4 + ".lubrication_system.oil_temperature", 130.0)], 10: [(FP % 4 + ".lubrication_system.oil_temperature", 60.0)]}))
     S.extend(fuzz_scenarios())
     return S
 

@@ -61,3 +61,36 @@ def test_state_machines_are_visited_completely():
 if __name__ == "__main__":
     for label, d in sorted(coverage().items()):
         print("%-40s %s" % (label, {k: len(v) for k, v in sorted(d.items())}))
+
+
+# real-valued physics members that rest at one or two values in EVERY fixture, with the reason (a member that sits on a clamp or on its
+# construction value hides whatever computes it: the rotor speed did, 3600 / 3780 rpm in 106 fixtures, until fixture c20 -- found by
+# tools/mutate_oracle.py's sample of the turbine's text)
+RESTING_BY_CONSTRUCTION = {
+    "fw.timer_motor_temp": "the motor temperature it watches (> 130 C) is an output every pump recomputes each step, 60-90 C at the reference's constants",
+    "fw.timer_vibration": "the vibration level it watches (> 10 mm/s) is an output every pump recomputes each step, below 6 mm/s with every wear at its trip value",
+    "pump[0].head_degradation": "performance factors are computed with a literal cavitation damage of 0.0 (pump_lubrication.py:742): the head loss is 0",
+    "pump[1].head_degradation": "as pump 0", "pump[2].head_degradation": "as pump 0", "pump[3].head_degradation": "as pump 0",
+    "pump[3].cavitation_time": "the spare pump never runs long enough to cavitate; pumps 0-2 cover the member",
+    "sec.previous_feedwater_temp": "a moving average of the literal 227 C the feedwater temperature estimate is",
+    "turb.timer_bearing_temp": "bearing metal temperatures are capped at 115 C, the timer starts above 120 C (test_state_machines_are_visited_completely)",
+    "turb.timer_overspeed": "the rotor model clamps the speed AT the trip value (> 3780 never holds)",
+    "chem[0].dissolved_oxygen": "assigned a literal every step (water_chemistry.py:352)", "chem[1].dissolved_oxygen": "as chem[0]",
+    "prim.burnable_poison_worth": "rests at 0 unless poked (fixture c11): no step changes it",
+    "prim.coolant_void_fraction": "rests at 0 unless poked (fixture c11): no step changes it",
+}
+
+
+def test_every_real_valued_physics_member_moves_in_some_fixture():
+    """fp64 members outside the maintenance bookkeeping must take at least three values across tests/golden/ (timers: two)"""
+    seen = {}
+    for name in fixture_names():
+        g = Golden(name)
+        for j, (kind, _slot, label, _p) in enumerate(g.cols):
+            if kind != "f64" or label.split(".")[0].split("[")[0] in ("maint", "mpump") or len(seen.get(label, ())) > 8:
+                continue
+            v = g.state[:, j]
+            seen.setdefault(label, set()).update(np.unique(v[~np.isnan(v)]).tolist()[:16])
+    # (a protection timer that a step of dt raises to dt and the next step clears has two values when it has run)
+    resting = sorted(l for l, s in seen.items() if len(s) < (2 if "timer" in l else 3) and l not in RESTING_BY_CONSTRUCTION)
+    assert not resting, "real-valued members that rest in every fixture: %s" % resting
