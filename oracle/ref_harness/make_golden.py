@@ -441,7 +441,10 @@ def scenarios():
     # C21: the feedwater system's equipment protection (pump_system.py:470-490): the bearing temperature it watches is the oil temperature + 5 K,
     # which a RUNNING pump's own update keeps inside [35, 75] C -- only the stopped spare keeps a poked 130 C long enough for the 120-C timer
     S.append(dict(name="c21_fw_equipment_protection", steps=20, noise=True, noise_seed=9, every=1,
-                  pokes={3: [(FP % 4 + ".lubrication_system.oil_temperature", 130.0)], 10: [(FP % 4 + ".lubrication_system.oil_temperature", 60.0)]}))
+                  pokes={3: [(FP % 4 + ".lubrication_system.oil_temperature", 130.0)], 10: [(FP % 4 + ".lubrication_system.oil_temperature", 60.0)],
+                         # a running pump ramps by 15 % per step towards its set-point: poked to 65 % it is at EXACTLY 80 % when its flow is computed (the flow
+                         # follows the demand ABOVE 0.8), at 10 % with a set-point of 3 % it is at 3 % (below 20 %: the floor of 5 % of the rated flow is above what 3 % speed delivers)
+                         12: [(FP % 2 + ".state.speed_percent", 65.0)], 15: [(FP % 3 + ".state.speed_percent", 10.0), (FP % 3 + ".state.speed_setpoint", 3.0)]}))
     S.extend(fuzz_scenarios())
     return S
 
