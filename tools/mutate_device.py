@@ -47,13 +47,22 @@ def device_sites(stem):
     lines = open(path).read().split("\n")
     # not on the GPU: a mutant of a line that computes an INDEX (ejector rotation, pump count) could address outside a private array,
     # and a faulting kernel can take the whole host down -- those lines are left to the CPU run
-    risky = ("lead_ejector", "lag_ejector", "lead_index", "lag_index", "needed", "pumps_needed")
-    return [(ln, col, length, rep.replace("npo_py", "npd_py"), kind) for ln, col, length, rep, kind in ss if not any(w in lines[ln] for w in risky)]
+    risky = ("lead_ejector", "lag_ejector", "lead_index", "lag_index", "needed", "pumps_needed", "remaining_stages", "NPD_EXT_IDX", "idx", "index")
+
+    def inside_brackets(line, col):
+        depth = 0
+        for ch in line[:col]:
+            depth += (ch == "[") - (ch == "]")
+        return depth > 0
+    return [(ln, col, length, rep.replace("npo_py", "npd_py"), kind) for ln, col, length, rep, kind in ss
+            if not any(w in lines[ln] for w in risky) and not inside_brackets(lines[ln], col)]
 
 
 def oracle_twin(stem, text, op, was, now, survivors):
     """what the CPU fixtures did with the same mutation of the same line of the restatement"""
     want = text.replace("npd_", "npo_").replace("NPD_", "NPO_").replace("__device__ __forceinline__", "NPO_FN").strip()
+    if not os.path.exists(os.path.join(ROOT, "oracle", "npo_%s.h" % stem)):
+        return "no twin line"
     lines = [l.strip() for l in open(os.path.join(ROOT, "oracle", "npo_%s.h" % stem)).read().split("\n")]
     if want not in lines:
         return "no twin line"
@@ -97,7 +106,8 @@ def cmd_build(args):
             sys.exit("build the product library first (make -C nuclear_sim_amd/csrc): %s is missing" % f)
     shutil.rmtree(OUT, ignore_errors=True); os.makedirs(OUT)
     rng = random.Random(args.seed)
-    pool_sites = [(stem, s) for stem in STEMS for s in device_sites(stem)]
+    stems = tuple(args.stems.split(",")) if args.stems else STEMS
+    pool_sites = [(stem, s) for stem in stems for s in device_sites(stem)]
     picks = rng.sample(pool_sites, args.sample)
     record = json.load(open(os.path.join(ROOT, "profiles", "r4_mutation_score.json")))
     jobs = [(k, stem, s) for k, (stem, s) in enumerate(picks)]
@@ -118,7 +128,7 @@ def cmd_run(args):
         # comparisons on random batches, the rk4 mode, the long run ...)
         index = json.load(open(args.stage2))
         for rec in index:
-            if rec.get("gpu") != "survived" or rec["twin"] != "killed":
+            if rec.get("gpu") != "survived" or (rec["twin"] != "killed" and not args.stage2_all):
                 continue
             env = dict(os.environ, NPB_LIB=os.path.join(OUT, "libnpb_%d.so" % rec["k"]), PYTHONDONTWRITEBYTECODE="1")
             t = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
@@ -160,6 +170,8 @@ if __name__ == "__main__":
     ap.add_argument("--sample", type=int, default=24)
     ap.add_argument("--jobs", type=int, default=6)
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--stems", default=None, help="build: device headers to mutate (default: the seven whose text the restatement shares), e.g. feedwater,turbine,lube")
+    ap.add_argument("--stage2-all", action="store_true", help="with --stage2: every survivor of the replays, whatever its twin")
     ap.add_argument("--stage2", default=None, help="run: a results file of an earlier `run`; its survivors with a CPU-killed twin get the whole GPU parity file")
     a = ap.parse_args()
     (cmd_build if a.cmd == "build" else cmd_run)(a)
