@@ -172,6 +172,7 @@ def main():
                     help="run only the mutants the record at --out lists as survivors (after fixtures were added or tolerances tightened) and move the ones now killed")
     ap.add_argument("--distinguishable-only", action="store_true",
                     help="with --retest-survivors: only the survivors tools/mutant_fuzz.py could tell from the original (the others stay listed)")
+    ap.add_argument("--seed", type=int, default=4, help="of --sample")
     ap.add_argument("--only-class", default=None, help="with --retest-survivors: only the survivors --annotate put in this class (e.g. unexplained)")
     ap.add_argument("--annotate", action="store_true", help="classify the survivors of the record at --out (equality / sliver / guarded / unexplained) and list the unexplained ones")
     args = ap.parse_args()
@@ -184,7 +185,7 @@ def main():
                 print("UNEXPLAINED %s:%d %s  %r -> %r   | %s   [%s]" % (r["file"], r["line"], r["op"], r["was"], r["now"], r["text"][:110], r.get("fuzz", "")[:40]))
         return
     jobs = []
-    rng = random.Random(4)
+    rng = random.Random(args.seed)
     if args.retest_survivors:
         old = json.load(open(args.out))
         # (records written before the column was kept match by line and token: two sites on a line with the same token are then both run)
