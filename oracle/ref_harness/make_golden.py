@@ -445,6 +445,15 @@ def scenarios():
                          # a running pump ramps by 15 % per step towards its set-point: poked to 65 % it is at EXACTLY 80 % when its flow is computed (the flow
                          # follows the demand ABOVE 0.8), at 10 % with a set-point of 3 % it is at 3 % (below 20 %: the floor of 5 % of the rated flow is above what 3 % speed delivers)
                          12: [(FP % 2 + ".state.speed_percent", 65.0)], 15: [(FP % 3 + ".state.speed_percent", 10.0), (FP % 3 + ".state.speed_setpoint", 3.0)]}))
+    # C22: the electrical-power gates of SecondaryReactorPhysics.update_system (secondary/__init__.py:750-932) on a plant that MAKES power (the
+    # default-configuration simulator's turbine trips on thermal expansion at its first step and the gates multiply zero from then on): the data-gen
+    # runner's plant with every feedwater pump stopped (feedwater below 300 kg/s: no electrical power whatever the turbine does), and a set-point of
+    # 160 % (clipped to 150 by the heat source)
+    S.append(dict(name="c22_power_gates", steps=30, dt=5.0, noise=True, noise_seed=42, every=1, feedwater_thresholds_only=True,
+                  runner=dict(action="oil_top_off", duration_hours=5.0),
+                  setpoints=lambda t: 160.0 if 20 <= t < 23 else None,
+                  pokes={8: [(FP % j + ".state.status", "=PumpStatus.STOPPED") for j in (1, 2, 3, 4)] + [(FP % j + ".state.speed_percent", 0.0) for j in (1, 2, 3, 4)]
+                            + [(FP % j + ".state.flow_rate", 0.0) for j in (1, 2, 3, 4)]}))
     S.extend(fuzz_scenarios())
     return S
 
