@@ -340,6 +340,10 @@ def scenarios():
         f = 1.0 / (1.0 + mm / 0.5)
         return [(STG % k + "deposit_thickness", mm) for k in range(14)] + [("~" + STG % k + "fouling_factor", f) for k in range(14)] \
             + [("~" + STG % k + "blade_condition_factor", f) for k in range(14)]
+    TT = "secondary_physics.turbine.thermal_tracker."
+
+    def stage_outlet(sim, k):
+        return float(list(sim.secondary_physics.turbine.stage_system.stages.values())[k].outlet_temperature)
     S.append(dict(name="c14_turbine_condenser_corners", steps=40, noise=True, noise_seed=9, every=1,
                   setpoints=lambda t: 100.0 if t < 24 else 35.0,
                   pokes={3: stage_deposits(2.0),
@@ -348,7 +352,13 @@ def scenarios():
                          12: [(CD + "vacuum_system.condenser_pressure", 0.02)], 14: [(CD + "vacuum_system.condenser_pressure", 0.002)],
                          16: [(CD + "vacuum_system.current_air_leakage", 0.16)],
                          20: [(CD + "tube_degradation.plugged_tube_count", 83500.0), (CD + "tube_degradation.active_tube_count", 500.0)],
-                         30: stage_deposits(0.1)}))
+                         30: stage_deposits(0.1),
+                         # the metal-temperature tracker (enhanced_physics.py:73-166): point 0 of rotor / casing / blades far above its target (the COOLING side
+                         # of the three rate clips: a start-up only ever shows the heating side), point 1 one kelvin off its target (inside the clips: the
+                         # relaxation itself, with the targets' 50 / 80 / 20 K offsets)
+                         34: [(TT + "rotor_temperatures[0]", 1000.0), (TT + "casing_temperatures[0]", 1000.0), (TT + "blade_temperatures[0]", 1000.0),
+                              (TT + "rotor_temperatures[1]", lambda sim: stage_outlet(sim, 1) - 50.0 + 1.0), (TT + "casing_temperatures[1]", lambda sim: stage_outlet(sim, 1) - 80.0 + 1.0),
+                              (TT + "blade_temperatures[1]", lambda sim: stage_outlet(sim, 1) - 20.0 + 1.0)]}))
     # C15: steam generators -- levels a hair inside the level factor's two thresholds (12.5 m, 8 m), every feedwater pump stopped under steam demand
     # (inventory depletion), a secondary pressure above the primary side's temperatures at low power (negative heat transfer), and the TSP
     # shutdown criteria one at a time: uneven deposits (maldistribution alone), a 41-year-old plate 52 % blocked (age alone)

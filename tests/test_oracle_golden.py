@@ -89,6 +89,11 @@ def test_oracle_replays_golden(oracle_lib, name):
                 for k in range(4):
                     want |= (int(ref["pump[%d].trip_active" % k]) != 0) << (8 + k)
                 assert (int(flags[0]) & ~4) == want, "%s trip flags step %d: %d, the reference's state says %d" % (name, t, int(flags[0]), want)
+        # ... and bit 2 is raised on exactly the steps whose poke put a NaN into one of the four members check_for_nan_values looks at
+        # (thermal_hydraulics.py:247-270; fixture c5) -- the generator drops every run in which a NaN arises by itself
+        nan_poked = any(isinstance(v, float) and np.isnan(v) and lab.split(".")[-1] in ("fuel_temperature", "neutron_flux", "coolant_temperature", "coolant_pressure")
+                        for lab, v in g.pokes.get(t, []))
+        assert bool(int(flags[0]) & 4) == nan_poked, "%s NaN-reset flag step %d" % (name, t)
         m = ~np.isnan(g.info[t])
         np.testing.assert_allclose(info[0][:g.info.shape[1]][m], g.info[t][m], rtol=RTOL, atol=1e-9, err_msg="%s info step %d" % (name, t))
         # the three turbine keys of info["secondary_system"] that come out of the step itself (include/npb.h NPB_INFO_TURBINE_*)
